@@ -1,0 +1,142 @@
+/*
+ * qchem_hip.h - C ABI of libqchem_hip.so, the MI355X (gfx950) Hartree-Fock hot path that sits behind the public API
+ * of qchem-rs's `core` crate.
+ *
+ * The reference has no FFI of its own; its boundary is the Rust API
+ *     core::hf::restricted_hartree_fock(&MolecularSystem, &HartreeFockConfig) -> Option<RestrictedHartreeFockOutput>
+ *     core::hf::unrestricted_hartree_fock(...)                                 (core/src/hf/rhf.rs:32, uhf.rs:36)
+ * plus the `molint` free functions those drivers call (rhf.rs:41-45, uhf.rs:52-55).  Every entry point below names
+ * the reference interface it replaces; INTEGRATION.md shows the `extern "C"` block and the safe wrapper a maintainer
+ * would add to `core/src/hf/` to route the two drivers through this library.
+ *
+ * Conventions
+ *   - plain pointers and sizes only; all matrices are n x n, f64, row-major (the ones crossing the boundary are
+ *     symmetric, so nalgebra's column-major DMatrix reads them unchanged); coordinates in bohr.
+ *   - every call returns a status: QC_OK, QC_NOT_CONVERGED (the reference's `None`), QC_DIIS_SINGULAR (the
+ *     reference's `expect("DIIS failed")` panic), or a negative error.  Nothing throws across the boundary.
+ *   - a qc_system handle owns its HIP stream and device buffers; it is not thread-safe; distinct handles may be used
+ *     from distinct threads.  No global mutable state.
+ *   - there is NO CPU fallback: any call that needs the GPU returns QC_ERR_NO_DEVICE when no gfx950 device is visible.
+ *     Creating a handle, querying sizes, the one-electron matrices and the work plan are host-only and work anywhere.
+ */
+#ifndef QCHEM_HIP_H
+#define QCHEM_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+enum {
+    QC_OK = 0,
+    QC_NOT_CONVERGED = 1,   /* rhf.rs:106-107 / uhf.rs:165-166 return None */
+    QC_DIIS_SINGULAR = 2,   /* rhf.rs:73 expect("DIIS failed") / uhf.rs:95-97 panic */
+    QC_ERR_INVALID = -1,
+    QC_ERR_NO_DEVICE = -2,
+    QC_ERR_HIP = -3,
+    QC_ERR_RCCL = -4,
+    QC_ERR_UNSUPPORTED = -5
+};
+
+typedef struct qc_system qc_system;
+
+/* ---- system model: replaces `&MolecularSystem` (molint::system, main.rs:76-77; members read at rhf.rs:36-37).
+ * Atoms: atomic numbers + xyz (bohr).  Shells are *segmented* contracted shells: centre atom index, angular momentum
+ * (0..3), pure (1 = real solid harmonics, 0 = Cartesian; ignored for L < 2), primitive count, then the primitives of
+ * all shells concatenated in `exponents` / `coefficients` (raw contraction coefficients as in the basis-set file;
+ * normalisation is done here).  Inputs are copied. */
+int qc_system_create(int natoms, const int32_t *atomic_numbers, const double *xyz,
+                     int nshells, const int32_t *shell_atom, const int32_t *shell_L, const int32_t *shell_pure,
+                     const int32_t *shell_nprim, const double *exponents, const double *coefficients,
+                     qc_system **out);
+void qc_system_destroy(qc_system *sys);
+
+int qc_nbasis(const qc_system *sys);              /* system.n_basis(), rhf.rs:37 */
+int qc_nelectrons(const qc_system *sys);          /* sum of atom.ordinal, rhf.rs:36 */
+int qc_nshells(const qc_system *sys);
+int64_t qc_nquartets(const qc_system *sys);       /* unique shell quartets (A>=B, C>=D, AB>=CD), before screening */
+double qc_nuclear_repulsion(const qc_system *sys);/* compute_nuclear_repulsion, rhf.rs:110-122 */
+
+/* ---- one-electron matrices: replace molint::overlap / kinetic / nuclear (rhf.rs:41-43).  Host code (round 1);
+ * out = caller-allocated n*n doubles. */
+int qc_overlap(const qc_system *sys, double *out);
+int qc_kinetic(const qc_system *sys, double *out);
+int qc_nuclear(const qc_system *sys, double *out);
+
+/* ---- two-electron integrals: replaces molint::eri (rhf.rs:45, uhf.rs:55).  GPU.  out = n^4 doubles on the host,
+ * row-major (i,j,k,l), chemists' notation (ij|kl) - the index order rhf.rs:60-61 reads.  Plumbing/tests only: the SCF
+ * drivers below never materialise this tensor. */
+int qc_eri_full(qc_system *sys, double *out);
+
+/* ---- Fock build: replaces compute_electronic_hamiltonian (rhf.rs:152-167 incl. the tensor of rhf.rs:58-62;
+ * uhf.rs:210-227).  GPU, direct: ERI shell quartets are evaluated and digested on the fly.
+ *   RHF:  G = J[D] - 1/2 K[D]          (D carries the factor 2 of rhf.rs:179)
+ *   UHF:  Ga = J[Da+Db] - K[Da],  Gb = J[Da+Db] - K[Db]
+ * Host pointers, n*n each.  With a communicator attached (qc_comm_init) each rank digests its shard of the quartet
+ * list and the partial matrices are summed with one RCCL all-reduce. */
+int qc_fock_rhf(qc_system *sys, const double *D, double *G);
+int qc_fock_uhf(qc_system *sys, const double *Da, const double *Db, double *Ga, double *Gb);
+/* Same with device pointers (inputs/outputs resident in HBM); asynchronous on the handle's stream. */
+int qc_fock_rhf_device(qc_system *sys, const double *dD, double *dG);
+int qc_fock_uhf_device(qc_system *sys, const double *dDa, const double *dDb, double *dGa, double *dGb);
+
+/* ---- symmetric eigensolver: replaces utils::sorted_eigs (hf/utils.rs:20-36).  GPU.  A: n*n symmetric;
+ * V: eigenvectors as columns (V[i*n+k] = component i of vector k); w ascending. */
+int qc_sym_eig(qc_system *sys, int n, const double *A, double *V, double *w);
+
+/* ---- SCF drivers: replace restricted_hartree_fock (rhf.rs:32-108) / unrestricted_hartree_fock (uhf.rs:36-167). */
+typedef struct {
+    size_t max_iterations;   /* HartreeFockConfig.max_iterations, hf/mod.rs:11 */
+    double epsilon;          /* HartreeFockConfig.epsilon, hf/mod.rs:14 */
+    /* extension block - zero-initialise for reference behaviour */
+    int32_t n_alpha;         /* UHF only; <= 0 with n_beta <= 0: the reference's rule N/2 each (uhf.rs:43-45) */
+    int32_t n_beta;
+    int32_t reserved[6];
+} qc_hf_config;
+
+typedef struct {
+    double *orbital_energies;        /* caller buffer, n doubles (RHF) - RestrictedHartreeFockOutput, rhf.rs:14-24 */
+    double *orbital_energies_beta;   /* caller buffer, n doubles (UHF beta; alpha goes to orbital_energies), uhf.rs:15-28 */
+    double electronic_energy;
+    double nuclear_repulsion;
+    size_t iterations;               /* 0-based index of the converging iteration (rhf.rs:101) */
+    /* timings of the run, milliseconds (not in the reference; the CLI prints its own wall-clock, main.rs:79-101) */
+    double ms_setup, ms_fock_total, ms_linalg_total, ms_total;
+} qc_hf_output;
+
+int qc_scf_rhf(qc_system *sys, const qc_hf_config *cfg, qc_hf_output *out);
+int qc_scf_uhf(qc_system *sys, const qc_hf_config *cfg, qc_hf_output *out);
+
+/* ---- multi-GPU (not in the reference, which is single-threaded; BASELINE.json north_star).  One process per GPU.
+ * Rank 0 calls qc_comm_unique_id, the host distributes the 128 bytes, every rank calls qc_comm_init, which creates
+ * an RCCL communicator on the current device and restricts this handle's Fock builds to shard `rank` of `nranks`. */
+int qc_comm_unique_id(uint8_t id[128]);
+int qc_comm_init(qc_system *sys, const uint8_t id[128], int rank, int nranks);
+/* Shard without a communicator (tests / external reduction): Fock builds then return the PARTIAL matrix. */
+int qc_set_shard(qc_system *sys, int rank, int nranks);
+/* Host-only view of the work plan: number of quartets and the cost-model flops assigned to a shard. */
+int qc_plan_shard(qc_system *sys, int rank, int nranks, int64_t *nquartets, double *flops);
+
+/* ---- measurement hooks */
+int qc_set_stream(qc_system *sys, void *hip_stream);  /* run on the caller's stream (e.g. torch's current stream) */
+int qc_device_ready(void);                             /* QC_OK if a gfx950 device is usable */
+/* Algorithmic work of one Fock build on this handle's shard (SURVEY.md 8d model): */
+typedef struct {
+    int64_t quartets;          /* unique shell quartets enumerated */
+    int64_t prim_quartets;     /* primitive quartets */
+    double bytes_alg;          /* pair data + 6 D blocks read + 6 F blocks read/write, bytes */
+    double flops_alg;          /* Boys + R table + Hermite contraction + digestion, flops */
+    int32_t nclasses;          /* kernel launches per build */
+} qc_work_stats;
+int qc_work_stats_get(qc_system *sys, qc_work_stats *out);
+/* Time `reps` Fock builds (RHF digestion of dD) per kernel class with hipEvents on the handle's stream.
+ * class_ms: caller buffer of `nclasses` floats (average ms per launch of each class kernel); class_id: LAB*16+LCD. */
+int qc_fock_profile(qc_system *sys, const double *dD, double *dG, int reps, float *class_ms, int32_t *class_id,
+                    int64_t *class_quartets, double *class_bytes, double *class_flops, float *total_ms);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

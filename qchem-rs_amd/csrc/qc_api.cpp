@@ -1,0 +1,596 @@
+// qc_api.cpp - the C ABI (include/qchem_hip.h) and the host-side SCF drivers.
+//
+// qc_scf_rhf / qc_scf_uhf restate the control flow of restricted_hartree_fock (core/src/hf/rhf.rs:32-108) and
+// unrestricted_hartree_fock (uhf.rs:36-167) - guess, DIIS windows, update order, energy expression, diagonal-only
+// convergence test - with every matrix resident in HBM and every O(n^3)/O(n^4) step a HIP kernel.  Only the DIIS
+// (<= 9 x 9) QR solve and the convergence decision run on the host, as they do in the reference.
+#include <rccl/rccl.h>
+
+#include <chrono>
+#include <cmath>
+#include <cstring>
+#include <deque>
+#include <new>
+
+#include "qc_internal.h"
+
+namespace {
+
+double now_ms() {
+    using namespace std::chrono;
+    return duration<double, std::milli>(steady_clock::now().time_since_epoch()).count();
+}
+
+struct DevBuf {
+    double *p = nullptr;
+    int alloc(size_t count) { return hipMalloc(&p, count * sizeof(double)) == hipSuccess ? QC_OK : QC_ERR_HIP; }
+    ~DevBuf() { if (p) (void)hipFree(p); }
+};
+
+// Householder QR solve, the arithmetic of nalgebra's `matrix.qr().solve(&b)` (diis.rs:50-51); false = zero pivot
+bool qr_solve(int m, std::vector<double> A, std::vector<double> y, std::vector<double> &x) {
+    for (int k = 0; k < m; ++k) {
+        double norm = 0.0;
+        for (int i = k; i < m; ++i) norm += A[i * m + k] * A[i * m + k];
+        norm = std::sqrt(norm);
+        if (norm == 0.0) return false;
+        const double alpha = A[k * m + k] > 0 ? -norm : norm;
+        std::vector<double> v(m, 0.0);
+        double vn = 0.0;
+        for (int i = k; i < m; ++i) { v[i] = A[i * m + k] - (i == k ? alpha : 0.0); vn += v[i] * v[i]; }
+        if (vn > 0.0) {
+            for (int j = k; j < m; ++j) {
+                double d = 0.0; for (int i = k; i < m; ++i) d += v[i] * A[i * m + j];
+                d *= 2.0 / vn; for (int i = k; i < m; ++i) A[i * m + j] -= d * v[i];
+            }
+            double d = 0.0; for (int i = k; i < m; ++i) d += v[i] * y[i];
+            d *= 2.0 / vn; for (int i = k; i < m; ++i) y[i] -= d * v[i];
+        }
+    }
+    x.assign(m, 0.0);
+    for (int i = m - 1; i >= 0; --i) {
+        double s = y[i];
+        for (int j = i + 1; j < m; ++j) s -= A[i * m + j] * x[j];
+        if (A[i * m + i] == 0.0) return false;
+        x[i] = s / A[i * m + i];
+    }
+    return true;
+}
+
+// Diis (diis.rs:6-60) with the sample window in HBM.  Newest sample first; B entries of older pairs are cached.
+struct DeviceDiis {
+    int minlen, maxlen, n;
+    std::deque<double *> err, fock;        // device matrices, newest at front
+    std::deque<std::vector<double>> dotrow; // dotrow[i][j] = <e_i, e_j> for j >= i (aligned with deque order)
+    std::vector<double *> pool;
+    double *d_dots = nullptr;
+    DeviceDiis(int mn, int mx, int n_) : minlen(mn), maxlen(mx), n(n_) {}
+    ~DeviceDiis() { for (auto p : pool) (void)hipFree(p); if (d_dots) (void)hipFree(d_dots); }
+    int init() {
+        for (int i = 0; i < 2 * (maxlen + 1); ++i) { double *p; if (hipMalloc(&p, sizeof(double) * n * n) != hipSuccess) return QC_ERR_HIP; pool.push_back(p); }
+        return hipMalloc(&d_dots, 16 * sizeof(double)) == hipSuccess ? QC_OK : QC_ERR_HIP;
+    }
+    // returns QC_OK and writes the extrapolated Fock into d_out, or QC_DIIS_SINGULAR
+    int fock_step(hipStream_t st, const double *d_err, const double *d_fock, double *d_out) {
+        const size_t bytes = sizeof(double) * n * n;
+        // push_front + truncate (diis.rs:29-30): recycle the oldest buffers
+        double *e, *f;
+        if ((int)err.size() == maxlen) { e = err.back(); f = fock.back(); err.pop_back(); fock.pop_back(); }
+        else { e = pool[2 * err.size()]; f = pool[2 * err.size() + 1]; }
+        if (hipMemcpyAsync(e, d_err, bytes, hipMemcpyDeviceToDevice, st) != hipSuccess) return QC_ERR_HIP;
+        if (hipMemcpyAsync(f, d_fock, bytes, hipMemcpyDeviceToDevice, st) != hipSuccess) return QC_ERR_HIP;
+        err.push_front(e); fock.push_front(f);
+        const int m = (int)err.size();
+        if (m < minlen) {       // diis.rs:33-38: not enough samples, hand back the newest Fock
+            if (hipMemcpyAsync(d_out, f, bytes, hipMemcpyDeviceToDevice, st) != hipSuccess) return QC_ERR_HIP;
+            // keep the dot cache aligned even while DIIS is idle
+        }
+        // new row of B: <e_0, e_j> for all j in the window
+        std::vector<const double *> ys(err.begin(), err.end());
+        qc_dots(st, n, e, ys.data(), m, d_dots);
+        std::vector<double> row(m);
+        if (hipMemcpyAsync(row.data(), d_dots, m * sizeof(double), hipMemcpyDeviceToHost, st) != hipSuccess) return QC_ERR_HIP;
+        if (hipStreamSynchronize(st) != hipSuccess) return QC_ERR_HIP;
+        dotrow.push_front(row);
+        if ((int)dotrow.size() > maxlen) dotrow.pop_back();
+        for (size_t i = 1; i < dotrow.size(); ++i) if ((int)dotrow[i].size() > m - (int)i) dotrow[i].resize(m - i);
+        if (m < minlen) return QC_OK;
+        std::vector<double> B((size_t)(m + 1) * (m + 1), 0.0), rhs(m + 1, 0.0), c;
+        for (int i = 0; i < m; ++i)
+            for (int j = i; j < m; ++j) B[i * (m + 1) + j] = B[j * (m + 1) + i] = dotrow[i][j - i];
+        for (int i = 0; i < m; ++i) B[i * (m + 1) + m] = B[m * (m + 1) + i] = 1.0;   // border +1, corner 0 (diis.rs:40-46)
+        rhs[m] = 1.0;
+        if (!qr_solve(m + 1, B, rhs, c)) return QC_DIIS_SINGULAR;
+        std::vector<const double *> fs(fock.begin(), fock.end());
+        qc_lincomb(st, n, fs.data(), c.data(), m, d_out);
+        return QC_OK;
+    }
+};
+
+struct ScfWork {
+    int n;
+    DevBuf H, S, X, t1, t2, Fp, Cp, C, w, ework, Fd, scal;
+    int init(int n_) {
+        n = n_;
+        const size_t nn = (size_t)n * n;
+        DevBuf *all[] = {&H, &S, &X, &t1, &t2, &Fp, &Cp, &C, &ework, &Fd};
+        for (auto b : all) if (b->alloc(nn) != QC_OK) return QC_ERR_HIP;
+        if (w.alloc(n) != QC_OK || scal.alloc(16) != QC_OK) return QC_ERR_HIP;
+        return QC_OK;
+    }
+};
+
+// sorted_eigs on device (utils.rs:20-36): Fp -> (Cp, w)
+int device_sorted_eigs(qc_system *S, ScfWork &W, double *dA, double *dV, double *dw) {
+    return qc_eig_device(S->stream, W.n, dA, dV, dw, W.ework.p);
+}
+
+// start-up shared by both drivers: H = T + V, X = S^-1/2 (rhf.rs:124-131), Hückel matrix (rhf.rs:141-143)
+int scf_setup(qc_system *S, ScfWork &W, std::vector<double> &h_eht) {
+    const int n = S->nbasis;
+    const size_t nn = (size_t)n * n;
+    std::vector<double> s(nn), t(nn), v(nn), h(nn);
+    qc_host_one_electron(S, 0, s.data());
+    qc_host_one_electron(S, 1, t.data());
+    qc_host_one_electron(S, 2, v.data());
+    for (size_t k = 0; k < nn; ++k) h[k] = t[k] + v[k];
+    h_eht.assign(nn, 0.0);
+    for (int i = 0; i < n; ++i)
+        for (int j = i; j < n; ++j)
+            h_eht[(size_t)i * n + j] = h_eht[(size_t)j * n + i] = 1.75 * s[(size_t)i * n + j] * (h[(size_t)i * n + i] + h[(size_t)j * n + j]) / 2.0;
+    hipStream_t st = S->stream;
+    QC_HIP_CHECK(hipMemcpyAsync(W.S.p, s.data(), nn * sizeof(double), hipMemcpyHostToDevice, st));
+    QC_HIP_CHECK(hipMemcpyAsync(W.H.p, h.data(), nn * sizeof(double), hipMemcpyHostToDevice, st));
+    QC_HIP_CHECK(hipStreamSynchronize(st));
+    // X = U (diag((U^T S U)_ii^-1/2) U^T): note the diagonal of the product, not the returned eigenvalues
+    int rc = device_sorted_eigs(S, W, W.S.p, W.Cp.p, W.w.p);          // U (column order is immaterial for X)
+    if (rc != QC_OK) return rc;
+    qc_gemm(st, n, n, n, 1.0, W.S.p, n, false, W.Cp.p, n, false, 0.0, W.t1.p, n);      // S U
+    qc_gemm(st, n, n, n, 1.0, W.Cp.p, n, true, W.t1.p, n, false, 0.0, W.t2.p, n);      // U^T (S U)
+    qc_scale_cols_invsqrt(st, n, W.Cp.p, W.t2.p, W.t1.p);                               // U diag^-1/2
+    qc_gemm(st, n, n, n, 1.0, W.t1.p, n, false, W.Cp.p, n, true, 0.0, W.X.p, n);       // (.) U^T
+    return QC_OK;
+}
+
+// compute_hückel_density (rhf.rs:133-150): D = factor * C_occ C_occ^T with C = X eigvecs(X^T H_eht X)
+int huckel_density(qc_system *S, ScfWork &W, const std::vector<double> &h_eht, int nocc, double factor, double *dD) {
+    const int n = S->nbasis;
+    hipStream_t st = S->stream;
+    QC_HIP_CHECK(hipMemcpyAsync(W.Fd.p, h_eht.data(), h_eht.size() * sizeof(double), hipMemcpyHostToDevice, st));
+    qc_gemm(st, n, n, n, 1.0, W.Fd.p, n, false, W.X.p, n, false, 0.0, W.t1.p, n);
+    qc_gemm(st, n, n, n, 1.0, W.X.p, n, true, W.t1.p, n, false, 0.0, W.Fp.p, n);
+    int rc = device_sorted_eigs(S, W, W.Fp.p, W.Cp.p, W.w.p);
+    if (rc != QC_OK) return rc;
+    qc_gemm(st, n, n, n, 1.0, W.X.p, n, false, W.Cp.p, n, false, 0.0, W.C.p, n);
+    if (nocc > 0) qc_gemm(st, n, n, nocc, factor, W.C.p, n, false, W.C.p, n, true, 0.0, dD, n);
+    else QC_HIP_CHECK(hipMemsetAsync(dD, 0, sizeof(double) * n * n, st));
+    return QC_OK;
+}
+
+// One spin's Roothaan step: F = H + G; e = FDS - SDF; DIIS; F' = X^T F X; eig; C = X C'   (rhf.rs:70-76)
+int roothaan_step(qc_system *S, ScfWork &W, DeviceDiis &diis, const double *dG, const double *dD, double *dw_out) {
+    const int n = S->nbasis;
+    hipStream_t st = S->stream;
+    qc_axpby(st, n, 1.0, W.H.p, 1.0, dG, W.t1.p);                                        // F
+    qc_gemm(st, n, n, n, 1.0, W.t1.p, n, false, dD, n, false, 0.0, W.t2.p, n);           // F D
+    qc_gemm(st, n, n, n, 1.0, W.t2.p, n, false, W.S.p, n, false, 0.0, W.Fp.p, n);        // F D S
+    qc_sub_transpose(st, n, W.Fp.p, W.t2.p);                                             // e = FDS - (FDS)^T = FDS - SDF
+    int rc = diis.fock_step(st, W.t2.p, W.t1.p, W.Fd.p);
+    if (rc != QC_OK) return rc;
+    qc_gemm(st, n, n, n, 1.0, W.Fd.p, n, false, W.X.p, n, false, 0.0, W.t1.p, n);        // F X
+    qc_gemm(st, n, n, n, 1.0, W.X.p, n, true, W.t1.p, n, false, 0.0, W.Fp.p, n);         // X^T (F X)
+    rc = device_sorted_eigs(S, W, W.Fp.p, W.Cp.p, dw_out);
+    if (rc != QC_OK) return rc;
+    qc_gemm(st, n, n, n, 1.0, W.X.p, n, false, W.Cp.p, n, false, 0.0, W.C.p, n);         // C = X C'
+    return QC_OK;
+}
+
+}  // namespace
+
+// =============================================================================================== C ABI
+extern "C" {
+
+int qc_system_create(int natoms, const int32_t *Z, const double *xyz, int nshells, const int32_t *shell_atom, const int32_t *shell_L,
+                     const int32_t *shell_pure, const int32_t *shell_nprim, const double *exponents, const double *coefficients,
+                     qc_system **out) {
+    if (!out || natoms <= 0 || nshells <= 0 || !Z || !xyz || !shell_atom || !shell_L || !shell_nprim || !exponents || !coefficients) return QC_ERR_INVALID;
+    qc_system *S = new (std::nothrow) qc_system();
+    if (!S) return QC_ERR_INVALID;
+    S->natoms = natoms; S->nshells = nshells;
+    S->Z.assign(Z, Z + natoms);
+    S->xyz.assign(xyz, xyz + 3 * natoms);
+    size_t po = 0;
+    for (int s = 0; s < nshells; ++s) {
+        QcShell sh{};
+        sh.atom = shell_atom[s]; sh.L = shell_L[s]; sh.nprim = shell_nprim[s];
+        sh.pure = (shell_pure && shell_pure[s] && sh.L >= 2) ? 1 : 0;
+        if (sh.atom < 0 || sh.atom >= natoms || sh.nprim <= 0 || sh.L < 0) { delete S; return QC_ERR_INVALID; }
+        if (sh.L > QC_LMAX) { delete S; return QC_ERR_UNSUPPORTED; }
+        sh.exps.assign(exponents + po, exponents + po + sh.nprim);
+        sh.coefs.assign(coefficients + po, coefficients + po + sh.nprim);
+        po += sh.nprim;
+        S->shells.push_back(std::move(sh));
+    }
+    qc_build_model(S);
+    *out = S;
+    return QC_OK;
+}
+
+void qc_system_destroy(qc_system *S) {
+    if (!S) return;
+    if (S->comm) { ncclCommDestroy((ncclComm_t)S->comm); S->comm = nullptr; }
+    qc_device_free(S);
+    delete S;
+}
+
+int qc_nbasis(const qc_system *S) { return S ? S->nbasis : QC_ERR_INVALID; }
+int qc_nelectrons(const qc_system *S) { return S ? S->nelec : QC_ERR_INVALID; }
+int qc_nshells(const qc_system *S) { return S ? S->nshells : QC_ERR_INVALID; }
+int64_t qc_nquartets(const qc_system *S) { return S ? S->nquartets : QC_ERR_INVALID; }
+
+double qc_nuclear_repulsion(const qc_system *S) {
+    double e = 0.0;
+    for (int a = 0; a < S->natoms; ++a)
+        for (int b = a + 1; b < S->natoms; ++b) {
+            double d2 = 0.0;
+            for (int k = 0; k < 3; ++k) { const double x = S->xyz[3 * b + k] - S->xyz[3 * a + k]; d2 += x * x; }
+            e += (double)(S->Z[a] * S->Z[b]) / std::sqrt(d2);
+        }
+    return e;
+}
+
+int qc_overlap(const qc_system *S, double *out) { if (!S || !out) return QC_ERR_INVALID; qc_host_one_electron(S, 0, out); return QC_OK; }
+int qc_kinetic(const qc_system *S, double *out) { if (!S || !out) return QC_ERR_INVALID; qc_host_one_electron(S, 1, out); return QC_OK; }
+int qc_nuclear(const qc_system *S, double *out) { if (!S || !out) return QC_ERR_INVALID; qc_host_one_electron(S, 2, out); return QC_OK; }
+
+int qc_set_stream(qc_system *S, void *hip_stream) {
+    if (!S) return QC_ERR_INVALID;
+    if (S->own_stream && S->stream) { (void)hipStreamDestroy(S->stream); S->own_stream = false; }
+    S->stream = (hipStream_t)hip_stream;
+    if (!S->stream && S->device_ready) { QC_HIP_CHECK(hipStreamCreateWithFlags(&S->stream, hipStreamNonBlocking)); S->own_stream = true; }
+    return QC_OK;
+}
+
+int qc_eri_full(qc_system *S, double *out) {
+    if (!S || !out) return QC_ERR_INVALID;
+    int rc = qc_device_init(S);
+    if (rc != QC_OK) return rc;
+    if (S->nranks != 1) return QC_ERR_INVALID;
+    const size_t n = S->nbasis, n4 = n * n * n * n;
+    DevBuf T;
+    if (T.alloc(n4) != QC_OK) return QC_ERR_HIP;
+    QC_HIP_CHECK(hipMemsetAsync(T.p, 0, n4 * sizeof(double), S->stream));
+    QcFockArgs a{};
+    a.eri_out = T.p;
+    rc = qc_launch_fock_classes(S, a, nullptr);
+    if (rc != QC_OK) return rc;
+    QC_HIP_CHECK(hipMemcpyAsync(out, T.p, n4 * sizeof(double), hipMemcpyDeviceToHost, S->stream));
+    QC_HIP_CHECK(hipStreamSynchronize(S->stream));
+    return QC_OK;
+}
+
+}  // extern "C"
+
+int qc_fock_build_device(qc_system *S, const double *dDa, const double *dDb, double *dGa, double *dGb, bool uhf) {
+    const int n = S->nbasis;
+    const size_t nn = (size_t)n * n;
+    hipStream_t st = S->stream;
+    const int nspin = uhf ? 2 : 1;
+    QC_HIP_CHECK(hipMemsetAsync(S->d_Gtmp, 0, nspin * nn * sizeof(double), st));
+    QcFockArgs a{};
+    if (uhf) {
+        qc_axpby(st, n, 1.0, dDa, 1.0, dDb, S->d_Dj);
+        a.Dj = S->d_Dj; a.Dk0 = dDa; a.Dk1 = dDb; a.cK = 1.0;
+    } else {
+        a.Dj = dDa; a.Dk0 = dDa; a.Dk1 = nullptr; a.cK = 0.5;
+    }
+    a.G0 = S->d_Gtmp; a.G1 = S->d_Gtmp + nn;
+    int rc = qc_launch_fock_classes(S, a, nullptr);
+    if (rc != QC_OK) return rc;
+    if (S->comm) {   // partial Fock matrices -> full, one all-reduce per build ([Ga|Gb] concatenated for UHF)
+        if (ncclAllReduce(S->d_Gtmp, S->d_Gtmp, nspin * nn, ncclDouble, ncclSum, (ncclComm_t)S->comm, st) != ncclSuccess) return QC_ERR_RCCL;
+    }
+    qc_symmetrize_add(st, n, S->d_Gtmp, dGa);
+    if (uhf) qc_symmetrize_add(st, n, S->d_Gtmp + nn, dGb);
+    return QC_OK;
+}
+
+extern "C" {
+
+int qc_fock_rhf_device(qc_system *S, const double *dD, double *dG) {
+    if (!S || !dD || !dG) return QC_ERR_INVALID;
+    int rc = qc_device_init(S);
+    if (rc != QC_OK) return rc;
+    return qc_fock_build_device(S, dD, nullptr, dG, nullptr, false);
+}
+int qc_fock_uhf_device(qc_system *S, const double *dDa, const double *dDb, double *dGa, double *dGb) {
+    if (!S || !dDa || !dDb || !dGa || !dGb) return QC_ERR_INVALID;
+    int rc = qc_device_init(S);
+    if (rc != QC_OK) return rc;
+    return qc_fock_build_device(S, dDa, dDb, dGa, dGb, true);
+}
+
+int qc_fock_rhf(qc_system *S, const double *D, double *G) {
+    if (!S || !D || !G) return QC_ERR_INVALID;
+    int rc = qc_device_init(S);
+    if (rc != QC_OK) return rc;
+    const size_t nn = (size_t)S->nbasis * S->nbasis;
+    QC_HIP_CHECK(hipMemcpyAsync(S->d_D, D, nn * sizeof(double), hipMemcpyHostToDevice, S->stream));
+    rc = qc_fock_build_device(S, S->d_D, nullptr, S->d_G, nullptr, false);
+    if (rc != QC_OK) return rc;
+    QC_HIP_CHECK(hipMemcpyAsync(G, S->d_G, nn * sizeof(double), hipMemcpyDeviceToHost, S->stream));
+    QC_HIP_CHECK(hipStreamSynchronize(S->stream));
+    return QC_OK;
+}
+
+int qc_fock_uhf(qc_system *S, const double *Da, const double *Db, double *Ga, double *Gb) {
+    if (!S || !Da || !Db || !Ga || !Gb) return QC_ERR_INVALID;
+    int rc = qc_device_init(S);
+    if (rc != QC_OK) return rc;
+    const size_t nn = (size_t)S->nbasis * S->nbasis;
+    QC_HIP_CHECK(hipMemcpyAsync(S->d_D, Da, nn * sizeof(double), hipMemcpyHostToDevice, S->stream));
+    QC_HIP_CHECK(hipMemcpyAsync(S->d_D + nn, Db, nn * sizeof(double), hipMemcpyHostToDevice, S->stream));
+    rc = qc_fock_build_device(S, S->d_D, S->d_D + nn, S->d_G, S->d_G + nn, true);
+    if (rc != QC_OK) return rc;
+    QC_HIP_CHECK(hipMemcpyAsync(Ga, S->d_G, nn * sizeof(double), hipMemcpyDeviceToHost, S->stream));
+    QC_HIP_CHECK(hipMemcpyAsync(Gb, S->d_G + nn, nn * sizeof(double), hipMemcpyDeviceToHost, S->stream));
+    QC_HIP_CHECK(hipStreamSynchronize(S->stream));
+    return QC_OK;
+}
+
+int qc_sym_eig(qc_system *S, int n, const double *A, double *V, double *w) {
+    if (!S || n <= 0 || !A || !V || !w) return QC_ERR_INVALID;
+    int rc = qc_device_init(S);
+    if (rc != QC_OK) return rc;
+    const size_t nn = (size_t)n * n;
+    DevBuf dA, dV, dw, dwork;
+    if (dA.alloc(nn) != QC_OK || dV.alloc(nn) != QC_OK || dw.alloc(n) != QC_OK || dwork.alloc(nn) != QC_OK) return QC_ERR_HIP;
+    QC_HIP_CHECK(hipMemcpyAsync(dA.p, A, nn * sizeof(double), hipMemcpyHostToDevice, S->stream));
+    rc = qc_eig_device(S->stream, n, dA.p, dV.p, dw.p, dwork.p);
+    if (rc != QC_OK) return rc;
+    QC_HIP_CHECK(hipMemcpyAsync(V, dV.p, nn * sizeof(double), hipMemcpyDeviceToHost, S->stream));
+    QC_HIP_CHECK(hipMemcpyAsync(w, dw.p, n * sizeof(double), hipMemcpyDeviceToHost, S->stream));
+    QC_HIP_CHECK(hipStreamSynchronize(S->stream));
+    return QC_OK;
+}
+
+// restricted_hartree_fock (rhf.rs:32-108)
+int qc_scf_rhf(qc_system *S, const qc_hf_config *cfg, qc_hf_output *out) {
+    if (!S || !cfg || !out || !out->orbital_energies) return QC_ERR_INVALID;
+    const double t_begin = now_ms();
+    int rc = qc_device_init(S);
+    if (rc != QC_OK) return rc;
+    const int n = S->nbasis, nocc = S->nelec / 2;                       // rhf.rs:36-37, :176
+    const size_t nn = (size_t)n * n;
+    hipStream_t st = S->stream;
+    ScfWork W;
+    if ((rc = W.init(n)) != QC_OK) return rc;
+    DevBuf D, Dn, G;
+    if (D.alloc(nn) != QC_OK || Dn.alloc(nn) != QC_OK || G.alloc(nn) != QC_OK) return QC_ERR_HIP;
+    out->nuclear_repulsion = qc_nuclear_repulsion(S);                   // rhf.rs:39
+    out->electronic_energy = 0.0; out->iterations = 0;
+    out->ms_fock_total = out->ms_linalg_total = 0.0;
+    std::vector<double> h_eht;
+    if ((rc = scf_setup(S, W, h_eht)) != QC_OK) return rc;              // rhf.rs:41-49
+    if ((rc = huckel_density(S, W, h_eht, nocc, 2.0, D.p)) != QC_OK) return rc;   // rhf.rs:50
+    DeviceDiis diis(4, 6, n);                                           // rhf.rs:65
+    if ((rc = diis.init()) != QC_OK) return rc;
+    QC_HIP_CHECK(hipStreamSynchronize(st));
+    out->ms_setup = now_ms() - t_begin;
+    hipEvent_t ev0, ev1, ev2;
+    QC_HIP_CHECK(hipEventCreate(&ev0)); QC_HIP_CHECK(hipEventCreate(&ev1)); QC_HIP_CHECK(hipEventCreate(&ev2));
+    int status = QC_NOT_CONVERGED;
+    for (size_t it = 0; it <= cfg->max_iterations; ++it) {              // rhf.rs:66 (inclusive range)
+        QC_HIP_CHECK(hipEventRecord(ev0, st));
+        if ((rc = qc_fock_build_device(S, D.p, nullptr, G.p, nullptr, false)) != QC_OK) { status = rc; break; }   // rhf.rs:67-68
+        QC_HIP_CHECK(hipEventRecord(ev1, st));
+        rc = roothaan_step(S, W, diis, G.p, D.p, W.w.p);                // rhf.rs:70-76
+        if (rc != QC_OK) { status = rc; break; }
+        qc_gemm(st, n, n, nocc, 2.0, W.C.p, n, false, W.C.p, n, true, 0.0, Dn.p, n);    // rhf.rs:78
+        qc_energy_rms(st, n, Dn.p, D.p, W.H.p, G.p, W.scal.p);          // rhf.rs:84-88 (updated D, G of this iteration)
+        double er[2];
+        QC_HIP_CHECK(hipMemcpyAsync(er, W.scal.p, 2 * sizeof(double), hipMemcpyDeviceToHost, st));
+        QC_HIP_CHECK(hipMemcpyAsync(D.p, Dn.p, nn * sizeof(double), hipMemcpyDeviceToDevice, st));   // D += 1.0 * dD (rhf.rs:80-82)
+        QC_HIP_CHECK(hipEventRecord(ev2, st));
+        QC_HIP_CHECK(hipStreamSynchronize(st));
+        float ms_f = 0, ms_l = 0;
+        (void)hipEventElapsedTime(&ms_f, ev0, ev1); (void)hipEventElapsedTime(&ms_l, ev1, ev2);
+        out->ms_fock_total += ms_f; out->ms_linalg_total += ms_l;
+        const double rms = std::sqrt(er[1] / n);
+        if (rms < cfg->epsilon) {                                       // rhf.rs:94
+            out->electronic_energy = er[0];
+            out->iterations = it;
+            QC_HIP_CHECK(hipMemcpy(out->orbital_energies, W.w.p, n * sizeof(double), hipMemcpyDeviceToHost));
+            status = QC_OK;
+            break;
+        }
+    }
+    (void)hipEventDestroy(ev0); (void)hipEventDestroy(ev1); (void)hipEventDestroy(ev2);
+    out->ms_total = now_ms() - t_begin;
+    return status;
+}
+
+// unrestricted_hartree_fock (uhf.rs:36-167); n_alpha/n_beta extension per SURVEY.md 8f item 4
+int qc_scf_uhf(qc_system *S, const qc_hf_config *cfg, qc_hf_output *out) {
+    if (!S || !cfg || !out || !out->orbital_energies || !out->orbital_energies_beta) return QC_ERR_INVALID;
+    const double t_begin = now_ms();
+    int rc = qc_device_init(S);
+    if (rc != QC_OK) return rc;
+    const int n = S->nbasis;
+    int nocc[2] = {S->nelec / 2, S->nelec / 2};                        // uhf.rs:43-45
+    if (cfg->n_alpha > 0 || cfg->n_beta > 0) { nocc[0] = cfg->n_alpha; nocc[1] = cfg->n_beta; }
+    if (nocc[0] < 0 || nocc[1] < 0 || nocc[0] > n || nocc[1] > n) return QC_ERR_INVALID;
+    const size_t nn = (size_t)n * n;
+    hipStream_t st = S->stream;
+    ScfWork W;
+    if ((rc = W.init(n)) != QC_OK) return rc;
+    DevBuf D, Dn, G, Cs, ws;                                            // two spins back to back
+    if (D.alloc(2 * nn) != QC_OK || Dn.alloc(nn) != QC_OK || G.alloc(2 * nn) != QC_OK || Cs.alloc(2 * nn) != QC_OK || ws.alloc(2 * n) != QC_OK) return QC_ERR_HIP;
+    out->nuclear_repulsion = qc_nuclear_repulsion(S);
+    out->electronic_energy = 0.0; out->iterations = 0;
+    out->ms_fock_total = out->ms_linalg_total = 0.0;
+    std::vector<double> h_eht;
+    if ((rc = scf_setup(S, W, h_eht)) != QC_OK) return rc;
+    for (int s = 0; s < 2; ++s)                                         // uhf.rs:60-63 (same guess, no factor 2)
+        if ((rc = huckel_density(S, W, h_eht, nocc[s], 1.0, D.p + s * nn)) != QC_OK) return rc;
+    DeviceDiis diis0(2, 8, n), diis1(2, 8, n);                          // uhf.rs:76-78
+    if ((rc = diis0.init()) != QC_OK || (rc = diis1.init()) != QC_OK) return rc;
+    DeviceDiis *diis[2] = {&diis0, &diis1};
+    QC_HIP_CHECK(hipStreamSynchronize(st));
+    out->ms_setup = now_ms() - t_begin;
+    hipEvent_t ev0, ev1, ev2;
+    QC_HIP_CHECK(hipEventCreate(&ev0)); QC_HIP_CHECK(hipEventCreate(&ev1)); QC_HIP_CHECK(hipEventCreate(&ev2));
+    int status = QC_NOT_CONVERGED;
+    for (size_t it = 0; it <= cfg->max_iterations && status == QC_NOT_CONVERGED; ++it) {
+        QC_HIP_CHECK(hipEventRecord(ev0, st));
+        // both spins' G from the *old* densities in one pass over the ERIs (uhf.rs:81-108)
+        if ((rc = qc_fock_build_device(S, D.p, D.p + nn, G.p, G.p + nn, true)) != QC_OK) { status = rc; break; }
+        QC_HIP_CHECK(hipEventRecord(ev1, st));
+        for (int s = 0; s < 2; ++s) {
+            rc = roothaan_step(S, W, *diis[s], G.p + s * nn, D.p + s * nn, ws.p + s * n);
+            if (rc != QC_OK) { status = rc; break; }
+            QC_HIP_CHECK(hipMemcpyAsync(Cs.p + s * nn, W.C.p, nn * sizeof(double), hipMemcpyDeviceToDevice, st));
+        }
+        if (status != QC_NOT_CONVERGED) break;
+        double rms_sum = 0.0, e_sum = 0.0;
+        for (int s = 0; s < 2; ++s) {                                   // uhf.rs:112-135
+            if (nocc[s] > 0) qc_gemm(st, n, n, nocc[s], 1.0, Cs.p + s * nn, n, false, Cs.p + s * nn, n, true, 0.0, Dn.p, n);
+            else QC_HIP_CHECK(hipMemsetAsync(Dn.p, 0, nn * sizeof(double), st));
+            qc_energy_rms(st, n, Dn.p, D.p + s * nn, W.H.p, G.p + s * nn, W.scal.p);
+            double er[2];
+            QC_HIP_CHECK(hipMemcpyAsync(er, W.scal.p, 2 * sizeof(double), hipMemcpyDeviceToHost, st));
+            QC_HIP_CHECK(hipMemcpyAsync(D.p + s * nn, Dn.p, nn * sizeof(double), hipMemcpyDeviceToDevice, st));
+            QC_HIP_CHECK(hipStreamSynchronize(st));
+            rms_sum += std::sqrt(er[1] / n);
+            e_sum += er[0];
+        }
+        QC_HIP_CHECK(hipEventRecord(ev2, st));
+        QC_HIP_CHECK(hipStreamSynchronize(st));
+        float ms_f = 0, ms_l = 0;
+        (void)hipEventElapsedTime(&ms_f, ev0, ev1); (void)hipEventElapsedTime(&ms_l, ev1, ev2);
+        out->ms_fock_total += ms_f; out->ms_linalg_total += ms_l;
+        const double density_rms = rms_sum / 2.0;                       // uhf.rs:137
+        if (density_rms / 2.0 < cfg->epsilon) {                         // uhf.rs:139
+            out->electronic_energy = e_sum;                             // uhf.rs:145-153
+            out->iterations = it;
+            QC_HIP_CHECK(hipMemcpy(out->orbital_energies, ws.p, n * sizeof(double), hipMemcpyDeviceToHost));
+            QC_HIP_CHECK(hipMemcpy(out->orbital_energies_beta, ws.p + n, n * sizeof(double), hipMemcpyDeviceToHost));
+            status = QC_OK;
+        }
+    }
+    (void)hipEventDestroy(ev0); (void)hipEventDestroy(ev1); (void)hipEventDestroy(ev2);
+    out->ms_total = now_ms() - t_begin;
+    return status;
+}
+
+// ---- multi-GPU
+int qc_comm_unique_id(uint8_t id[128]) {
+    static_assert(sizeof(ncclUniqueId) == 128, "ncclUniqueId size");
+    ncclUniqueId u;
+    if (ncclGetUniqueId(&u) != ncclSuccess) return QC_ERR_RCCL;
+    std::memcpy(id, &u, 128);
+    return QC_OK;
+}
+
+int qc_set_shard(qc_system *S, int rank, int nranks) {
+    if (!S || nranks <= 0 || rank < 0 || rank >= nranks) return QC_ERR_INVALID;
+    S->rank = rank; S->nranks = nranks;
+    return qc_device_reshard(S);
+}
+
+int qc_comm_init(qc_system *S, const uint8_t id[128], int rank, int nranks) {
+    if (!S || !id) return QC_ERR_INVALID;
+    int rc = qc_device_init(S);
+    if (rc != QC_OK) return rc;
+    if ((rc = qc_set_shard(S, rank, nranks)) != QC_OK) return rc;
+    ncclUniqueId u;
+    std::memcpy(&u, id, 128);
+    ncclComm_t comm;
+    if (ncclCommInitRank(&comm, nranks, u, rank) != ncclSuccess) return QC_ERR_RCCL;
+    S->comm = comm;
+    return QC_OK;
+}
+
+int qc_plan_shard(qc_system *S, int rank, int nranks, int64_t *nquartets, double *flops) {
+    if (!S || nranks <= 0 || rank < 0 || rank >= nranks) return QC_ERR_INVALID;
+    const int r0 = S->rank, n0 = S->nranks;
+    S->rank = rank; S->nranks = nranks;
+    qc_build_shards(S);
+    int64_t nq = 0; double fl = 0.0;
+    for (const auto &c : S->classes) { nq += (int64_t)c.shard.size(); fl += c.flops_alg; }
+    if (nquartets) *nquartets = nq;
+    if (flops) *flops = fl;
+    S->rank = r0; S->nranks = n0;
+    qc_build_shards(S);
+    return QC_OK;
+}
+
+// list the quartets of a shard as (shell A, B, C, D) so a host-side checker can digest exactly the same units
+int qc_plan_shard_quartets(qc_system *S, int rank, int nranks, int32_t *abcd /* 4 * nquartets or NULL */, int64_t capacity) {
+    if (!S || nranks <= 0 || rank < 0 || rank >= nranks) return QC_ERR_INVALID;
+    int64_t k = 0;
+    for (const auto &c : S->classes)
+        for (size_t i = 0; i < c.tasks.size(); ++i) {
+            if ((int)(i % nranks) != rank) continue;
+            if (abcd) {
+                if (k >= capacity) return QC_ERR_INVALID;
+                abcd[4 * k + 0] = S->pairA[c.tasks[i].bra]; abcd[4 * k + 1] = S->pairB[c.tasks[i].bra];
+                abcd[4 * k + 2] = S->pairA[c.tasks[i].ket]; abcd[4 * k + 3] = S->pairB[c.tasks[i].ket];
+            }
+            ++k;
+        }
+    return (int)k;
+}
+
+int qc_work_stats_get(qc_system *S, qc_work_stats *out) {
+    if (!S || !out) return QC_ERR_INVALID;
+    std::memset(out, 0, sizeof(*out));
+    for (const auto &c : S->classes) {
+        if (c.shard.empty()) continue;
+        out->quartets += (int64_t)c.shard.size(); out->prim_quartets += c.prim_quartets;
+        out->bytes_alg += c.bytes_alg; out->flops_alg += c.flops_alg; out->nclasses += 1;
+    }
+    return QC_OK;
+}
+
+int qc_fock_profile(qc_system *S, const double *dD, double *dG, int reps, float *class_ms, int32_t *class_id, int64_t *class_quartets,
+                    double *class_bytes, double *class_flops, float *total_ms) {
+    if (!S || !dD || !dG || reps <= 0) return QC_ERR_INVALID;
+    int rc = qc_device_init(S);
+    if (rc != QC_OK) return rc;
+    const int n = S->nbasis;
+    const size_t nn = (size_t)n * n;
+    std::vector<float> acc(S->classes.size(), 0.f), one(S->classes.size(), 0.f);
+    float tot = 0.f;
+    hipEvent_t e0, e1;
+    QC_HIP_CHECK(hipEventCreate(&e0)); QC_HIP_CHECK(hipEventCreate(&e1));
+    for (int r = 0; r < reps; ++r) {
+        QC_HIP_CHECK(hipMemsetAsync(S->d_Gtmp, 0, nn * sizeof(double), S->stream));
+        QcFockArgs a{};
+        a.Dj = dD; a.Dk0 = dD; a.Dk1 = nullptr; a.cK = 0.5; a.G0 = S->d_Gtmp; a.G1 = S->d_Gtmp + nn;
+        if ((rc = qc_launch_fock_classes(S, a, one.data())) != QC_OK) return rc;
+        for (size_t i = 0; i < acc.size(); ++i) acc[i] += one[i];
+        // un-instrumented whole build for the total
+        QC_HIP_CHECK(hipEventRecord(e0, S->stream));
+        if ((rc = qc_fock_build_device(S, dD, nullptr, dG, nullptr, false)) != QC_OK) return rc;
+        QC_HIP_CHECK(hipEventRecord(e1, S->stream));
+        QC_HIP_CHECK(hipEventSynchronize(e1));
+        float ms; (void)hipEventElapsedTime(&ms, e0, e1); tot += ms;
+    }
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    int k = 0;
+    for (size_t i = 0; i < S->classes.size(); ++i) {
+        const QcClass &c = S->classes[i];
+        if (c.shard.empty()) continue;
+        if (class_ms) class_ms[k] = acc[i] / reps;
+        if (class_id) class_id[k] = c.LAB * 16 + c.LCD;
+        if (class_quartets) class_quartets[k] = (int64_t)c.shard.size();
+        if (class_bytes) class_bytes[k] = c.bytes_alg;
+        if (class_flops) class_flops[k] = c.flops_alg;
+        ++k;
+    }
+    if (total_ms) *total_ms = tot / reps;
+    return QC_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,304 @@
+// qc_fock_kernel.h - the direct-SCF ERI + Fock digestion kernel for one quartet class (LAB | LCD), gfx950 / wave64.
+//
+// Replaces molint::eri (rhf.rs:45) fused with compute_electronic_hamiltonian (rhf.rs:152-167, uhf.rs:210-227): every
+// unique shell quartet (ab|cd) is evaluated by McMurchie-Davidson in the *Hermite-matrix* form
+//        (ab|cd) = sum_{ij in ab} sum_{kl in cd}  E_ab,ij^T  .  Rmat(p_ij, q_kl)  .  E_cd,kl
+// (E = per-primitive-pair Hermite expansion matrices prepared once per geometry, spherical transform and contraction
+// coefficients folded in; Rmat[h1][h2] = (-1)^{|h2|} R_{h1+h2}) and immediately contracted with the density into the
+// six J/K blocks.  f64 throughout.
+//
+// Mapping (one wave = one workgroup = one quartet at a time, grid-stride over the class's task list):
+//   lanes = G groups x C columns, C = pow2 >= n_cd (ket function pairs), G = 64 / C.
+//   * a lane owns one ket column cd: its ket expansion column e[HCD] and the half-contracted W[HAB] live in VGPRs;
+//   * the G groups split the primitive quartets of a contracted quartet (each group has its own R table in LDS);
+//     for (ss|ss) this degenerates to one primitive quartet per lane, for high-L classes to one R table per wave;
+//   * R tables are built cooperatively by the C lanes of a group in LDS; step 2 reads each R_s once (gen_step2.py);
+//   * the contracted block I[ab][cd] is accumulated in LDS (ds_add_f64), density tiles are staged in LDS, and the six
+//     J/K block updates are reduced over LDS and flushed with global_atomic_add_f64.
+#pragma once
+#include "qc_internal.h"
+
+struct QcKernelArgs {
+    const QcPairDesc *pairs;
+    const double *pairdata;
+    const QcTask *tasks;
+    int ntasks;
+    const double *boys;
+    int n;
+    const double *Dj, *Dk0, *Dk1;
+    double *G0, *G1;
+    double cK;
+    double *eri_out;
+};
+
+template <int LAB, int LCD>
+__device__ __forceinline__ void qc_step2(double (&W)[qc_nherm(LAB)], const double (&e)[qc_nherm(LCD)], const double *__restrict__ R);
+
+// (t,u,v) of every Hermite index up to order QC_LTOT
+struct QcTuvTable { unsigned char t[qc_nherm(QC_LTOT)], u[qc_nherm(QC_LTOT)], v[qc_nherm(QC_LTOT)]; };
+__host__ __device__ constexpr QcTuvTable qc_make_tuv() {
+    QcTuvTable T{};
+    int k = 0;
+    for (int N = 0; N <= QC_LTOT; ++N)
+        for (int t = N; t >= 0; --t)
+            for (int u = N - t; u >= 0; --u) { T.t[k] = (unsigned char)t; T.u[k] = (unsigned char)u; T.v[k] = (unsigned char)(N - t - u); ++k; }
+    return T;
+}
+__device__ constexpr QcTuvTable qc_tuv = qc_make_tuv();
+
+// Boys function F_0..F_L at x: 8-term Taylor expansion about the nearest grid point of the pre-tabulated
+// F_n(x_k) for the top order, downward recursion below it; asymptotic form + upward recursion beyond the table.
+template <int L>
+__device__ __forceinline__ void qc_boys(double x, const double *__restrict__ tab, double (&F)[L + 1]) {
+    if (x < QC_BOYS_XMAX) {
+        const int k = (int)(x * (1.0 / QC_BOYS_DX) + 0.5);
+        const double d = k * QC_BOYS_DX - x;
+        const double *row = tab + k * QC_BOYS_NORD + L;
+        double f = row[7] * (1.0 / 5040.0);
+        f = fma(f, d, row[6] * (1.0 / 720.0));
+        f = fma(f, d, row[5] * (1.0 / 120.0));
+        f = fma(f, d, row[4] * (1.0 / 24.0));
+        f = fma(f, d, row[3] * (1.0 / 6.0));
+        f = fma(f, d, row[2] * 0.5);
+        f = fma(f, d, row[1]);
+        f = fma(f, d, row[0]);
+        F[L] = f;
+        if constexpr (L > 0) {
+            const double ex = exp(-x), x2 = 2.0 * x;
+#pragma unroll
+            for (int n = L; n > 0; --n) F[n - 1] = fma(x2, F[n], ex) * (1.0 / (2 * n - 1));
+        }
+    } else {
+        const double rx = 1.0 / x;
+        F[0] = 0.5 * sqrt(M_PI * rx);
+        if constexpr (L > 0) {
+            const double ex = exp(-x), hr = 0.5 * rx;
+#pragma unroll
+            for (int n = 0; n < L; ++n) F[n + 1] = fma((double)(2 * n + 1), F[n], -ex) * hr;
+        }
+    }
+}
+
+// offset of level n inside the R work array (levels hold orders 0..L-n)
+template <int L>
+__host__ __device__ constexpr int qc_roff(int n) {
+    int o = 0;
+    for (int m = 0; m < n; ++m) o += qc_nherm(L - m);
+    return o;
+}
+
+// Cooperative Hermite-Coulomb table R^0_{tuv}, t+u+v <= L, by the `C` lanes of a group (lane-in-group `li`), in LDS.
+// On return Rw[0 .. nherm(L)) holds R^0.  Every lane of the workgroup must call this (it contains barriers).
+template <int L>
+__device__ __forceinline__ void qc_build_r(double *__restrict__ Rw, int li, int C, double alpha, double X, double Y, double Z,
+                                           const double (&F)[L + 1]) {
+    if (li == 0) {
+        double f = 1.0;
+#pragma unroll
+        for (int n = 0; n <= L; ++n) { Rw[qc_roff<L>(n)] = f * F[n]; f *= -2.0 * alpha; }
+    }
+    if constexpr (L > 0) {
+        __syncthreads();
+#pragma unroll
+        for (int N = 1; N <= L; ++N) {
+            const int cnt = (N + 1) * (N + 2) / 2, total = (L - N + 1) * cnt, base = qc_nherm(N - 1);
+            for (int e = li; e < total; e += C) {
+                const int n = e / cnt, idx = base + (e - n * cnt);
+                const int t = qc_tuv.t[idx], u = qc_tuv.u[idx], v = qc_tuv.v[idx];
+                // level offsets: qc_roff<L>(n) for runtime n
+                int o1 = 0;
+                for (int m = 0; m <= n; ++m) o1 += qc_nherm(L - m);     // offset of level n+1
+                const int o0 = o1 - qc_nherm(L - n);
+                const double *up = Rw + o1;
+                double val;
+                if (t > 0) {
+                    val = X * up[qc_hidx(t - 1, u, v)];
+                    if (t > 1) val = fma((double)(t - 1), up[qc_hidx(t - 2, u, v)], val);
+                } else if (u > 0) {
+                    val = Y * up[qc_hidx(t, u - 1, v)];
+                    if (u > 1) val = fma((double)(u - 1), up[qc_hidx(t, u - 2, v)], val);
+                } else {
+                    val = Z * up[qc_hidx(t, u, v - 1)];
+                    if (v > 1) val = fma((double)(v - 1), up[qc_hidx(t, u, v - 2)], val);
+                }
+                Rw[o0 + idx] = val;
+            }
+            __syncthreads();
+        }
+    } else {
+        __syncthreads();
+    }
+}
+
+template <int LAB, int LCD>
+__global__ __launch_bounds__(64) void qc_fock_class_kernel(const QcKernelArgs a) {
+    constexpr int L = LAB + LCD, HAB = qc_nherm(LAB), HCD = qc_nherm(LCD), RW = qc_rwork(L);
+    extern __shared__ double lds[];
+    const int lane = threadIdx.x;
+    const double *__restrict__ pd = a.pairdata;
+    const int n = a.n;
+    const bool uhf = a.Dk1 != nullptr;
+
+    for (int task = blockIdx.x; task < a.ntasks; task += gridDim.x) {
+        const QcTask tk = a.tasks[task];
+        const QcPairDesc pb = a.pairs[tk.bra], pk = a.pairs[tk.ket];
+        const int na = pb.na, nb = pb.nb, nc = pk.na, nd = pk.nb;
+        const int nab = na * nb, ncd = nc * nd;
+        int C = 1, lgC = 0;
+        while (C < ncd && C < 64) { C <<= 1; ++lgC; }
+        const int G = 64 >> lgC, g = lane >> lgC, li = lane & (C - 1);
+        double *Rw = lds + g * RW;
+        double *Iblk = lds + G * RW;
+        double *tDj_ab = Iblk + nab * ncd, *tDj_cd = tDj_ab + nab;
+        double *tK = tDj_cd + ncd;   // per spin: Dk_ac, Dk_ad, Dk_bc, Dk_bd
+        const int ktile = na * nc + na * nd + nb * nc + nb * nd;
+
+        for (int i = lane; i < nab * ncd; i += 64) Iblk[i] = 0.0;
+        if (a.eri_out == nullptr) {   // stage the density tiles this quartet touches
+            for (int i = lane; i < nab; i += 64) tDj_ab[i] = a.Dj[(size_t)(pb.offa + i / nb) * n + pb.offb + i % nb];
+            for (int i = lane; i < ncd; i += 64) tDj_cd[i] = a.Dj[(size_t)(pk.offa + i / nd) * n + pk.offb + i % nd];
+            for (int s = 0; s < (uhf ? 2 : 1); ++s) {
+                const double *Dk = s ? a.Dk1 : a.Dk0;
+                double *t0 = tK + s * ktile, *t1 = t0 + na * nc, *t2 = t1 + na * nd, *t3 = t2 + nb * nc;
+                for (int i = lane; i < na * nc; i += 64) t0[i] = Dk[(size_t)(pb.offa + i / nc) * n + pk.offa + i % nc];
+                for (int i = lane; i < na * nd; i += 64) t1[i] = Dk[(size_t)(pb.offa + i / nd) * n + pk.offb + i % nd];
+                for (int i = lane; i < nb * nc; i += 64) t2[i] = Dk[(size_t)(pb.offb + i / nc) * n + pk.offa + i % nc];
+                for (int i = lane; i < nb * nd; i += 64) t3[i] = Dk[(size_t)(pb.offb + i / nd) * n + pk.offb + i % nd];
+            }
+        }
+        __syncthreads();
+
+        const int strideB = 4 + HAB * nab, strideK = 4 + HCD * ncd;
+        const int npq = pb.K * pk.K, chunk = (npq + G - 1) / G;
+        const int lo = g * chunk, hi = min(npq, lo + chunk);
+        const double *braBase = pd + pb.doff, *ketBase = pd + pk.doff;
+
+        for (int cbase = 0; cbase < ncd; cbase += 64) {   // one pass unless the ket pair has > 64 function pairs
+            const int col = cbase + li;
+            const bool colok = col < ncd;
+            double W[HAB];
+#pragma unroll
+            for (int h = 0; h < HAB; ++h) W[h] = 0.0;
+            int cur_ij = -1;
+
+            auto flush = [&](int ij) {   // step 3: I[ab][col] += sum_h E_ab,ij[h][ab] W[h]
+                const double *Eab = braBase + (size_t)ij * strideB + 4;
+                for (int ab = 0; ab < nab; ++ab) {
+                    double acc = 0.0;
+#pragma unroll
+                    for (int h = 0; h < HAB; ++h) acc = fma(Eab[h * nab + ab], W[h], acc);
+                    if (colok) atomicAdd(&Iblk[ab * ncd + col], acc);
+                }
+            };
+
+            for (int it = 0; it < chunk; ++it) {
+                const int pq = lo + it;
+                const bool valid = pq < hi;
+                const int pqc = valid ? pq : npq - 1;
+                const int ij = pqc / pk.K, kl = pqc - ij * pk.K;
+                if (valid && ij != cur_ij) {
+                    if (cur_ij >= 0) flush(cur_ij);
+#pragma unroll
+                    for (int h = 0; h < HAB; ++h) W[h] = 0.0;
+                    cur_ij = ij;
+                }
+                const double *bra = braBase + (size_t)ij * strideB, *ket = ketBase + (size_t)kl * strideK;
+                const double p = bra[0], q = ket[0];
+                const double X = bra[1] - ket[1], Y = bra[2] - ket[2], Z = bra[3] - ket[3];
+                const double pq_sum = p + q, alpha = p * q / pq_sum;
+                const double pref = 1.0 / sqrt(pq_sum);
+                double F[L + 1];
+                qc_boys<L>(alpha * (X * X + Y * Y + Z * Z), a.boys, F);
+                __syncthreads();                      // previous iteration's readers of Rw are done
+                qc_build_r<L>(Rw, li, C, alpha, X, Y, Z, F);
+                double e[HCD];
+                const double sc = (valid && colok) ? pref : 0.0;
+                const double *Ecd = ket + 4 + (colok ? col : 0);
+#pragma unroll
+                for (int h = 0; h < HCD; ++h) e[h] = Ecd[h * ncd] * sc;
+                qc_step2<LAB, LCD>(W, e, Rw);
+            }
+            if (cur_ij >= 0) flush(cur_ij);
+        }
+        __syncthreads();
+
+        const double f = (pb.shA_eq_shB ? 0.5 : 1.0) * (pk.shA_eq_shB ? 0.5 : 1.0) * (tk.bra == tk.ket ? 0.5 : 1.0);
+        if (a.eri_out != nullptr) {
+            // materialise (ij|kl) with its 8 symmetry images: the tensor molint::eri returns (tests / plumbing only)
+            const size_t n1 = n, n2 = n1 * n1, n3 = n2 * n1;
+            for (int x = lane; x < nab * ncd; x += 64) {
+                const int ab = x / ncd, cd = x - ab * ncd;
+                const size_t i = pb.offa + ab / nb, j = pb.offb + ab % nb, k = pk.offa + cd / nd, l = pk.offb + cd % nd;
+                const double v = Iblk[x];
+                double *o = a.eri_out;
+                o[i * n3 + j * n2 + k * n1 + l] = v; o[j * n3 + i * n2 + k * n1 + l] = v;
+                o[i * n3 + j * n2 + l * n1 + k] = v; o[j * n3 + i * n2 + l * n1 + k] = v;
+                o[k * n3 + l * n2 + i * n1 + j] = v; o[l * n3 + k * n2 + i * n1 + j] = v;
+                o[k * n3 + l * n2 + j * n1 + i] = v; o[l * n3 + k * n2 + j * n1 + i] = v;
+            }
+        } else {
+            // J blocks: Gt_ab += 2f sum_cd I D_cd ; Gt_cd += 2f sum_ab I D_ab   (final G = Gt + Gt^T)
+            const double fj = 2.0 * f;
+            for (int ab = lane; ab < nab; ab += 64) {
+                double s = 0.0;
+                for (int cd = 0; cd < ncd; ++cd) s = fma(Iblk[ab * ncd + cd], tDj_cd[cd], s);
+                const size_t o = (size_t)(pb.offa + ab / nb) * n + pb.offb + ab % nb;
+                unsafeAtomicAdd(&a.G0[o], fj * s);
+                if (uhf) unsafeAtomicAdd(&a.G1[o], fj * s);
+            }
+            for (int cd = lane; cd < ncd; cd += 64) {
+                double s = 0.0;
+                for (int ab = 0; ab < nab; ++ab) s = fma(Iblk[ab * ncd + cd], tDj_ab[ab], s);
+                const size_t o = (size_t)(pk.offa + cd / nd) * n + pk.offb + cd % nd;
+                unsafeAtomicAdd(&a.G0[o], fj * s);
+                if (uhf) unsafeAtomicAdd(&a.G1[o], fj * s);
+            }
+            // K blocks: Gt_ac -= cK f sum_bd I D_bd, and the ad / bc / bd images
+            const double fk = -a.cK * f;
+            for (int s = 0; s < (uhf ? 2 : 1); ++s) {
+                double *Gs = s ? a.G1 : a.G0;
+                const double *t_ac = tK + s * ktile, *t_ad = t_ac + na * nc, *t_bc = t_ad + na * nd, *t_bd = t_bc + nb * nc;
+                for (int x = lane; x < na * nc; x += 64) {          // (i,k) <- sum_{j,l} I[ij,kl] D[j,l]
+                    const int i = x / nc, k = x - i * nc;
+                    double acc = 0.0;
+                    for (int j = 0; j < nb; ++j)
+                        for (int l = 0; l < nd; ++l) acc = fma(Iblk[(i * nb + j) * ncd + k * nd + l], t_bd[j * nd + l], acc);
+                    unsafeAtomicAdd(&Gs[(size_t)(pb.offa + i) * n + pk.offa + k], fk * acc);
+                }
+                for (int x = lane; x < na * nd; x += 64) {          // (i,l) <- sum_{j,k} I[ij,kl] D[j,k]
+                    const int i = x / nd, l = x - i * nd;
+                    double acc = 0.0;
+                    for (int j = 0; j < nb; ++j)
+                        for (int k = 0; k < nc; ++k) acc = fma(Iblk[(i * nb + j) * ncd + k * nd + l], t_bc[j * nc + k], acc);
+                    unsafeAtomicAdd(&Gs[(size_t)(pb.offa + i) * n + pk.offb + l], fk * acc);
+                }
+                for (int x = lane; x < nb * nc; x += 64) {          // (j,k) <- sum_{i,l} I[ij,kl] D[i,l]
+                    const int j = x / nc, k = x - j * nc;
+                    double acc = 0.0;
+                    for (int i = 0; i < na; ++i)
+                        for (int l = 0; l < nd; ++l) acc = fma(Iblk[(i * nb + j) * ncd + k * nd + l], t_ad[i * nd + l], acc);
+                    unsafeAtomicAdd(&Gs[(size_t)(pb.offb + j) * n + pk.offa + k], fk * acc);
+                }
+                for (int x = lane; x < nb * nd; x += 64) {          // (j,l) <- sum_{i,k} I[ij,kl] D[i,k]
+                    const int j = x / nd, l = x - j * nd;
+                    double acc = 0.0;
+                    for (int i = 0; i < na; ++i)
+                        for (int k = 0; k < nc; ++k) acc = fma(Iblk[(i * nb + j) * ncd + k * nd + l], t_ac[i * nc + k], acc);
+                    unsafeAtomicAdd(&Gs[(size_t)(pb.offb + j) * n + pk.offb + l], fk * acc);
+                }
+            }
+        }
+        __syncthreads();   // Iblk / tiles are reused by the next task
+    }
+}
+
+template <int LAB, int LCD>
+int qc_launch_class(int grid, size_t lds, hipStream_t st, const QcKernelArgs &a) {
+    auto kern = qc_fock_class_kernel<LAB, LCD>;
+    if (lds > 48 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return QC_ERR_HIP;
+    }
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(64), lds, st, a);
+    return hipGetLastError() == hipSuccess ? QC_OK : QC_ERR_HIP;
+}

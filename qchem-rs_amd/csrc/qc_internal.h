@@ -1,0 +1,130 @@
+// qc_internal.h - shared declarations of libqchem_hip.so (host model, device buffers, kernel launchers).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <cstdio>
+#include <string>
+#include <vector>
+
+#include "../../include/qchem_hip.h"
+
+constexpr int QC_LMAX = 3;              // highest shell angular momentum with kernels (f)
+constexpr int QC_LPAIR = 2 * QC_LMAX;   // highest pair angular momentum
+constexpr int QC_LTOT = 4 * QC_LMAX;    // highest Hermite order of an ERI
+
+__host__ __device__ constexpr int qc_nherm(int L) { return (L + 1) * (L + 2) * (L + 3) / 6; }
+__host__ __device__ constexpr int qc_ncart(int L) { return (L + 1) * (L + 2) / 2; }
+// Hermite index of (t,u,v): grouped by total order N = t+u+v, then t descending, then u descending.
+__host__ __device__ constexpr int qc_hidx(int t, int u, int v) {
+    return (t + u + v) * (t + u + v + 1) * (t + u + v + 2) / 6 + (u + v) * (u + v + 1) / 2 + v;
+}
+// size of the Hermite-Coulomb work array sum_{n=0..L} nherm(L-n) = C(L+4,4)
+__host__ __device__ constexpr int qc_rwork(int L) { return (L + 1) * (L + 2) * (L + 3) * (L + 4) / 24; }
+
+struct QcShell {
+    int atom, L, pure, nprim, ncart, nfunc, off;
+    double A[3];
+    std::vector<double> exps, coefs;  // coefs include the (L,0,0) primitive norm
+    std::vector<double> T;            // nfunc x ncart, rows scaled to unit self-overlap
+};
+
+// Device-visible pair descriptor (8 ints)
+struct QcPairDesc {
+    int doff;     // offset (in doubles) of this pair's primitive blocks in the pair-data array
+    int K;        // primitive pairs
+    int na, nb;   // basis functions of shell A / B
+    int offa, offb;
+    int L;        // la + lb
+    int shA_eq_shB;
+};
+
+struct QcTask { int bra, ket; };  // pair indices; (bra|ket) is one unique shell quartet
+
+struct QcClass {
+    int LAB, LCD;                 // Hermite orders of bra / ket pairs
+    std::vector<QcTask> tasks;    // all unique quartets of this class (full list)
+    std::vector<QcTask> shard;    // the ones this rank digests
+    QcTask *d_tasks = nullptr;    // device copy of `shard`
+    int lds_bytes = 0;
+    // work model of `shard`
+    int64_t prim_quartets = 0;
+    double bytes_alg = 0, flops_alg = 0;
+};
+
+struct qc_system {
+    int natoms = 0, nshells = 0, nbasis = 0, nelec = 0;
+    std::vector<int> Z;
+    std::vector<double> xyz;
+    std::vector<QcShell> shells;
+    // pairs
+    std::vector<QcPairDesc> pairs;
+    std::vector<int> pairA, pairB;
+    std::vector<double> pairdata;
+    std::vector<QcClass> classes;
+    int64_t nquartets = 0;
+    int rank = 0, nranks = 1;
+    // device
+    bool device_ready = false;
+    int device = -1;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    double *d_pairdata = nullptr;
+    QcPairDesc *d_pairs = nullptr;
+    double *d_boys = nullptr;
+    double *d_D = nullptr, *d_G = nullptr;   // 2 * n*n each (alpha/beta or Dj/Dk)
+    double *d_Gtmp = nullptr;                // 2 * n*n accumulation target
+    double *d_Dj = nullptr;
+    void *comm = nullptr;                    // ncclComm_t
+    std::string last_error;
+};
+
+// ---- host model (qc_system.cpp)
+void qc_build_model(qc_system *S);
+void qc_build_shards(qc_system *S);
+void qc_host_one_electron(const qc_system *S, int which, double *out);
+void qc_boys_host(int nmax, double x, double *F);
+
+// Boys table: F_n(x_k), x_k = k * QC_BOYS_DX, n = 0..QC_BOYS_NORD-1
+constexpr double QC_BOYS_DX = 0.1;
+constexpr int QC_BOYS_NGRID = 421;             // x up to 42
+constexpr double QC_BOYS_XMAX = 41.9;          // beyond: asymptotic + upward recursion
+constexpr int QC_BOYS_NORD = QC_LTOT + 8;      // orders kept per grid point
+
+// ---- device side (qc_fock.hip / qc_linalg.hip)
+int qc_device_init(qc_system *S);
+void qc_device_free(qc_system *S);
+// digestion modes
+struct QcFockArgs {
+    const double *Dj;     // density contracted into J (n*n)
+    const double *Dk0;    // density contracted into K for spin 0
+    const double *Dk1;    // spin 1 (UHF) or nullptr
+    double *G0, *G1;      // accumulation targets (pre-zeroed), unsymmetrised
+    double cK;            // K prefactor (0.5 RHF, 1.0 UHF)
+    double *eri_out;      // if non-null: store the integrals into the n^4 tensor instead of digesting
+};
+int qc_launch_fock_classes(qc_system *S, const QcFockArgs &a, float *class_ms /*nullable*/);
+int qc_fock_build_device(qc_system *S, const double *dDa, const double *dDb, double *dGa, double *dGb, bool uhf);
+
+// dense linear algebra on the handle's stream (all row-major n x n, device pointers)
+void qc_gemm(hipStream_t st, int m, int n, int k, double alpha, const double *A, int lda, bool ta, const double *B,
+             int ldb, bool tb, double beta, double *C, int ldc);
+int qc_eig_device(hipStream_t st, int n, double *dA /*destroyed*/, double *dV, double *dw, double *d_work);
+void qc_axpby(hipStream_t st, int n, double a, const double *x, double b, const double *y, double *out);
+void qc_sub_transpose(hipStream_t st, int n, const double *M, double *out);              // out = M - M^T
+void qc_symmetrize_add(hipStream_t st, int n, const double *Gt, double *G);              // G = Gt + Gt^T
+void qc_dots(hipStream_t st, int n, const double *x, const double *const *ys, int ny, double *out);  // device ptr list
+void qc_lincomb(hipStream_t st, int n, const double *const *Fs, const double *c, int m, double *out);   // out = sum c_i Fs_i
+void qc_scale_cols_invsqrt(hipStream_t st, int n, const double *U, const double *Lam, double *out);
+int qc_device_reshard(qc_system *S);
+void qc_energy_rms(hipStream_t st, int n, const double *Dnew, const double *Dold, const double *H, const double *G,
+                   double *out2);  // out2[0] = 0.5 tr(Dnew (2H+G)), out2[1] = sum_i (Dnew-Dold)_ii^2
+
+#define QC_HIP_CHECK(expr)                                                                  \
+    do {                                                                                    \
+        hipError_t _e = (expr);                                                             \
+        if (_e != hipSuccess) {                                                             \
+            fprintf(stderr, "qchem_hip: %s failed: %s (%s:%d)\n", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
+            return QC_ERR_HIP;                                                              \
+        }                                                                                   \
+    } while (0)

@@ -1,0 +1,326 @@
+// qc_system.cpp - host model of a molecule + basis for the MI355X Hartree-Fock path.
+//
+// Replaces what the reference receives as `&MolecularSystem` from molint (main.rs:76-77; members read at
+// rhf.rs:36-37) and precomputes, once per geometry, everything the HIP kernels stream: normalised shells, the
+// shell-pair list with per-primitive-pair Hermite expansion matrices (spherical transform, contraction coefficients
+// and the pair part of the ERI prefactor folded in), the class-sorted unique-quartet task lists and their
+// per-rank shards.  Also holds the host implementation of molint::overlap/kinetic/nuclear (rhf.rs:41-43), which
+// SURVEY.md 8f ranks as "next" for the GPU.  Integral formulas: McMurchie-Davidson.
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <numeric>
+
+#include "qc_internal.h"
+
+namespace {
+
+double dfact(int n) { double r = 1.0; for (; n > 1; n -= 2) r *= n; return r; }
+double binom(int n, int k) { if (k < 0 || k > n) return 0.0; double r = 1.0; for (int i = 1; i <= k; ++i) r = r * (n - k + i) / i; return r; }
+
+struct Cart { int x, y, z; };
+std::vector<Cart> cart_list(int L) {
+    std::vector<Cart> v;
+    for (int lx = L; lx >= 0; --lx) for (int ly = L - lx; ly >= 0; --ly) v.push_back({lx, ly, L - lx - ly});
+    return v;
+}
+
+// real solid harmonic S_lm in Cartesian monomials, Helgaker-Jorgensen-Olsen eq. 6.4.47 (scale fixed afterwards)
+std::vector<double> solid_row(int l, int m, const std::vector<Cart> &cl) {
+    std::vector<double> row(cl.size(), 0.0);
+    const int am = std::abs(m), neg = m < 0 ? 1 : 0;
+    for (int t = 0; 2 * t <= l - am; ++t)
+        for (int u = 0; u <= t; ++u)
+            for (int k = 0; 2 * k + neg <= am; ++k) {          // 2v = 2k + neg
+                const int tv = 2 * k + neg;
+                double c = ((t + k) & 1 ? -1.0 : 1.0) * std::pow(0.25, t) * binom(l, t) * binom(l - t, am + t) * binom(t, u) * binom(am, tv);
+                const int ex = 2 * t + am - 2 * u - tv, ey = 2 * u + tv, ez = l - 2 * t - am;
+                if (ex < 0) continue;
+                for (size_t i = 0; i < cl.size(); ++i)
+                    if (cl[i].x == ex && cl[i].y == ey && cl[i].z == ez) row[i] += c;
+            }
+    return row;
+}
+
+double mono_overlap_1d(int n, double p) { return (n & 1) ? 0.0 : dfact(n - 1) / std::pow(2.0 * p, n / 2) * std::sqrt(M_PI / p); }
+
+// 1-D Hermite expansion coefficients E[i][j][t], i<=imax, j<=jmax (flat, stride helpers)
+struct E1 {
+    int imax, jmax, tdim;
+    std::vector<double> v;
+    E1(int im, int jm) : imax(im), jmax(jm), tdim(im + jm + 2), v((size_t)(im + 1) * (jm + 1) * (im + jm + 2), 0.0) {}
+    double &at(int i, int j, int t) { return v[((size_t)i * (jmax + 1) + j) * tdim + t]; }
+    double get(int i, int j, int t) const { return (t < 0 || t > i + j) ? 0.0 : v[((size_t)i * (jmax + 1) + j) * tdim + t]; }
+};
+E1 hermite_e(int imax, int jmax, double a, double b, double Q) {
+    E1 E(imax, jmax);
+    const double p = a + b, h = 0.5 / p, xpa = -b / p * Q, xpb = a / p * Q;
+    E.at(0, 0, 0) = std::exp(-a * b / p * Q * Q);
+    for (int i = 1; i <= imax; ++i)
+        for (int t = 0; t <= i; ++t)
+            E.at(i, 0, t) = h * E.get(i - 1, 0, t - 1) + xpa * E.get(i - 1, 0, t) + (t + 1) * E.get(i - 1, 0, t + 1);
+    for (int j = 1; j <= jmax; ++j)
+        for (int i = 0; i <= imax; ++i)
+            for (int t = 0; t <= i + j; ++t)
+                E.at(i, j, t) = h * E.get(i, j - 1, t - 1) + xpb * E.get(i, j - 1, t) + (t + 1) * E.get(i, j - 1, t + 1);
+    return E;
+}
+
+// Hermite Coulomb integrals R^0_tuv, t+u+v <= L (host, for the nuclear-attraction matrix)
+void hermite_r_host(int L, double alpha, const double PC[3], std::vector<double> &R0) {
+    std::vector<std::vector<double>> W(L + 1, std::vector<double>(qc_nherm(L), 0.0));
+    std::vector<double> F(L + 1);
+    qc_boys_host(L, alpha * (PC[0] * PC[0] + PC[1] * PC[1] + PC[2] * PC[2]), F.data());
+    double f = 1.0;
+    for (int n = 0; n <= L; ++n) { W[n][0] = f * F[n]; f *= -2.0 * alpha; }
+    for (int N = 1; N <= L; ++N)
+        for (int n = 0; n + N <= L; ++n)
+            for (int t = N; t >= 0; --t)
+                for (int u = N - t; u >= 0; --u) {
+                    const int v = N - t - u;
+                    double val;
+                    if (t) val = PC[0] * W[n + 1][qc_hidx(t - 1, u, v)] + (t > 1 ? (t - 1) * W[n + 1][qc_hidx(t - 2, u, v)] : 0.0);
+                    else if (u) val = PC[1] * W[n + 1][qc_hidx(t, u - 1, v)] + (u > 1 ? (u - 1) * W[n + 1][qc_hidx(t, u - 2, v)] : 0.0);
+                    else val = PC[2] * W[n + 1][qc_hidx(t, u, v - 1)] + (v > 1 ? (v - 1) * W[n + 1][qc_hidx(t, u, v - 2)] : 0.0);
+                    W[n][qc_hidx(t, u, v)] = val;
+                }
+    R0 = W[0];
+}
+
+}  // namespace
+
+// F_n(x), n = 0..nmax: Kummer series at nmax + downward recursion; erf + upward recursion for large x.
+void qc_boys_host(int nmax, double x, double *F) {
+    const double ex = std::exp(-x);
+    if (x < 38.0) {
+        double term = 1.0 / (2 * nmax + 1), sum = term;
+        for (int k = 1; k < 500; ++k) { term *= 2.0 * x / (2 * nmax + 2 * k + 1); sum += term; if (term < 1e-18 * sum) break; }
+        F[nmax] = ex * sum;
+        for (int n = nmax; n > 0; --n) F[n - 1] = (2.0 * x * F[n] + ex) / (2 * n - 1);
+    } else {
+        F[0] = 0.5 * std::sqrt(M_PI / x) * std::erf(std::sqrt(x));
+        for (int n = 0; n < nmax; ++n) F[n + 1] = ((2 * n + 1) * F[n] - ex) / (2.0 * x);
+    }
+}
+
+static void normalise_shell(QcShell &sh) {
+    const int L = sh.L;
+    auto cl = cart_list(L);
+    sh.ncart = (int)cl.size();
+    sh.nfunc = sh.pure ? 2 * L + 1 : sh.ncart;
+    for (int i = 0; i < sh.nprim; ++i) {
+        const double a = sh.exps[i];
+        sh.coefs[i] *= std::pow(2.0 * a / M_PI, 0.75) * std::pow(4.0 * a, 0.5 * L) / std::sqrt(dfact(2 * L - 1));
+    }
+    sh.T.assign((size_t)sh.nfunc * sh.ncart, 0.0);
+    if (sh.pure) {
+        for (int m = -L; m <= L; ++m) { auto r = solid_row(L, m, cl); std::copy(r.begin(), r.end(), sh.T.begin() + (size_t)(m + L) * sh.ncart); }
+    } else {
+        for (int c = 0; c < sh.ncart; ++c) sh.T[(size_t)c * sh.ncart + c] = 1.0;
+    }
+    // contracted self-overlap of the monomials, then scale each function to unit norm
+    std::vector<double> M((size_t)sh.ncart * sh.ncart, 0.0);
+    for (int c1 = 0; c1 < sh.ncart; ++c1)
+        for (int c2 = 0; c2 < sh.ncart; ++c2) {
+            double s = 0.0;
+            for (int i = 0; i < sh.nprim; ++i)
+                for (int j = 0; j < sh.nprim; ++j) {
+                    const double p = sh.exps[i] + sh.exps[j];
+                    s += sh.coefs[i] * sh.coefs[j] * mono_overlap_1d(cl[c1].x + cl[c2].x, p) * mono_overlap_1d(cl[c1].y + cl[c2].y, p) *
+                         mono_overlap_1d(cl[c1].z + cl[c2].z, p);
+                }
+            M[(size_t)c1 * sh.ncart + c2] = s;
+        }
+    for (int f = 0; f < sh.nfunc; ++f) {
+        double *row = &sh.T[(size_t)f * sh.ncart];
+        double s2 = 0.0;
+        for (int c1 = 0; c1 < sh.ncart; ++c1) for (int c2 = 0; c2 < sh.ncart; ++c2) s2 += row[c1] * row[c2] * M[(size_t)c1 * sh.ncart + c2];
+        const double sc = 1.0 / std::sqrt(s2);
+        for (int c = 0; c < sh.ncart; ++c) row[c] *= sc;
+    }
+}
+
+// Hermite expansion matrix of one primitive pair in basis functions: out[h * nab + (fa*nb+fb)], h < nherm(la+lb).
+static void pair_hermite_matrix(const QcShell &A, const QcShell &B, int i, int j, double scale, double *out, double *p_out, double P[3]) {
+    const int la = A.L, lb = B.L, nh = qc_nherm(la + lb), nab = A.nfunc * B.nfunc;
+    const double a = A.exps[i], b = B.exps[j], p = a + b;
+    for (int k = 0; k < 3; ++k) P[k] = (a * A.A[k] + b * B.A[k]) / p;
+    *p_out = p;
+    E1 Ex = hermite_e(la, lb, a, b, A.A[0] - B.A[0]), Ey = hermite_e(la, lb, a, b, A.A[1] - B.A[1]), Ez = hermite_e(la, lb, a, b, A.A[2] - B.A[2]);
+    auto ca = cart_list(la), cb = cart_list(lb);
+    const double cc = A.coefs[i] * B.coefs[j] * scale;
+    std::vector<double> Ec((size_t)ca.size() * cb.size() * nh, 0.0);
+    for (size_t x = 0; x < ca.size(); ++x)
+        for (size_t y = 0; y < cb.size(); ++y) {
+            double *row = &Ec[(x * cb.size() + y) * nh];
+            for (int t = 0; t <= ca[x].x + cb[y].x; ++t)
+                for (int u = 0; u <= ca[x].y + cb[y].y; ++u)
+                    for (int v = 0; v <= ca[x].z + cb[y].z; ++v)
+                        row[qc_hidx(t, u, v)] = cc * Ex.get(ca[x].x, cb[y].x, t) * Ey.get(ca[x].y, cb[y].y, u) * Ez.get(ca[x].z, cb[y].z, v);
+        }
+    std::fill(out, out + (size_t)nh * nab, 0.0);
+    for (int fa = 0; fa < A.nfunc; ++fa)
+        for (size_t x = 0; x < ca.size(); ++x) {
+            const double ta = A.T[(size_t)fa * A.ncart + x];
+            if (ta == 0.0) continue;
+            for (int fb = 0; fb < B.nfunc; ++fb)
+                for (size_t y = 0; y < cb.size(); ++y) {
+                    const double tb = ta * B.T[(size_t)fb * B.ncart + y];
+                    if (tb == 0.0) continue;
+                    const double *row = &Ec[(x * cb.size() + y) * nh];
+                    for (int h = 0; h < nh; ++h) out[(size_t)h * nab + fa * B.nfunc + fb] += tb * row[h];
+                }
+        }
+}
+
+void qc_build_model(qc_system *S) {
+    int off = 0;
+    for (auto &sh : S->shells) {
+        for (int k = 0; k < 3; ++k) sh.A[k] = S->xyz[3 * sh.atom + k];
+        normalise_shell(sh);
+        sh.off = off;
+        off += sh.nfunc;
+    }
+    S->nbasis = off;
+    S->nelec = std::accumulate(S->Z.begin(), S->Z.end(), 0);
+    // shell pairs A >= B, with per-primitive-pair blocks [p, Px, Py, Pz, E(nherm x nab)].
+    // The pair part of the ERI prefactor 2 pi^{5/2} / (p q sqrt(p+q)) is folded in as sqrt(2) pi^{5/4} / p.
+    const double half_pref = std::sqrt(2.0) * std::pow(M_PI, 1.25);
+    S->pairs.clear(); S->pairA.clear(); S->pairB.clear(); S->pairdata.clear();
+    for (int a = 0; a < S->nshells; ++a)
+        for (int b = 0; b <= a; ++b) {
+            const QcShell &A = S->shells[a], &B = S->shells[b];
+            QcPairDesc d;
+            d.doff = (int)S->pairdata.size();
+            d.K = A.nprim * B.nprim;
+            d.na = A.nfunc; d.nb = B.nfunc; d.offa = A.off; d.offb = B.off; d.L = A.L + B.L; d.shA_eq_shB = (a == b);
+            const int nh = qc_nherm(d.L), nab = d.na * d.nb, stride = 4 + nh * nab;
+            S->pairdata.resize(S->pairdata.size() + (size_t)d.K * stride);
+            for (int i = 0; i < A.nprim; ++i)
+                for (int j = 0; j < B.nprim; ++j) {
+                    double *blk = &S->pairdata[d.doff + (size_t)(i * B.nprim + j) * stride];
+                    double p, P[3];
+                    const double pp = A.exps[i] + B.exps[j];
+                    pair_hermite_matrix(A, B, i, j, half_pref / pp, blk + 4, &p, P);
+                    blk[0] = p; blk[1] = P[0]; blk[2] = P[1]; blk[3] = P[2];
+                }
+            S->pairs.push_back(d); S->pairA.push_back(a); S->pairB.push_back(b);
+        }
+    // unique quartets (pair P >= pair Q), oriented so the wider pair is the ket (column side), bucketed by class
+    const int np = (int)S->pairs.size();
+    S->nquartets = (int64_t)np * (np + 1) / 2;
+    std::vector<std::vector<QcTask>> bucket((QC_LPAIR + 1) * (QC_LPAIR + 1));
+    for (int P = 0; P < np; ++P)
+        for (int Q = 0; Q <= P; ++Q) {
+            const QcPairDesc &dp = S->pairs[P], &dq = S->pairs[Q];
+            const int np_ = dp.na * dp.nb, nq_ = dq.na * dq.nb;
+            const bool p_is_ket = (np_ > nq_) || (np_ == nq_ && dp.L >= dq.L);
+            QcTask t = p_is_ket ? QcTask{Q, P} : QcTask{P, Q};
+            bucket[S->pairs[t.bra].L * (QC_LPAIR + 1) + S->pairs[t.ket].L].push_back(t);
+        }
+    S->classes.clear();
+    for (int lab = 0; lab <= QC_LPAIR; ++lab)
+        for (int lcd = 0; lcd <= QC_LPAIR; ++lcd) {
+            auto &v = bucket[lab * (QC_LPAIR + 1) + lcd];
+            if (v.empty()) continue;
+            // heaviest first: primitive-quartet count is the dominant cost inside a class
+            std::stable_sort(v.begin(), v.end(), [&](const QcTask &x, const QcTask &y) {
+                return (int64_t)S->pairs[x.bra].K * S->pairs[x.ket].K > (int64_t)S->pairs[y.bra].K * S->pairs[y.ket].K;
+            });
+            QcClass c; c.LAB = lab; c.LCD = lcd; c.tasks = std::move(v);
+            S->classes.push_back(std::move(c));
+        }
+    qc_build_shards(S);
+}
+
+// Static shard: inside every class the cost-sorted task list is dealt round-robin to the ranks, so each rank holds
+// the same mix of classes and (to within one task per class) the same modelled cost.  Data-only; no communication.
+void qc_build_shards(qc_system *S) {
+    for (auto &c : S->classes) {
+        c.shard.clear();
+        for (size_t i = 0; i < c.tasks.size(); ++i)
+            if ((int)(i % S->nranks) == S->rank) c.shard.push_back(c.tasks[i]);
+        c.prim_quartets = 0; c.bytes_alg = 0; c.flops_alg = 0;
+        int lds = 0;
+        for (const auto &t : c.shard) {
+            const QcPairDesc &b = S->pairs[t.bra], &k = S->pairs[t.ket];
+            const QcShell &A = S->shells[S->pairA[t.bra]], &B = S->shells[S->pairB[t.bra]];
+            const QcShell &C = S->shells[S->pairA[t.ket]], &D = S->shells[S->pairB[t.ket]];
+            const double Kab = b.K, Kcd = k.K, L = b.L + k.L;
+            const double hab = qc_nherm(b.L), hcd = qc_nherm(k.L);
+            const double na = b.na, nb = b.nb, nc = k.na, nd = k.nb;
+            const double ca = A.ncart, cb = B.ncart, cc = C.ncart, cd = D.ncart;
+            c.prim_quartets += (int64_t)(Kab * Kcd);
+            // SURVEY.md 8(d) work model, verbatim
+            c.bytes_alg += 8.0 * (5.0 * (Kab + Kcd) + 3.0 * (na * nb + nc * nd + na * nc + na * nd + nb * nc + nb * nd));
+            c.flops_alg += Kab * Kcd * (40.0 * (L + 1) + 3.0 * qc_rwork((int)L) + 2.0 * hab * hcd) + 2.0 * ca * cb * hab * hcd +
+                           2.0 * ca * cb * cc * cd * hcd + 12.0 * na * nb * nc * nd;
+            // LDS need of the kernel for this task (see qc_fock.hip: layout_lds)
+            const int ncd = k.na * k.nb, nab = b.na * b.nb;
+            int C2 = 1; while (C2 < ncd && C2 < 64) C2 <<= 1;
+            const int G = 64 / C2;
+            const int words = G * qc_rwork(b.L + k.L) + nab * ncd + 2 * (nab + ncd) + 2 * (b.na * k.na + b.na * k.nb + b.nb * k.na + b.nb * k.nb);
+            lds = std::max(lds, words * 8);
+        }
+        c.lds_bytes = lds;
+    }
+}
+
+// ---- one-electron matrices on the host (molint::overlap / kinetic / nuclear, rhf.rs:41-43); which: 0 S, 1 T, 2 V
+void qc_host_one_electron(const qc_system *S, int which, double *out) {
+    const int n = S->nbasis;
+    std::fill(out, out + (size_t)n * n, 0.0);
+    std::vector<double> R0;
+    for (int a = 0; a < S->nshells; ++a)
+        for (int b = 0; b <= a; ++b) {
+            const QcShell &A = S->shells[a], &B = S->shells[b];
+            auto ca = cart_list(A.L), cb = cart_list(B.L);
+            std::vector<double> cart(ca.size() * cb.size(), 0.0);
+            for (int i = 0; i < A.nprim; ++i)
+                for (int j = 0; j < B.nprim; ++j) {
+                    const double ea = A.exps[i], eb = B.exps[j], p = ea + eb, cc = A.coefs[i] * B.coefs[j];
+                    double P[3];
+                    for (int k = 0; k < 3; ++k) P[k] = (ea * A.A[k] + eb * B.A[k]) / p;
+                    E1 E[3] = {hermite_e(A.L, B.L + 2, ea, eb, A.A[0] - B.A[0]), hermite_e(A.L, B.L + 2, ea, eb, A.A[1] - B.A[1]),
+                               hermite_e(A.L, B.L + 2, ea, eb, A.A[2] - B.A[2])};
+                    const double s3 = std::pow(M_PI / p, 1.5);
+                    for (size_t x = 0; x < ca.size(); ++x)
+                        for (size_t y = 0; y < cb.size(); ++y) {
+                            const int ai[3] = {ca[x].x, ca[x].y, ca[x].z}, bi[3] = {cb[y].x, cb[y].y, cb[y].z};
+                            double val = 0.0;
+                            if (which == 0) {
+                                val = s3 * E[0].get(ai[0], bi[0], 0) * E[1].get(ai[1], bi[1], 0) * E[2].get(ai[2], bi[2], 0);
+                            } else if (which == 1) {
+                                // -1/2 d^2/dx^2 acting on the ket primitive, one axis at a time
+                                double s1[3], t1[3];
+                                for (int k = 0; k < 3; ++k) {
+                                    s1[k] = E[k].get(ai[k], bi[k], 0);
+                                    t1[k] = 4.0 * eb * eb * E[k].get(ai[k], bi[k] + 2, 0) - 2.0 * eb * (2 * bi[k] + 1) * s1[k];
+                                    if (bi[k] >= 2) t1[k] += bi[k] * (bi[k] - 1) * E[k].get(ai[k], bi[k] - 2, 0);
+                                }
+                                val = -0.5 * s3 * (t1[0] * s1[1] * s1[2] + s1[0] * t1[1] * s1[2] + s1[0] * s1[1] * t1[2]);
+                            } else {
+                                for (int c = 0; c < S->natoms; ++c) {
+                                    const double PC[3] = {P[0] - S->xyz[3 * c], P[1] - S->xyz[3 * c + 1], P[2] - S->xyz[3 * c + 2]};
+                                    hermite_r_host(A.L + B.L, p, PC, R0);
+                                    double acc = 0.0;
+                                    for (int t = 0; t <= ai[0] + bi[0]; ++t)
+                                        for (int u = 0; u <= ai[1] + bi[1]; ++u)
+                                            for (int v = 0; v <= ai[2] + bi[2]; ++v)
+                                                acc += E[0].get(ai[0], bi[0], t) * E[1].get(ai[1], bi[1], u) * E[2].get(ai[2], bi[2], v) * R0[qc_hidx(t, u, v)];
+                                    val -= S->Z[c] * 2.0 * M_PI / p * acc;
+                                }
+                            }
+                            cart[x * cb.size() + y] += cc * val;
+                        }
+                }
+            for (int fa = 0; fa < A.nfunc; ++fa)
+                for (int fb = 0; fb < B.nfunc; ++fb) {
+                    double v = 0.0;
+                    for (size_t x = 0; x < ca.size(); ++x)
+                        for (size_t y = 0; y < cb.size(); ++y) v += A.T[(size_t)fa * A.ncart + x] * B.T[(size_t)fb * B.ncart + y] * cart[x * cb.size() + y];
+                    out[(size_t)(A.off + fa) * n + B.off + fb] = v;
+                    out[(size_t)(B.off + fb) * n + A.off + fa] = v;
+                }
+        }
+}

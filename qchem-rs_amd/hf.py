@@ -1,0 +1,277 @@
+"""Host-side mirror of the reference's `core::hf` API over the C ABI of libqchem_hip.so (include/qchem_hip.h).
+
+Names, argument meaning and error behaviour follow the reference so the parity tests read like its callers:
+  HartreeFockConfig{max_iterations, epsilon}            core/src/hf/mod.rs:9-15
+  restricted_hartree_fock(system, config) -> Option     core/src/hf/rhf.rs:32-35   (None = not converged, rhf.rs:107)
+  unrestricted_hartree_fock(system, config) -> Option   core/src/hf/uhf.rs:36-39
+  RestrictedHartreeFockOutput / UnrestrictedHartreeFockOutput incl. total_energy()   rhf.rs:14-30, uhf.rs:15-34
+  overlap / kinetic / nuclear / eri                     the molint free functions called at rhf.rs:41-45
+A singular DIIS system raises RuntimeError("DIIS failed") where the reference panics (rhf.rs:73, uhf.rs:95-97).
+
+This module is ctypes plumbing only: no arithmetic of the hot path happens in Python, and there is no CPU fallback -
+every compute call goes to the HIP library and raises if the library or a gfx950 device is missing.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+from dataclasses import dataclass, field
+from typing import List, Optional
+
+import numpy as np
+
+from .loader import MolecularSystem
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libqchem_hip.so")
+
+QC_OK, QC_NOT_CONVERGED, QC_DIIS_SINGULAR = 0, 1, 2
+QC_ERR_INVALID, QC_ERR_NO_DEVICE, QC_ERR_HIP, QC_ERR_RCCL, QC_ERR_UNSUPPORTED = -1, -2, -3, -4, -5
+_ERR = {-1: "invalid argument", -2: "no gfx950 device visible (there is no CPU fallback)", -3: "HIP runtime error",
+        -4: "RCCL error", -5: "unsupported (angular momentum > f, or n too large for the in-LDS eigensolver)"}
+
+EXPORTS = ["qc_system_create", "qc_system_destroy", "qc_nbasis", "qc_nelectrons", "qc_nshells", "qc_nquartets",
+           "qc_nuclear_repulsion", "qc_overlap", "qc_kinetic", "qc_nuclear", "qc_eri_full", "qc_fock_rhf", "qc_fock_uhf",
+           "qc_fock_rhf_device", "qc_fock_uhf_device", "qc_sym_eig", "qc_scf_rhf", "qc_scf_uhf", "qc_comm_unique_id",
+           "qc_comm_init", "qc_set_shard", "qc_plan_shard", "qc_set_stream", "qc_device_ready", "qc_work_stats_get",
+           "qc_fock_profile"]
+
+
+class QcError(RuntimeError):
+    pass
+
+
+class _Config(C.Structure):
+    _fields_ = [("max_iterations", C.c_size_t), ("epsilon", C.c_double), ("n_alpha", C.c_int32), ("n_beta", C.c_int32),
+                ("reserved", C.c_int32 * 6)]
+
+
+class _Output(C.Structure):
+    _fields_ = [("orbital_energies", C.POINTER(C.c_double)), ("orbital_energies_beta", C.POINTER(C.c_double)),
+                ("electronic_energy", C.c_double), ("nuclear_repulsion", C.c_double), ("iterations", C.c_size_t),
+                ("ms_setup", C.c_double), ("ms_fock_total", C.c_double), ("ms_linalg_total", C.c_double),
+                ("ms_total", C.c_double)]
+
+
+class WorkStats(C.Structure):
+    _fields_ = [("quartets", C.c_int64), ("prim_quartets", C.c_int64), ("bytes_alg", C.c_double),
+                ("flops_alg", C.c_double), ("nclasses", C.c_int32)]
+
+
+_lib = None
+_dp = np.ctypeslib.ndpointer(np.float64, flags="C_CONTIGUOUS")
+_ip = np.ctypeslib.ndpointer(np.int32, flags="C_CONTIGUOUS")
+
+
+def build_library(force: bool = False) -> str:
+    """Compile libqchem_hip.so for gfx950 in-tree (hipcc cross-compiles without a GPU)."""
+    csrc = os.path.join(_HERE, "csrc")
+    if force:
+        subprocess.check_call(["make", "-s", "-C", csrc, "clean"])
+    subprocess.check_call(["make", "-s", "-j8", "-C", csrc])
+    return LIB_PATH
+
+
+def lib():
+    """The loaded HIP library.  Raises if it has not been built - the product path never falls back to the CPU."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise QcError(f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                          "(qchem-rs_amd has no CPU fallback)")
+        L = C.CDLL(LIB_PATH)
+        vp = C.c_void_p
+        L.qc_system_create.argtypes = [C.c_int, _ip, _dp, C.c_int, _ip, _ip, _ip, _ip, _dp, _dp, C.POINTER(vp)]
+        L.qc_system_destroy.argtypes = [vp]; L.qc_system_destroy.restype = None
+        for f in ("qc_nbasis", "qc_nelectrons", "qc_nshells"):
+            getattr(L, f).argtypes = [vp]
+        L.qc_nquartets.argtypes = [vp]; L.qc_nquartets.restype = C.c_int64
+        L.qc_nuclear_repulsion.argtypes = [vp]; L.qc_nuclear_repulsion.restype = C.c_double
+        for f in ("qc_overlap", "qc_kinetic", "qc_nuclear", "qc_eri_full"):
+            getattr(L, f).argtypes = [vp, _dp]
+        L.qc_fock_rhf.argtypes = [vp, _dp, _dp]
+        L.qc_fock_uhf.argtypes = [vp, _dp, _dp, _dp, _dp]
+        L.qc_fock_rhf_device.argtypes = [vp, vp, vp]
+        L.qc_fock_uhf_device.argtypes = [vp, vp, vp, vp, vp]
+        L.qc_sym_eig.argtypes = [vp, C.c_int, _dp, _dp, _dp]
+        L.qc_scf_rhf.argtypes = [vp, C.POINTER(_Config), C.POINTER(_Output)]
+        L.qc_scf_uhf.argtypes = [vp, C.POINTER(_Config), C.POINTER(_Output)]
+        L.qc_comm_unique_id.argtypes = [C.c_char_p]
+        L.qc_comm_init.argtypes = [vp, C.c_char_p, C.c_int, C.c_int]
+        L.qc_set_shard.argtypes = [vp, C.c_int, C.c_int]
+        L.qc_plan_shard.argtypes = [vp, C.c_int, C.c_int, C.POINTER(C.c_int64), C.POINTER(C.c_double)]
+        L.qc_plan_shard_quartets.argtypes = [vp, C.c_int, C.c_int, vp, C.c_int64]
+        L.qc_set_stream.argtypes = [vp, vp]
+        L.qc_device_ready.argtypes = []
+        L.qc_work_stats_get.argtypes = [vp, C.POINTER(WorkStats)]
+        L.qc_fock_profile.argtypes = [vp, vp, vp, C.c_int, vp, vp, vp, vp, vp, vp]
+        _lib = L
+    return _lib
+
+
+def _check(rc: int, what: str):
+    if rc < 0:
+        raise QcError(f"{what}: {_ERR.get(rc, rc)}")
+    return rc
+
+
+def device_ready() -> bool:
+    return lib().qc_device_ready() == QC_OK
+
+
+class System:
+    """Owning wrapper of a `qc_system` handle (the `&MolecularSystem` the reference drivers borrow)."""
+
+    def __init__(self, mol: MolecularSystem):
+        self.mol = mol
+        self._h = C.c_void_p()
+        _check(lib().qc_system_create(len(mol.atoms), mol.atomic_numbers(), mol.coordinates(), mol.n_shells, mol.shell_atom,
+                                      mol.shell_L, mol.shell_pure, mol.shell_nprim, mol.exponents, mol.coefficients,
+                                      C.byref(self._h)), "qc_system_create")
+        self.n = lib().qc_nbasis(self._h)
+
+    def __del__(self):
+        try:
+            if self._h:
+                lib().qc_system_destroy(self._h); self._h = None
+        except Exception:
+            pass
+
+    @property
+    def handle(self): return self._h
+    def n_basis(self) -> int: return self.n
+    def n_electrons(self) -> int: return lib().qc_nelectrons(self._h)
+    def n_quartets(self) -> int: return lib().qc_nquartets(self._h)
+    def nuclear_repulsion(self) -> float: return lib().qc_nuclear_repulsion(self._h)
+
+    def _mat(self, fn):
+        M = np.zeros((self.n, self.n)); _check(getattr(lib(), fn)(self._h, M), fn); return M
+
+    def overlap(self): return self._mat("qc_overlap")
+    def kinetic(self): return self._mat("qc_kinetic")
+    def nuclear(self): return self._mat("qc_nuclear")
+
+    def eri(self):
+        I = np.zeros((self.n,) * 4); _check(lib().qc_eri_full(self._h, I.reshape(-1)), "qc_eri_full"); return I
+
+    def fock_rhf(self, D):
+        G = np.zeros((self.n, self.n))
+        _check(lib().qc_fock_rhf(self._h, np.ascontiguousarray(D, np.float64), G), "qc_fock_rhf"); return G
+
+    def fock_uhf(self, Da, Db):
+        Ga, Gb = np.zeros((self.n, self.n)), np.zeros((self.n, self.n))
+        _check(lib().qc_fock_uhf(self._h, np.ascontiguousarray(Da, np.float64), np.ascontiguousarray(Db, np.float64), Ga, Gb),
+               "qc_fock_uhf")
+        return Ga, Gb
+
+    def sym_eig(self, A):
+        A = np.ascontiguousarray(A, np.float64); n = A.shape[0]
+        V = np.zeros((n, n)); w = np.zeros(n)
+        _check(lib().qc_sym_eig(self._h, n, A, V, w), "qc_sym_eig"); return V, w
+
+    def set_shard(self, rank, nranks): _check(lib().qc_set_shard(self._h, rank, nranks), "qc_set_shard")
+
+    def plan_shard(self, rank, nranks):
+        nq, fl = C.c_int64(), C.c_double()
+        _check(lib().qc_plan_shard(self._h, rank, nranks, C.byref(nq), C.byref(fl)), "qc_plan_shard")
+        return nq.value, fl.value
+
+    def plan_shard_quartets(self, rank, nranks):
+        k = _check(lib().qc_plan_shard_quartets(self._h, rank, nranks, None, 0), "qc_plan_shard_quartets")
+        out = np.zeros((k, 4), np.int32)
+        _check(lib().qc_plan_shard_quartets(self._h, rank, nranks, out.ctypes.data_as(C.c_void_p), k), "qc_plan_shard_quartets")
+        return out
+
+    def comm_init(self, uid: bytes, rank: int, nranks: int):
+        _check(lib().qc_comm_init(self._h, uid, rank, nranks), "qc_comm_init")
+
+    def set_stream(self, stream_ptr: int): _check(lib().qc_set_stream(self._h, C.c_void_p(stream_ptr)), "qc_set_stream")
+
+    def work_stats(self) -> WorkStats:
+        ws = WorkStats(); _check(lib().qc_work_stats_get(self._h, C.byref(ws)), "qc_work_stats_get"); return ws
+
+    def fock_rhf_device(self, dD_ptr: int, dG_ptr: int):
+        _check(lib().qc_fock_rhf_device(self._h, C.c_void_p(dD_ptr), C.c_void_p(dG_ptr)), "qc_fock_rhf_device")
+
+    def fock_profile(self, dD_ptr: int, dG_ptr: int, reps: int):
+        k = self.work_stats().nclasses
+        ms = np.zeros(k, np.float32); cid = np.zeros(k, np.int32); nq = np.zeros(k, np.int64)
+        by = np.zeros(k); fl = np.zeros(k); tot = C.c_float()
+        p = lambda a: a.ctypes.data_as(C.c_void_p)
+        _check(lib().qc_fock_profile(self._h, C.c_void_p(dD_ptr), C.c_void_p(dG_ptr), reps, p(ms), p(cid), p(nq), p(by), p(fl),
+                                     C.cast(C.byref(tot), C.c_void_p)), "qc_fock_profile")
+        return dict(class_ms=ms, class_id=cid, quartets=nq, bytes=by, flops=fl, total_ms=tot.value)
+
+
+def comm_unique_id() -> bytes:
+    buf = C.create_string_buffer(128)
+    _check(lib().qc_comm_unique_id(buf), "qc_comm_unique_id")
+    return buf.raw
+
+
+# ------------------------------------------------------------------ the reference's public API (hf/mod.rs:5-15)
+@dataclass
+class HartreeFockConfig:
+    max_iterations: int = 100      # CLI default, main.rs:33
+    epsilon: float = 1e-6          # CLI default, main.rs:36
+    n_alpha: int = 0               # extension (uhf only); 0/0 = the reference's N/2 rule (uhf.rs:43-45)
+    n_beta: int = 0
+
+
+@dataclass
+class RestrictedHartreeFockOutput:
+    orbital_energies: List[float]
+    electronic_energy: float
+    nuclear_repulsion: float
+    iterations: int
+    timings_ms: dict = field(default_factory=dict)
+
+    def total_energy(self) -> float:
+        return self.electronic_energy + self.nuclear_repulsion
+
+
+@dataclass
+class UnrestrictedHartreeFockOutput:
+    orbital_energies_alpha: List[float]
+    orbital_energies_beta: List[float]
+    electronic_energy: float
+    nuclear_repulsion: float
+    iterations: int
+    timings_ms: dict = field(default_factory=dict)
+
+    def total_energy(self) -> float:
+        return self.electronic_energy + self.nuclear_repulsion
+
+
+def _as_system(system) -> System:
+    return system if isinstance(system, System) else System(system)
+
+
+def _run(fn, system, config, uhf):
+    sysh = _as_system(system)
+    n = sysh.n
+    wa, wb = np.zeros(n), np.zeros(n)
+    cfg = _Config(int(config.max_iterations), float(config.epsilon), int(config.n_alpha), int(config.n_beta))
+    out = _Output()
+    out.orbital_energies = wa.ctypes.data_as(C.POINTER(C.c_double))
+    out.orbital_energies_beta = wb.ctypes.data_as(C.POINTER(C.c_double))
+    rc = getattr(lib(), fn)(sysh.handle, C.byref(cfg), C.byref(out))
+    if rc == QC_DIIS_SINGULAR:
+        raise RuntimeError("DIIS failed")                 # rhf.rs:73 / uhf.rs:95-97
+    _check(rc, fn)
+    if rc == QC_NOT_CONVERGED:
+        return None                                       # rhf.rs:106-107
+    t = dict(setup=out.ms_setup, fock=out.ms_fock_total, linalg=out.ms_linalg_total, total=out.ms_total)
+    if uhf:
+        return UnrestrictedHartreeFockOutput(wa.tolist(), wb.tolist(), out.electronic_energy, out.nuclear_repulsion,
+                                             int(out.iterations), t)
+    return RestrictedHartreeFockOutput(wa.tolist(), out.electronic_energy, out.nuclear_repulsion, int(out.iterations), t)
+
+
+def restricted_hartree_fock(system, config: HartreeFockConfig) -> Optional[RestrictedHartreeFockOutput]:
+    return _run("qc_scf_rhf", system, config, False)
+
+
+def unrestricted_hartree_fock(system, config: HartreeFockConfig) -> Optional[UnrestrictedHartreeFockOutput]:
+    return _run("qc_scf_uhf", system, config, True)
