@@ -109,6 +109,21 @@ typedef struct {
 int qc_scf_rhf(qc_system *sys, const qc_hf_config *cfg, qc_hf_output *out);
 int qc_scf_uhf(qc_system *sys, const qc_hf_config *cfg, qc_hf_output *out);
 
+/* ---- the same drivers one loop-body pass at a time, for a host that owns the convergence loop itself (the Rust
+ * `core` crate in the north-star design; bench.py times exactly K passes through these).
+ *   begin   = everything before the loop: integrals, S^-1/2, Hueckel guess, DIIS windows  (rhf.rs:36-65, uhf.rs:40-78)
+ *   iterate = one pass of the body: G, F, error, DIIS, eigensolve, new density, energy, rms (rhf.rs:67-88, uhf.rs:81-137);
+ *             returns the electronic energy of rhf.rs:84-85 (uhf.rs:145-153) and the density rms the reference
+ *             compares with epsilon (for UHF the averaged value of uhf.rs:137, to be tested as rms/2 < epsilon). */
+typedef struct qc_scf_state qc_scf_state;
+int qc_scf_begin_rhf(qc_system *sys, qc_scf_state **out);
+int qc_scf_begin_uhf(qc_system *sys, int n_alpha, int n_beta, qc_scf_state **out);
+int qc_scf_iterate(qc_scf_state *st, double *electronic_energy, double *density_rms);
+int qc_scf_orbital_energies(qc_scf_state *st, int spin, double *out_n);
+int qc_scf_density(qc_scf_state *st, int spin, double *out_nxn);
+int qc_scf_timings(qc_scf_state *st, double *ms_setup, double *ms_fock, double *ms_linalg);
+void qc_scf_end(qc_scf_state *st);
+
 /* ---- multi-GPU (not in the reference, which is single-threaded; BASELINE.json north_star).  One process per GPU.
  * Rank 0 calls qc_comm_unique_id, the host distributes the 128 bytes, every rank calls qc_comm_init, which creates
  * an RCCL communicator on the current device and restricts this handle's Fock builds to shard `rank` of `nranks`. */
@@ -118,6 +133,8 @@ int qc_comm_init(qc_system *sys, const uint8_t id[128], int rank, int nranks);
 int qc_set_shard(qc_system *sys, int rank, int nranks);
 /* Host-only view of the work plan: number of quartets and the cost-model flops assigned to a shard. */
 int qc_plan_shard(qc_system *sys, int rank, int nranks, int64_t *nquartets, double *flops);
+/* The shard's quartets as shell indices (A,B,C,D), 4 ints each; abcd == NULL: returns the count only. */
+int qc_plan_shard_quartets(qc_system *sys, int rank, int nranks, int32_t *abcd, int64_t capacity);
 
 /* ---- measurement hooks */
 int qc_set_stream(qc_system *sys, void *hip_stream);  /* run on the caller's stream (e.g. torch's current stream) */

@@ -10,6 +10,7 @@
 #include <cmath>
 #include <cstring>
 #include <deque>
+#include <memory>
 #include <new>
 
 #include "qc_internal.h"
@@ -354,134 +355,157 @@ int qc_sym_eig(qc_system *S, int n, const double *A, double *V, double *w) {
     return QC_OK;
 }
 
-// restricted_hartree_fock (rhf.rs:32-108)
-int qc_scf_rhf(qc_system *S, const qc_hf_config *cfg, qc_hf_output *out) {
-    if (!S || !cfg || !out || !out->orbital_energies) return QC_ERR_INVALID;
-    const double t_begin = now_ms();
+// ---- step-wise drivers: the host (the Rust `core` crate in the north-star design) owns the convergence loop and
+// calls one FFI entry per loop-body pass; qc_scf_rhf / qc_scf_uhf below are that loop written in C++.
+}  // extern "C"
+
+struct qc_scf_state {
+    qc_system *S = nullptr;
+    bool uhf = false;
+    int nocc[2] = {0, 0};
+    ScfWork W;
+    DevBuf D, Dn, G, Cs, ws;
+    DeviceDiis *diis[2] = {nullptr, nullptr};
+    hipEvent_t ev0 = nullptr, ev1 = nullptr, ev2 = nullptr;
+    double ms_fock = 0, ms_linalg = 0, ms_setup = 0;
+    ~qc_scf_state() {
+        delete diis[0]; delete diis[1];
+        if (ev0) (void)hipEventDestroy(ev0);
+        if (ev1) (void)hipEventDestroy(ev1);
+        if (ev2) (void)hipEventDestroy(ev2);
+    }
+};
+
+static int scf_begin(qc_system *S, bool uhf, int n_alpha, int n_beta, qc_scf_state **out) {
+    if (!S || !out) return QC_ERR_INVALID;
+    const double t0 = now_ms();
     int rc = qc_device_init(S);
     if (rc != QC_OK) return rc;
-    const int n = S->nbasis, nocc = S->nelec / 2;                       // rhf.rs:36-37, :176
+    const int n = S->nbasis;
     const size_t nn = (size_t)n * n;
-    hipStream_t st = S->stream;
-    ScfWork W;
-    if ((rc = W.init(n)) != QC_OK) return rc;
-    DevBuf D, Dn, G;
-    if (D.alloc(nn) != QC_OK || Dn.alloc(nn) != QC_OK || G.alloc(nn) != QC_OK) return QC_ERR_HIP;
-    out->nuclear_repulsion = qc_nuclear_repulsion(S);                   // rhf.rs:39
-    out->electronic_energy = 0.0; out->iterations = 0;
-    out->ms_fock_total = out->ms_linalg_total = 0.0;
+    qc_scf_state *st = new (std::nothrow) qc_scf_state();
+    if (!st) return QC_ERR_INVALID;
+    std::unique_ptr<qc_scf_state> guard(st);
+    st->S = S; st->uhf = uhf;
+    st->nocc[0] = st->nocc[1] = S->nelec / 2;                             // rhf.rs:176 / uhf.rs:43-45
+    if (uhf && (n_alpha > 0 || n_beta > 0)) { st->nocc[0] = n_alpha; st->nocc[1] = n_beta; }
+    if (st->nocc[0] < 0 || st->nocc[1] < 0 || st->nocc[0] > n || st->nocc[1] > n) return QC_ERR_INVALID;
+    const int nspin = uhf ? 2 : 1;
+    if ((rc = st->W.init(n)) != QC_OK) return rc;
+    if (st->D.alloc(nspin * nn) != QC_OK || st->Dn.alloc(nn) != QC_OK || st->G.alloc(nspin * nn) != QC_OK ||
+        st->Cs.alloc(nspin * nn) != QC_OK || st->ws.alloc(nspin * n) != QC_OK) return QC_ERR_HIP;
     std::vector<double> h_eht;
-    if ((rc = scf_setup(S, W, h_eht)) != QC_OK) return rc;              // rhf.rs:41-49
-    if ((rc = huckel_density(S, W, h_eht, nocc, 2.0, D.p)) != QC_OK) return rc;   // rhf.rs:50
-    DeviceDiis diis(4, 6, n);                                           // rhf.rs:65
-    if ((rc = diis.init()) != QC_OK) return rc;
-    QC_HIP_CHECK(hipStreamSynchronize(st));
-    out->ms_setup = now_ms() - t_begin;
-    hipEvent_t ev0, ev1, ev2;
-    QC_HIP_CHECK(hipEventCreate(&ev0)); QC_HIP_CHECK(hipEventCreate(&ev1)); QC_HIP_CHECK(hipEventCreate(&ev2));
+    if ((rc = scf_setup(S, st->W, h_eht)) != QC_OK) return rc;           // rhf.rs:41-49
+    for (int s = 0; s < nspin; ++s)                                       // rhf.rs:50 / uhf.rs:60-63
+        if ((rc = huckel_density(S, st->W, h_eht, st->nocc[s], uhf ? 1.0 : 2.0, st->D.p + s * nn)) != QC_OK) return rc;
+    for (int s = 0; s < nspin; ++s) {                                     // Diis::new(4,6) rhf.rs:65 / (2,8) uhf.rs:76-78
+        st->diis[s] = uhf ? new DeviceDiis(2, 8, n) : new DeviceDiis(4, 6, n);
+        if ((rc = st->diis[s]->init()) != QC_OK) return rc;
+    }
+    QC_HIP_CHECK(hipEventCreate(&st->ev0)); QC_HIP_CHECK(hipEventCreate(&st->ev1)); QC_HIP_CHECK(hipEventCreate(&st->ev2));
+    QC_HIP_CHECK(hipStreamSynchronize(S->stream));
+    st->ms_setup = now_ms() - t0;
+    *out = guard.release();
+    return QC_OK;
+}
+
+// one pass of the loop body.  RHF: rhf.rs:67-88.  UHF: uhf.rs:81-137 (returns the reference's `density_rms`,
+// i.e. (rms_a + rms_b) / 2, and the energy expression of uhf.rs:145-153 evaluated every pass).
+static int scf_iterate(qc_scf_state *st, double *energy, double *rms_out) {
+    qc_system *S = st->S;
+    const int n = S->nbasis;
+    const size_t nn = (size_t)n * n;
+    hipStream_t sm = S->stream;
+    const int nspin = st->uhf ? 2 : 1;
+    int rc;
+    QC_HIP_CHECK(hipEventRecord(st->ev0, sm));
+    // G of every spin from the *old* densities, one pass over the ERIs
+    if ((rc = qc_fock_build_device(S, st->D.p, st->uhf ? st->D.p + nn : nullptr, st->G.p, st->uhf ? st->G.p + nn : nullptr, st->uhf)) != QC_OK) return rc;
+    QC_HIP_CHECK(hipEventRecord(st->ev1, sm));
+    for (int s = 0; s < nspin; ++s) {
+        if ((rc = roothaan_step(S, st->W, *st->diis[s], st->G.p + s * nn, st->D.p + s * nn, st->ws.p + s * n)) != QC_OK) return rc;
+        QC_HIP_CHECK(hipMemcpyAsync(st->Cs.p + s * nn, st->W.C.p, nn * sizeof(double), hipMemcpyDeviceToDevice, sm));
+    }
+    double rms_sum = 0.0, e_sum = 0.0;
+    for (int s = 0; s < nspin; ++s) {
+        if (st->nocc[s] > 0) qc_gemm(sm, n, n, st->nocc[s], st->uhf ? 1.0 : 2.0, st->Cs.p + s * nn, n, false, st->Cs.p + s * nn, n, true, 0.0, st->Dn.p, n);
+        else QC_HIP_CHECK(hipMemsetAsync(st->Dn.p, 0, nn * sizeof(double), sm));
+        qc_energy_rms(sm, n, st->Dn.p, st->D.p + s * nn, st->W.H.p, st->G.p + s * nn, st->W.scal.p + 2 * s);
+        QC_HIP_CHECK(hipMemcpyAsync(st->D.p + s * nn, st->Dn.p, nn * sizeof(double), hipMemcpyDeviceToDevice, sm));   // D += 1.0 * dD
+    }
+    double er[4];
+    QC_HIP_CHECK(hipMemcpyAsync(er, st->W.scal.p, 2 * nspin * sizeof(double), hipMemcpyDeviceToHost, sm));
+    QC_HIP_CHECK(hipEventRecord(st->ev2, sm));
+    QC_HIP_CHECK(hipStreamSynchronize(sm));
+    for (int s = 0; s < nspin; ++s) { e_sum += er[2 * s]; rms_sum += std::sqrt(er[2 * s + 1] / n); }
+    float ms_f = 0, ms_l = 0;
+    (void)hipEventElapsedTime(&ms_f, st->ev0, st->ev1); (void)hipEventElapsedTime(&ms_l, st->ev1, st->ev2);
+    st->ms_fock += ms_f; st->ms_linalg += ms_l;
+    if (energy) *energy = e_sum;
+    if (rms_out) *rms_out = st->uhf ? rms_sum / 2.0 : rms_sum;
+    return QC_OK;
+}
+
+static int scf_run(qc_system *S, const qc_hf_config *cfg, qc_hf_output *out, bool uhf) {
+    if (!S || !cfg || !out || !out->orbital_energies || (uhf && !out->orbital_energies_beta)) return QC_ERR_INVALID;
+    const double t_begin = now_ms();
+    qc_scf_state *st = nullptr;
+    int rc = scf_begin(S, uhf, cfg->n_alpha, cfg->n_beta, &st);
+    if (rc != QC_OK) return rc;
+    std::unique_ptr<qc_scf_state> guard(st);
+    const int n = S->nbasis;
+    out->nuclear_repulsion = qc_nuclear_repulsion(S);                    // rhf.rs:39
+    out->electronic_energy = 0.0; out->iterations = 0;
     int status = QC_NOT_CONVERGED;
-    for (size_t it = 0; it <= cfg->max_iterations; ++it) {              // rhf.rs:66 (inclusive range)
-        QC_HIP_CHECK(hipEventRecord(ev0, st));
-        if ((rc = qc_fock_build_device(S, D.p, nullptr, G.p, nullptr, false)) != QC_OK) { status = rc; break; }   // rhf.rs:67-68
-        QC_HIP_CHECK(hipEventRecord(ev1, st));
-        rc = roothaan_step(S, W, diis, G.p, D.p, W.w.p);                // rhf.rs:70-76
+    for (size_t it = 0; it <= cfg->max_iterations; ++it) {               // inclusive range, rhf.rs:66 / uhf.rs:80
+        double e = 0.0, rms = 0.0;
+        rc = scf_iterate(st, &e, &rms);
         if (rc != QC_OK) { status = rc; break; }
-        qc_gemm(st, n, n, nocc, 2.0, W.C.p, n, false, W.C.p, n, true, 0.0, Dn.p, n);    // rhf.rs:78
-        qc_energy_rms(st, n, Dn.p, D.p, W.H.p, G.p, W.scal.p);          // rhf.rs:84-88 (updated D, G of this iteration)
-        double er[2];
-        QC_HIP_CHECK(hipMemcpyAsync(er, W.scal.p, 2 * sizeof(double), hipMemcpyDeviceToHost, st));
-        QC_HIP_CHECK(hipMemcpyAsync(D.p, Dn.p, nn * sizeof(double), hipMemcpyDeviceToDevice, st));   // D += 1.0 * dD (rhf.rs:80-82)
-        QC_HIP_CHECK(hipEventRecord(ev2, st));
-        QC_HIP_CHECK(hipStreamSynchronize(st));
-        float ms_f = 0, ms_l = 0;
-        (void)hipEventElapsedTime(&ms_f, ev0, ev1); (void)hipEventElapsedTime(&ms_l, ev1, ev2);
-        out->ms_fock_total += ms_f; out->ms_linalg_total += ms_l;
-        const double rms = std::sqrt(er[1] / n);
-        if (rms < cfg->epsilon) {                                       // rhf.rs:94
-            out->electronic_energy = er[0];
-            out->iterations = it;
-            QC_HIP_CHECK(hipMemcpy(out->orbital_energies, W.w.p, n * sizeof(double), hipMemcpyDeviceToHost));
+        const bool conv = uhf ? (rms / 2.0 < cfg->epsilon) : (rms < cfg->epsilon);   // uhf.rs:139 / rhf.rs:94
+        if (conv) {
+            out->electronic_energy = e; out->iterations = it;
+            QC_HIP_CHECK(hipMemcpy(out->orbital_energies, st->ws.p, n * sizeof(double), hipMemcpyDeviceToHost));
+            if (uhf) QC_HIP_CHECK(hipMemcpy(out->orbital_energies_beta, st->ws.p + n, n * sizeof(double), hipMemcpyDeviceToHost));
             status = QC_OK;
             break;
         }
     }
-    (void)hipEventDestroy(ev0); (void)hipEventDestroy(ev1); (void)hipEventDestroy(ev2);
+    out->ms_setup = st->ms_setup; out->ms_fock_total = st->ms_fock; out->ms_linalg_total = st->ms_linalg;
     out->ms_total = now_ms() - t_begin;
     return status;
 }
 
-// unrestricted_hartree_fock (uhf.rs:36-167); n_alpha/n_beta extension per SURVEY.md 8f item 4
-int qc_scf_uhf(qc_system *S, const qc_hf_config *cfg, qc_hf_output *out) {
-    if (!S || !cfg || !out || !out->orbital_energies || !out->orbital_energies_beta) return QC_ERR_INVALID;
-    const double t_begin = now_ms();
-    int rc = qc_device_init(S);
-    if (rc != QC_OK) return rc;
-    const int n = S->nbasis;
-    int nocc[2] = {S->nelec / 2, S->nelec / 2};                        // uhf.rs:43-45
-    if (cfg->n_alpha > 0 || cfg->n_beta > 0) { nocc[0] = cfg->n_alpha; nocc[1] = cfg->n_beta; }
-    if (nocc[0] < 0 || nocc[1] < 0 || nocc[0] > n || nocc[1] > n) return QC_ERR_INVALID;
-    const size_t nn = (size_t)n * n;
-    hipStream_t st = S->stream;
-    ScfWork W;
-    if ((rc = W.init(n)) != QC_OK) return rc;
-    DevBuf D, Dn, G, Cs, ws;                                            // two spins back to back
-    if (D.alloc(2 * nn) != QC_OK || Dn.alloc(nn) != QC_OK || G.alloc(2 * nn) != QC_OK || Cs.alloc(2 * nn) != QC_OK || ws.alloc(2 * n) != QC_OK) return QC_ERR_HIP;
-    out->nuclear_repulsion = qc_nuclear_repulsion(S);
-    out->electronic_energy = 0.0; out->iterations = 0;
-    out->ms_fock_total = out->ms_linalg_total = 0.0;
-    std::vector<double> h_eht;
-    if ((rc = scf_setup(S, W, h_eht)) != QC_OK) return rc;
-    for (int s = 0; s < 2; ++s)                                         // uhf.rs:60-63 (same guess, no factor 2)
-        if ((rc = huckel_density(S, W, h_eht, nocc[s], 1.0, D.p + s * nn)) != QC_OK) return rc;
-    DeviceDiis diis0(2, 8, n), diis1(2, 8, n);                          // uhf.rs:76-78
-    if ((rc = diis0.init()) != QC_OK || (rc = diis1.init()) != QC_OK) return rc;
-    DeviceDiis *diis[2] = {&diis0, &diis1};
-    QC_HIP_CHECK(hipStreamSynchronize(st));
-    out->ms_setup = now_ms() - t_begin;
-    hipEvent_t ev0, ev1, ev2;
-    QC_HIP_CHECK(hipEventCreate(&ev0)); QC_HIP_CHECK(hipEventCreate(&ev1)); QC_HIP_CHECK(hipEventCreate(&ev2));
-    int status = QC_NOT_CONVERGED;
-    for (size_t it = 0; it <= cfg->max_iterations && status == QC_NOT_CONVERGED; ++it) {
-        QC_HIP_CHECK(hipEventRecord(ev0, st));
-        // both spins' G from the *old* densities in one pass over the ERIs (uhf.rs:81-108)
-        if ((rc = qc_fock_build_device(S, D.p, D.p + nn, G.p, G.p + nn, true)) != QC_OK) { status = rc; break; }
-        QC_HIP_CHECK(hipEventRecord(ev1, st));
-        for (int s = 0; s < 2; ++s) {
-            rc = roothaan_step(S, W, *diis[s], G.p + s * nn, D.p + s * nn, ws.p + s * n);
-            if (rc != QC_OK) { status = rc; break; }
-            QC_HIP_CHECK(hipMemcpyAsync(Cs.p + s * nn, W.C.p, nn * sizeof(double), hipMemcpyDeviceToDevice, st));
-        }
-        if (status != QC_NOT_CONVERGED) break;
-        double rms_sum = 0.0, e_sum = 0.0;
-        for (int s = 0; s < 2; ++s) {                                   // uhf.rs:112-135
-            if (nocc[s] > 0) qc_gemm(st, n, n, nocc[s], 1.0, Cs.p + s * nn, n, false, Cs.p + s * nn, n, true, 0.0, Dn.p, n);
-            else QC_HIP_CHECK(hipMemsetAsync(Dn.p, 0, nn * sizeof(double), st));
-            qc_energy_rms(st, n, Dn.p, D.p + s * nn, W.H.p, G.p + s * nn, W.scal.p);
-            double er[2];
-            QC_HIP_CHECK(hipMemcpyAsync(er, W.scal.p, 2 * sizeof(double), hipMemcpyDeviceToHost, st));
-            QC_HIP_CHECK(hipMemcpyAsync(D.p + s * nn, Dn.p, nn * sizeof(double), hipMemcpyDeviceToDevice, st));
-            QC_HIP_CHECK(hipStreamSynchronize(st));
-            rms_sum += std::sqrt(er[1] / n);
-            e_sum += er[0];
-        }
-        QC_HIP_CHECK(hipEventRecord(ev2, st));
-        QC_HIP_CHECK(hipStreamSynchronize(st));
-        float ms_f = 0, ms_l = 0;
-        (void)hipEventElapsedTime(&ms_f, ev0, ev1); (void)hipEventElapsedTime(&ms_l, ev1, ev2);
-        out->ms_fock_total += ms_f; out->ms_linalg_total += ms_l;
-        const double density_rms = rms_sum / 2.0;                       // uhf.rs:137
-        if (density_rms / 2.0 < cfg->epsilon) {                         // uhf.rs:139
-            out->electronic_energy = e_sum;                             // uhf.rs:145-153
-            out->iterations = it;
-            QC_HIP_CHECK(hipMemcpy(out->orbital_energies, ws.p, n * sizeof(double), hipMemcpyDeviceToHost));
-            QC_HIP_CHECK(hipMemcpy(out->orbital_energies_beta, ws.p + n, n * sizeof(double), hipMemcpyDeviceToHost));
-            status = QC_OK;
-        }
-    }
-    (void)hipEventDestroy(ev0); (void)hipEventDestroy(ev1); (void)hipEventDestroy(ev2);
-    out->ms_total = now_ms() - t_begin;
-    return status;
+extern "C" {
+
+int qc_scf_begin_rhf(qc_system *S, qc_scf_state **out) { return scf_begin(S, false, 0, 0, out); }
+int qc_scf_begin_uhf(qc_system *S, int n_alpha, int n_beta, qc_scf_state **out) { return scf_begin(S, true, n_alpha, n_beta, out); }
+int qc_scf_iterate(qc_scf_state *st, double *electronic_energy, double *density_rms) {
+    if (!st) return QC_ERR_INVALID;
+    return scf_iterate(st, electronic_energy, density_rms);
 }
+int qc_scf_orbital_energies(qc_scf_state *st, int spin, double *out) {
+    if (!st || !out || spin < 0 || spin > (st->uhf ? 1 : 0)) return QC_ERR_INVALID;
+    QC_HIP_CHECK(hipMemcpy(out, st->ws.p + (size_t)spin * st->S->nbasis, st->S->nbasis * sizeof(double), hipMemcpyDeviceToHost));
+    return QC_OK;
+}
+int qc_scf_density(qc_scf_state *st, int spin, double *out) {
+    if (!st || !out || spin < 0 || spin > (st->uhf ? 1 : 0)) return QC_ERR_INVALID;
+    const size_t nn = (size_t)st->S->nbasis * st->S->nbasis;
+    QC_HIP_CHECK(hipMemcpy(out, st->D.p + spin * nn, nn * sizeof(double), hipMemcpyDeviceToHost));
+    return QC_OK;
+}
+int qc_scf_timings(qc_scf_state *st, double *ms_setup, double *ms_fock, double *ms_linalg) {
+    if (!st) return QC_ERR_INVALID;
+    if (ms_setup) *ms_setup = st->ms_setup;
+    if (ms_fock) *ms_fock = st->ms_fock;
+    if (ms_linalg) *ms_linalg = st->ms_linalg;
+    return QC_OK;
+}
+void qc_scf_end(qc_scf_state *st) { delete st; }
+
+// restricted_hartree_fock (rhf.rs:32-108) / unrestricted_hartree_fock (uhf.rs:36-167)
+int qc_scf_rhf(qc_system *S, const qc_hf_config *cfg, qc_hf_output *out) { return scf_run(S, cfg, out, false); }
+int qc_scf_uhf(qc_system *S, const qc_hf_config *cfg, qc_hf_output *out) { return scf_run(S, cfg, out, true); }
 
 // ---- multi-GPU
 int qc_comm_unique_id(uint8_t id[128]) {

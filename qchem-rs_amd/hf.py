@@ -35,7 +35,8 @@ EXPORTS = ["qc_system_create", "qc_system_destroy", "qc_nbasis", "qc_nelectrons"
            "qc_nuclear_repulsion", "qc_overlap", "qc_kinetic", "qc_nuclear", "qc_eri_full", "qc_fock_rhf", "qc_fock_uhf",
            "qc_fock_rhf_device", "qc_fock_uhf_device", "qc_sym_eig", "qc_scf_rhf", "qc_scf_uhf", "qc_comm_unique_id",
            "qc_comm_init", "qc_set_shard", "qc_plan_shard", "qc_set_stream", "qc_device_ready", "qc_work_stats_get",
-           "qc_fock_profile"]
+           "qc_fock_profile", "qc_plan_shard_quartets", "qc_scf_begin_rhf", "qc_scf_begin_uhf", "qc_scf_iterate",
+           "qc_scf_orbital_energies", "qc_scf_density", "qc_scf_timings", "qc_scf_end"]
 
 
 class QcError(RuntimeError):
@@ -106,6 +107,13 @@ def lib():
         L.qc_device_ready.argtypes = []
         L.qc_work_stats_get.argtypes = [vp, C.POINTER(WorkStats)]
         L.qc_fock_profile.argtypes = [vp, vp, vp, C.c_int, vp, vp, vp, vp, vp, vp]
+        L.qc_scf_begin_rhf.argtypes = [vp, C.POINTER(vp)]
+        L.qc_scf_begin_uhf.argtypes = [vp, C.c_int, C.c_int, C.POINTER(vp)]
+        L.qc_scf_iterate.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_double)]
+        L.qc_scf_orbital_energies.argtypes = [vp, C.c_int, _dp]
+        L.qc_scf_density.argtypes = [vp, C.c_int, _dp]
+        L.qc_scf_timings.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double)]
+        L.qc_scf_end.argtypes = [vp]; L.qc_scf_end.restype = None
         _lib = L
     return _lib
 
@@ -202,6 +210,49 @@ class System:
         _check(lib().qc_fock_profile(self._h, C.c_void_p(dD_ptr), C.c_void_p(dG_ptr), reps, p(ms), p(cid), p(nq), p(by), p(fl),
                                      C.cast(C.byref(tot), C.c_void_p)), "qc_fock_profile")
         return dict(class_ms=ms, class_id=cid, quartets=nq, bytes=by, flops=fl, total_ms=tot.value)
+
+
+class ScfStepper:
+    """One loop-body pass per call (`qc_scf_begin_* / qc_scf_iterate / qc_scf_end`): what a host that owns the
+    convergence loop binds, and what bench.py times."""
+
+    def __init__(self, system: "System", uhf: bool = False, n_alpha: int = 0, n_beta: int = 0):
+        self.system = system
+        self.uhf = uhf
+        self._st = C.c_void_p()
+        if uhf:
+            _check(lib().qc_scf_begin_uhf(system.handle, n_alpha, n_beta, C.byref(self._st)), "qc_scf_begin_uhf")
+        else:
+            _check(lib().qc_scf_begin_rhf(system.handle, C.byref(self._st)), "qc_scf_begin_rhf")
+
+    def iterate(self):
+        e, r = C.c_double(), C.c_double()
+        rc = lib().qc_scf_iterate(self._st, C.byref(e), C.byref(r))
+        if rc == QC_DIIS_SINGULAR:
+            raise RuntimeError("DIIS failed")
+        _check(rc, "qc_scf_iterate")
+        return e.value, r.value
+
+    def orbital_energies(self, spin=0):
+        w = np.zeros(self.system.n); _check(lib().qc_scf_orbital_energies(self._st, spin, w), "qc_scf_orbital_energies"); return w
+
+    def density(self, spin=0):
+        D = np.zeros((self.system.n, self.system.n)); _check(lib().qc_scf_density(self._st, spin, D), "qc_scf_density"); return D
+
+    def timings(self):
+        a, b, c = C.c_double(), C.c_double(), C.c_double()
+        _check(lib().qc_scf_timings(self._st, C.byref(a), C.byref(b), C.byref(c)), "qc_scf_timings")
+        return dict(setup=a.value, fock=b.value, linalg=c.value)
+
+    def close(self):
+        if self._st:
+            lib().qc_scf_end(self._st); self._st = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 def comm_unique_id() -> bytes:
