@@ -110,11 +110,12 @@ struct DeviceDiis {
 
 struct ScfWork {
     int n;
-    DevBuf H, S, X, t1, t2, Fp, Cp, C, w, ework, Fd, scal;
+    DevBuf H, S, X, t1, t2, Fp, Cp, C, w, ework, Fd, scal, CpPrev[2];
+    bool have_prev[2] = {false, false};
     int init(int n_) {
         n = n_;
         const size_t nn = (size_t)n * n;
-        DevBuf *all[] = {&H, &S, &X, &t1, &t2, &Fp, &Cp, &C, &ework, &Fd};
+        DevBuf *all[] = {&H, &S, &X, &t1, &t2, &Fp, &Cp, &C, &ework, &Fd, &CpPrev[0], &CpPrev[1]};
         for (auto b : all) if (b->alloc(nn) != QC_OK) return QC_ERR_HIP;
         if (w.alloc(n) != QC_OK || scal.alloc(16) != QC_OK) return QC_ERR_HIP;
         return QC_OK;
@@ -169,7 +170,7 @@ int huckel_density(qc_system *S, ScfWork &W, const std::vector<double> &h_eht, i
 }
 
 // One spin's Roothaan step: F = H + G; e = FDS - SDF; DIIS; F' = X^T F X; eig; C = X C'   (rhf.rs:70-76)
-int roothaan_step(qc_system *S, ScfWork &W, DeviceDiis &diis, const double *dG, const double *dD, double *dw_out) {
+int roothaan_step(qc_system *S, ScfWork &W, DeviceDiis &diis, const double *dG, const double *dD, double *dw_out, int spin) {
     const int n = S->nbasis;
     hipStream_t st = S->stream;
     qc_axpby(st, n, 1.0, W.H.p, 1.0, dG, W.t1.p);                                        // F
@@ -180,8 +181,12 @@ int roothaan_step(qc_system *S, ScfWork &W, DeviceDiis &diis, const double *dG, 
     if (rc != QC_OK) return rc;
     qc_gemm(st, n, n, n, 1.0, W.Fd.p, n, false, W.X.p, n, false, 0.0, W.t1.p, n);        // F X
     qc_gemm(st, n, n, n, 1.0, W.X.p, n, true, W.t1.p, n, false, 0.0, W.Fp.p, n);         // X^T (F X)
-    rc = device_sorted_eigs(S, W, W.Fp.p, W.Cp.p, dw_out);
+    // sorted_eigs (rhf.rs:75), warm-started from this spin's previous eigenvectors once they exist
+    if (W.have_prev[spin]) rc = qc_eig_device_warm(st, n, W.Fp.p, W.CpPrev[spin].p, W.Cp.p, dw_out, W.ework.p, W.t1.p, W.t2.p);
+    else rc = device_sorted_eigs(S, W, W.Fp.p, W.Cp.p, dw_out);
     if (rc != QC_OK) return rc;
+    QC_HIP_CHECK(hipMemcpyAsync(W.CpPrev[spin].p, W.Cp.p, sizeof(double) * n * n, hipMemcpyDeviceToDevice, st));
+    W.have_prev[spin] = true;
     qc_gemm(st, n, n, n, 1.0, W.X.p, n, false, W.Cp.p, n, false, 0.0, W.C.p, n);         // C = X C'
     return QC_OK;
 }
@@ -261,9 +266,7 @@ int qc_eri_full(qc_system *S, double *out) {
     DevBuf T;
     if (T.alloc(n4) != QC_OK) return QC_ERR_HIP;
     QC_HIP_CHECK(hipMemsetAsync(T.p, 0, n4 * sizeof(double), S->stream));
-    QcFockArgs a{};
-    a.eri_out = T.p;
-    rc = qc_launch_fock_classes(S, a, nullptr);
+    rc = qc_launch_eri_full(S, T.p);
     if (rc != QC_OK) return rc;
     QC_HIP_CHECK(hipMemcpyAsync(out, T.p, n4 * sizeof(double), hipMemcpyDeviceToHost, S->stream));
     QC_HIP_CHECK(hipStreamSynchronize(S->stream));
@@ -276,23 +279,39 @@ int qc_fock_build_device(qc_system *S, const double *dDa, const double *dDb, dou
     const int n = S->nbasis;
     const size_t nn = (size_t)n * n;
     hipStream_t st = S->stream;
-    const int nspin = uhf ? 2 : 1;
-    QC_HIP_CHECK(hipMemsetAsync(S->d_Gtmp, 0, nspin * nn * sizeof(double), st));
+    // Spin symmetry: the reference evaluates both spins with identical arithmetic (uhf.rs:210-227), so bitwise-equal
+    // densities give bitwise-equal G (its closed-shell UHF never breaks symmetry).  Atomic accumulation
+    // order would not preserve that, so equal spins are detected and digested once.
+    bool twin = false;
+    if (uhf) {
+        int diff = 1;
+        QC_HIP_CHECK(hipMemsetAsync(S->d_flag, 0, sizeof(int), st));
+        qc_count_diff(st, nn, dDa, dDb, S->d_flag);
+        QC_HIP_CHECK(hipMemcpyAsync(&diff, S->d_flag, sizeof(int), hipMemcpyDeviceToHost, st));
+        QC_HIP_CHECK(hipStreamSynchronize(st));
+        twin = (diff == 0);
+    }
+    const bool two = uhf && !twin;
+    const int nspin = two ? 2 : 1;
+    QC_HIP_CHECK(hipMemsetAsync(S->d_Gtmp, 0, (size_t)QC_NREP * nspin * nn * sizeof(double), st));
     QcFockArgs a{};
+    a.nrep = QC_NREP; a.rep_stride = nspin * nn;
     if (uhf) {
         qc_axpby(st, n, 1.0, dDa, 1.0, dDb, S->d_Dj);
-        a.Dj = S->d_Dj; a.Dk0 = dDa; a.Dk1 = dDb; a.cK = 1.0;
+        a.Dj = S->d_Dj; a.Dk0 = dDa; a.Dk1 = two ? dDb : nullptr; a.cK = 1.0;
     } else {
         a.Dj = dDa; a.Dk0 = dDa; a.Dk1 = nullptr; a.cK = 0.5;
     }
     a.G0 = S->d_Gtmp; a.G1 = S->d_Gtmp + nn;
     int rc = qc_launch_fock_classes(S, a, nullptr);
     if (rc != QC_OK) return rc;
+    qc_reduce_replicas(st, nspin * nn, QC_NREP, nspin * nn, S->d_Gtmp);
     if (S->comm) {   // partial Fock matrices -> full, one all-reduce per build ([Ga|Gb] concatenated for UHF)
         if (ncclAllReduce(S->d_Gtmp, S->d_Gtmp, nspin * nn, ncclDouble, ncclSum, (ncclComm_t)S->comm, st) != ncclSuccess) return QC_ERR_RCCL;
     }
     qc_symmetrize_add(st, n, S->d_Gtmp, dGa);
-    if (uhf) qc_symmetrize_add(st, n, S->d_Gtmp + nn, dGb);
+    if (two) qc_symmetrize_add(st, n, S->d_Gtmp + nn, dGb);
+    else if (uhf) QC_HIP_CHECK(hipMemcpyAsync(dGb, dGa, nn * sizeof(double), hipMemcpyDeviceToDevice, st));
     return QC_OK;
 }
 
@@ -423,7 +442,7 @@ static int scf_iterate(qc_scf_state *st, double *energy, double *rms_out) {
     if ((rc = qc_fock_build_device(S, st->D.p, st->uhf ? st->D.p + nn : nullptr, st->G.p, st->uhf ? st->G.p + nn : nullptr, st->uhf)) != QC_OK) return rc;
     QC_HIP_CHECK(hipEventRecord(st->ev1, sm));
     for (int s = 0; s < nspin; ++s) {
-        if ((rc = roothaan_step(S, st->W, *st->diis[s], st->G.p + s * nn, st->D.p + s * nn, st->ws.p + s * n)) != QC_OK) return rc;
+        if ((rc = roothaan_step(S, st->W, *st->diis[s], st->G.p + s * nn, st->D.p + s * nn, st->ws.p + s * n, s)) != QC_OK) return rc;
         QC_HIP_CHECK(hipMemcpyAsync(st->Cs.p + s * nn, st->W.C.p, nn * sizeof(double), hipMemcpyDeviceToDevice, sm));
     }
     double rms_sum = 0.0, e_sum = 0.0;
@@ -589,8 +608,9 @@ int qc_fock_profile(qc_system *S, const double *dD, double *dG, int reps, float 
     hipEvent_t e0, e1;
     QC_HIP_CHECK(hipEventCreate(&e0)); QC_HIP_CHECK(hipEventCreate(&e1));
     for (int r = 0; r < reps; ++r) {
-        QC_HIP_CHECK(hipMemsetAsync(S->d_Gtmp, 0, nn * sizeof(double), S->stream));
+        QC_HIP_CHECK(hipMemsetAsync(S->d_Gtmp, 0, (size_t)QC_NREP * nn * sizeof(double), S->stream));
         QcFockArgs a{};
+        a.nrep = QC_NREP; a.rep_stride = nn;
         a.Dj = dD; a.Dk0 = dD; a.Dk1 = nullptr; a.cK = 0.5; a.G0 = S->d_Gtmp; a.G1 = S->d_Gtmp + nn;
         if ((rc = qc_launch_fock_classes(S, a, one.data())) != QC_OK) return rc;
         for (size_t i = 0; i < acc.size(); ++i) acc[i] += one[i];

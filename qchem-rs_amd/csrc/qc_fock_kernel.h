@@ -7,26 +7,33 @@
 // coefficients folded in; Rmat[h1][h2] = (-1)^{|h2|} R_{h1+h2}) and immediately contracted with the density into the
 // six J/K blocks.  f64 throughout.
 //
-// Mapping (one wave = one workgroup = one quartet at a time, grid-stride over the class's task list):
-//   lanes = G groups x C columns, C = pow2 >= n_cd (ket function pairs), G = 64 / C.
+// Work unit = "slot": one shell quartet (bra pair | ket pair) restricted to a range of its primitive quartets (deeply
+// contracted quartets are cut into several slots so no lane group runs a long sequential loop; digestion is linear,
+// every slot digests its own partial block).
+// Mapping (one wave = one workgroup, grid-stride over batches of G slots of one launch bucket (LAB, LCD, C)):
+//   lanes = G groups x C columns, C = pow2 >= n_cd (ket function pairs), G = 64 / C; group g works on slot g of the
+//   batch, completely independently of the other groups (own LDS region, own descriptors, own digestion).
 //   * a lane owns one ket column cd: its ket expansion column e[HCD] and the half-contracted W[HAB] live in VGPRs;
-//   * the G groups split the primitive quartets of a contracted quartet (each group has its own R table in LDS);
-//     for (ss|ss) this degenerates to one primitive quartet per lane, for high-L classes to one R table per wave;
+//   * for (ss|ss) this is one primitive-quartet stream per lane (64 quartets per wave), for the high-L classes one
+//     quartet per wave with the R table shared by 64 columns;
 //   * R tables are built cooperatively by the C lanes of a group in LDS; step 2 reads each R_s once (gen_step2.py);
-//   * the contracted block I[ab][cd] is accumulated in LDS (ds_add_f64), density tiles are staged in LDS, and the six
-//     J/K block updates are reduced over LDS and flushed with global_atomic_add_f64.
+//   * the contracted block I[ab][cd] lives in the group's LDS region, density tiles are staged next to it, and the six
+//     J/K block updates are reduced over LDS and flushed with global_atomic_add_f64 into one of `nrep` replicas.
 #pragma once
 #include "qc_internal.h"
 
 struct QcKernelArgs {
     const QcPairDesc *pairs;
     const double *pairdata;
-    const QcTask *tasks;
-    int ntasks;
+    const QcSlot *slots;      // work units of this launch: (bra pair, ket pair, primitive-quartet range)
+    int nslots;
+    int slot_words;           // LDS doubles per lane group (R work array + I block + density tiles)
     const double *boys;
     int n;
     const double *Dj, *Dk0, *Dk1;
-    double *G0, *G1;
+    double *G0, *G1;          // replica 0 of the accumulation targets
+    size_t rep_stride;        // doubles between replicas
+    int nrep;                 // accumulation replicas (spreads global-atomic contention)
     double cK;
     double *eri_out;
 };
@@ -130,51 +137,55 @@ __device__ __forceinline__ void qc_build_r(double *__restrict__ Rw, int li, int 
     }
 }
 
-template <int LAB, int LCD>
+template <int LAB, int LCD, int LGC>
 __global__ __launch_bounds__(64) void qc_fock_class_kernel(const QcKernelArgs a) {
     constexpr int L = LAB + LCD, HAB = qc_nherm(LAB), HCD = qc_nherm(LCD), RW = qc_rwork(L);
+    constexpr int C = 1 << LGC, G = 64 >> LGC;
     extern __shared__ double lds[];
-    const int lane = threadIdx.x;
+    const int lane = threadIdx.x, g = lane >> LGC, li = lane & (C - 1);
     const double *__restrict__ pd = a.pairdata;
     const int n = a.n;
     const bool uhf = a.Dk1 != nullptr;
+    double *const Rw = lds + (size_t)g * a.slot_words;     // this group's private LDS region
+    double *const Iblk = Rw + RW;
+    const size_t rep = (size_t)(blockIdx.x % a.nrep) * a.rep_stride;   // accumulation replica of this workgroup
 
-    for (int task = blockIdx.x; task < a.ntasks; task += gridDim.x) {
-        const QcTask tk = a.tasks[task];
-        const QcPairDesc pb = a.pairs[tk.bra], pk = a.pairs[tk.ket];
+    for (int wave = blockIdx.x; wave * G < a.nslots; wave += gridDim.x) {
+        const int slot = wave * G + g;
+        const bool active = slot < a.nslots;
+        const QcSlot sl = a.slots[active ? slot : a.nslots - 1];
+        const QcPairDesc pb = a.pairs[sl.bra], pk = a.pairs[sl.ket];
         const int na = pb.na, nb = pb.nb, nc = pk.na, nd = pk.nb;
         const int nab = na * nb, ncd = nc * nd;
-        int C = 1, lgC = 0;
-        while (C < ncd && C < 64) { C <<= 1; ++lgC; }
-        const int G = 64 >> lgC, g = lane >> lgC, li = lane & (C - 1);
-        double *Rw = lds + g * RW;
-        double *Iblk = lds + G * RW;
         double *tDj_ab = Iblk + nab * ncd, *tDj_cd = tDj_ab + nab;
         double *tK = tDj_cd + ncd;   // per spin: Dk_ac, Dk_ad, Dk_bc, Dk_bd
         const int ktile = na * nc + na * nd + nb * nc + nb * nd;
 
-        for (int i = lane; i < nab * ncd; i += 64) Iblk[i] = 0.0;
-        if (a.eri_out == nullptr) {   // stage the density tiles this quartet touches
-            for (int i = lane; i < nab; i += 64) tDj_ab[i] = a.Dj[(size_t)(pb.offa + i / nb) * n + pb.offb + i % nb];
-            for (int i = lane; i < ncd; i += 64) tDj_cd[i] = a.Dj[(size_t)(pk.offa + i / nd) * n + pk.offb + i % nd];
-            for (int s = 0; s < (uhf ? 2 : 1); ++s) {
-                const double *Dk = s ? a.Dk1 : a.Dk0;
-                double *t0 = tK + s * ktile, *t1 = t0 + na * nc, *t2 = t1 + na * nd, *t3 = t2 + nb * nc;
-                for (int i = lane; i < na * nc; i += 64) t0[i] = Dk[(size_t)(pb.offa + i / nc) * n + pk.offa + i % nc];
-                for (int i = lane; i < na * nd; i += 64) t1[i] = Dk[(size_t)(pb.offa + i / nd) * n + pk.offb + i % nd];
-                for (int i = lane; i < nb * nc; i += 64) t2[i] = Dk[(size_t)(pb.offb + i / nc) * n + pk.offa + i % nc];
-                for (int i = lane; i < nb * nd; i += 64) t3[i] = Dk[(size_t)(pb.offb + i / nd) * n + pk.offb + i % nd];
+        if (active) {
+            for (int i = li; i < nab * ncd; i += C) Iblk[i] = 0.0;
+            if (a.eri_out == nullptr) {   // stage the density tiles this quartet touches
+                for (int i = li; i < nab; i += C) tDj_ab[i] = a.Dj[(size_t)(pb.offa + i / nb) * n + pb.offb + i % nb];
+                for (int i = li; i < ncd; i += C) tDj_cd[i] = a.Dj[(size_t)(pk.offa + i / nd) * n + pk.offb + i % nd];
+                for (int s = 0; s < (uhf ? 2 : 1); ++s) {
+                    const double *Dk = s ? a.Dk1 : a.Dk0;
+                    double *t0 = tK + s * ktile, *t1 = t0 + na * nc, *t2 = t1 + na * nd, *t3 = t2 + nb * nc;
+                    for (int i = li; i < na * nc; i += C) t0[i] = Dk[(size_t)(pb.offa + i / nc) * n + pk.offa + i % nc];
+                    for (int i = li; i < na * nd; i += C) t1[i] = Dk[(size_t)(pb.offa + i / nd) * n + pk.offb + i % nd];
+                    for (int i = li; i < nb * nc; i += C) t2[i] = Dk[(size_t)(pb.offb + i / nc) * n + pk.offa + i % nc];
+                    for (int i = li; i < nb * nd; i += C) t3[i] = Dk[(size_t)(pb.offb + i / nd) * n + pk.offb + i % nd];
+                }
             }
         }
-        __syncthreads();
-
         const int strideB = 4 + HAB * nab, strideK = 4 + HCD * ncd;
-        const int npq = pb.K * pk.K, chunk = (npq + G - 1) / G;
-        const int lo = g * chunk, hi = min(npq, lo + chunk);
+        const int len = active ? sl.hi - sl.lo : 0;
+        int maxlen = len;                                   // uniform trip count: the longest slot of this wave
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) maxlen = max(maxlen, __shfl_xor(maxlen, o, 64));
         const double *braBase = pd + pb.doff, *ketBase = pd + pk.doff;
+        const int npass = (LGC == 6) ? (ncd + 63) / 64 : 1;  // > 1 only for ket pairs with more than 64 function pairs
 
-        for (int cbase = 0; cbase < ncd; cbase += 64) {   // one pass unless the ket pair has > 64 function pairs
-            const int col = cbase + li;
+        for (int pass = 0; pass < npass; ++pass) {
+            const int col = pass * 64 + li;
             const bool colok = col < ncd;
             double W[HAB];
 #pragma unroll
@@ -187,15 +198,14 @@ __global__ __launch_bounds__(64) void qc_fock_class_kernel(const QcKernelArgs a)
                     double acc = 0.0;
 #pragma unroll
                     for (int h = 0; h < HAB; ++h) acc = fma(Eab[h * nab + ab], W[h], acc);
-                    if (colok) atomicAdd(&Iblk[ab * ncd + col], acc);
+                    if (colok) Iblk[ab * ncd + col] += acc;      // column `col` of this slot belongs to this lane alone
                 }
             };
 
-            for (int it = 0; it < chunk; ++it) {
-                const int pq = lo + it;
-                const bool valid = pq < hi;
-                const int pqc = valid ? pq : npq - 1;
-                const int ij = pqc / pk.K, kl = pqc - ij * pk.K;
+            for (int it = 0; it < maxlen; ++it) {
+                const bool valid = it < len;
+                const int pq = valid ? sl.lo + it : sl.lo;
+                const int ij = pq / pk.K, kl = pq - ij * pk.K;
                 if (valid && ij != cur_ij) {
                     if (cur_ij >= 0) flush(cur_ij);
 #pragma unroll
@@ -222,79 +232,83 @@ __global__ __launch_bounds__(64) void qc_fock_class_kernel(const QcKernelArgs a)
         }
         __syncthreads();
 
-        const double f = (pb.shA_eq_shB ? 0.5 : 1.0) * (pk.shA_eq_shB ? 0.5 : 1.0) * (tk.bra == tk.ket ? 0.5 : 1.0);
-        if (a.eri_out != nullptr) {
-            // materialise (ij|kl) with its 8 symmetry images: the tensor molint::eri returns (tests / plumbing only)
-            const size_t n1 = n, n2 = n1 * n1, n3 = n2 * n1;
-            for (int x = lane; x < nab * ncd; x += 64) {
-                const int ab = x / ncd, cd = x - ab * ncd;
-                const size_t i = pb.offa + ab / nb, j = pb.offb + ab % nb, k = pk.offa + cd / nd, l = pk.offb + cd % nd;
-                const double v = Iblk[x];
-                double *o = a.eri_out;
-                o[i * n3 + j * n2 + k * n1 + l] = v; o[j * n3 + i * n2 + k * n1 + l] = v;
-                o[i * n3 + j * n2 + l * n1 + k] = v; o[j * n3 + i * n2 + l * n1 + k] = v;
-                o[k * n3 + l * n2 + i * n1 + j] = v; o[l * n3 + k * n2 + i * n1 + j] = v;
-                o[k * n3 + l * n2 + j * n1 + i] = v; o[l * n3 + k * n2 + j * n1 + i] = v;
-            }
-        } else {
-            // J blocks: Gt_ab += 2f sum_cd I D_cd ; Gt_cd += 2f sum_ab I D_ab   (final G = Gt + Gt^T)
-            const double fj = 2.0 * f;
-            for (int ab = lane; ab < nab; ab += 64) {
-                double s = 0.0;
-                for (int cd = 0; cd < ncd; ++cd) s = fma(Iblk[ab * ncd + cd], tDj_cd[cd], s);
-                const size_t o = (size_t)(pb.offa + ab / nb) * n + pb.offb + ab % nb;
-                unsafeAtomicAdd(&a.G0[o], fj * s);
-                if (uhf) unsafeAtomicAdd(&a.G1[o], fj * s);
-            }
-            for (int cd = lane; cd < ncd; cd += 64) {
-                double s = 0.0;
-                for (int ab = 0; ab < nab; ++ab) s = fma(Iblk[ab * ncd + cd], tDj_ab[ab], s);
-                const size_t o = (size_t)(pk.offa + cd / nd) * n + pk.offb + cd % nd;
-                unsafeAtomicAdd(&a.G0[o], fj * s);
-                if (uhf) unsafeAtomicAdd(&a.G1[o], fj * s);
-            }
-            // K blocks: Gt_ac -= cK f sum_bd I D_bd, and the ad / bc / bd images
-            const double fk = -a.cK * f;
-            for (int s = 0; s < (uhf ? 2 : 1); ++s) {
-                double *Gs = s ? a.G1 : a.G0;
-                const double *t_ac = tK + s * ktile, *t_ad = t_ac + na * nc, *t_bc = t_ad + na * nd, *t_bd = t_bc + nb * nc;
-                for (int x = lane; x < na * nc; x += 64) {          // (i,k) <- sum_{j,l} I[ij,kl] D[j,l]
-                    const int i = x / nc, k = x - i * nc;
-                    double acc = 0.0;
-                    for (int j = 0; j < nb; ++j)
-                        for (int l = 0; l < nd; ++l) acc = fma(Iblk[(i * nb + j) * ncd + k * nd + l], t_bd[j * nd + l], acc);
-                    unsafeAtomicAdd(&Gs[(size_t)(pb.offa + i) * n + pk.offa + k], fk * acc);
+        if (active) {
+            const double f = (pb.shA_eq_shB ? 0.5 : 1.0) * (pk.shA_eq_shB ? 0.5 : 1.0) * (sl.bra == sl.ket ? 0.5 : 1.0);
+            if (a.eri_out != nullptr) {
+                // materialise (ij|kl) with its 8 symmetry images: the tensor molint::eri returns (tests / plumbing only;
+                // the host hands this mode unsplit slots, so plain stores are complete values)
+                const size_t n1 = n, n2 = n1 * n1, n3 = n2 * n1;
+                for (int x = li; x < nab * ncd; x += C) {
+                    const int ab = x / ncd, cd = x - ab * ncd;
+                    const size_t i = pb.offa + ab / nb, j = pb.offb + ab % nb, k = pk.offa + cd / nd, l = pk.offb + cd % nd;
+                    const double v = Iblk[x];
+                    double *o = a.eri_out;
+                    o[i * n3 + j * n2 + k * n1 + l] = v; o[j * n3 + i * n2 + k * n1 + l] = v;
+                    o[i * n3 + j * n2 + l * n1 + k] = v; o[j * n3 + i * n2 + l * n1 + k] = v;
+                    o[k * n3 + l * n2 + i * n1 + j] = v; o[l * n3 + k * n2 + i * n1 + j] = v;
+                    o[k * n3 + l * n2 + j * n1 + i] = v; o[l * n3 + k * n2 + j * n1 + i] = v;
                 }
-                for (int x = lane; x < na * nd; x += 64) {          // (i,l) <- sum_{j,k} I[ij,kl] D[j,k]
-                    const int i = x / nd, l = x - i * nd;
-                    double acc = 0.0;
-                    for (int j = 0; j < nb; ++j)
-                        for (int k = 0; k < nc; ++k) acc = fma(Iblk[(i * nb + j) * ncd + k * nd + l], t_bc[j * nc + k], acc);
-                    unsafeAtomicAdd(&Gs[(size_t)(pb.offa + i) * n + pk.offb + l], fk * acc);
+            } else {
+                double *G0 = a.G0 + rep, *G1 = a.G1 + rep;
+                // J blocks: Gt_ab += 2f sum_cd I D_cd ; Gt_cd += 2f sum_ab I D_ab   (final G = Gt + Gt^T)
+                const double fj = 2.0 * f;
+                for (int ab = li; ab < nab; ab += C) {
+                    double s = 0.0;
+                    for (int cd = 0; cd < ncd; ++cd) s = fma(Iblk[ab * ncd + cd], tDj_cd[cd], s);
+                    const size_t o = (size_t)(pb.offa + ab / nb) * n + pb.offb + ab % nb;
+                    unsafeAtomicAdd(&G0[o], fj * s);
+                    if (uhf) unsafeAtomicAdd(&G1[o], fj * s);
                 }
-                for (int x = lane; x < nb * nc; x += 64) {          // (j,k) <- sum_{i,l} I[ij,kl] D[i,l]
-                    const int j = x / nc, k = x - j * nc;
-                    double acc = 0.0;
-                    for (int i = 0; i < na; ++i)
-                        for (int l = 0; l < nd; ++l) acc = fma(Iblk[(i * nb + j) * ncd + k * nd + l], t_ad[i * nd + l], acc);
-                    unsafeAtomicAdd(&Gs[(size_t)(pb.offb + j) * n + pk.offa + k], fk * acc);
+                for (int cd = li; cd < ncd; cd += C) {
+                    double s = 0.0;
+                    for (int ab = 0; ab < nab; ++ab) s = fma(Iblk[ab * ncd + cd], tDj_ab[ab], s);
+                    const size_t o = (size_t)(pk.offa + cd / nd) * n + pk.offb + cd % nd;
+                    unsafeAtomicAdd(&G0[o], fj * s);
+                    if (uhf) unsafeAtomicAdd(&G1[o], fj * s);
                 }
-                for (int x = lane; x < nb * nd; x += 64) {          // (j,l) <- sum_{i,k} I[ij,kl] D[i,k]
-                    const int j = x / nd, l = x - j * nd;
-                    double acc = 0.0;
-                    for (int i = 0; i < na; ++i)
-                        for (int k = 0; k < nc; ++k) acc = fma(Iblk[(i * nb + j) * ncd + k * nd + l], t_ac[i * nc + k], acc);
-                    unsafeAtomicAdd(&Gs[(size_t)(pb.offb + j) * n + pk.offb + l], fk * acc);
+                // K blocks: Gt_ac -= cK f sum_bd I D_bd, and the ad / bc / bd images
+                const double fk = -a.cK * f;
+                for (int s = 0; s < (uhf ? 2 : 1); ++s) {
+                    double *Gs = s ? G1 : G0;
+                    const double *t_ac = tK + s * ktile, *t_ad = t_ac + na * nc, *t_bc = t_ad + na * nd, *t_bd = t_bc + nb * nc;
+                    for (int x = li; x < na * nc; x += C) {          // (i,k) <- sum_{j,l} I[ij,kl] D[j,l]
+                        const int i = x / nc, k = x - i * nc;
+                        double acc = 0.0;
+                        for (int j = 0; j < nb; ++j)
+                            for (int l = 0; l < nd; ++l) acc = fma(Iblk[(i * nb + j) * ncd + k * nd + l], t_bd[j * nd + l], acc);
+                        unsafeAtomicAdd(&Gs[(size_t)(pb.offa + i) * n + pk.offa + k], fk * acc);
+                    }
+                    for (int x = li; x < na * nd; x += C) {          // (i,l) <- sum_{j,k} I[ij,kl] D[j,k]
+                        const int i = x / nd, l = x - i * nd;
+                        double acc = 0.0;
+                        for (int j = 0; j < nb; ++j)
+                            for (int k = 0; k < nc; ++k) acc = fma(Iblk[(i * nb + j) * ncd + k * nd + l], t_bc[j * nc + k], acc);
+                        unsafeAtomicAdd(&Gs[(size_t)(pb.offa + i) * n + pk.offb + l], fk * acc);
+                    }
+                    for (int x = li; x < nb * nc; x += C) {          // (j,k) <- sum_{i,l} I[ij,kl] D[i,l]
+                        const int j = x / nc, k = x - j * nc;
+                        double acc = 0.0;
+                        for (int i = 0; i < na; ++i)
+                            for (int l = 0; l < nd; ++l) acc = fma(Iblk[(i * nb + j) * ncd + k * nd + l], t_ad[i * nd + l], acc);
+                        unsafeAtomicAdd(&Gs[(size_t)(pb.offb + j) * n + pk.offa + k], fk * acc);
+                    }
+                    for (int x = li; x < nb * nd; x += C) {          // (j,l) <- sum_{i,k} I[ij,kl] D[i,k]
+                        const int j = x / nd, l = x - j * nd;
+                        double acc = 0.0;
+                        for (int i = 0; i < na; ++i)
+                            for (int k = 0; k < nc; ++k) acc = fma(Iblk[(i * nb + j) * ncd + k * nd + l], t_ac[i * nc + k], acc);
+                        unsafeAtomicAdd(&Gs[(size_t)(pb.offb + j) * n + pk.offb + l], fk * acc);
+                    }
                 }
             }
         }
-        __syncthreads();   // Iblk / tiles are reused by the next task
+        __syncthreads();   // the slot regions are reused by the next batch of slots
     }
 }
 
-template <int LAB, int LCD>
+template <int LAB, int LCD, int LGC>
 int qc_launch_class(int grid, size_t lds, hipStream_t st, const QcKernelArgs &a) {
-    auto kern = qc_fock_class_kernel<LAB, LCD>;
+    auto kern = qc_fock_class_kernel<LAB, LCD, LGC>;
     if (lds > 48 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return QC_ERR_HIP;

@@ -12,6 +12,9 @@
 constexpr int QC_LMAX = 3;              // highest shell angular momentum with kernels (f)
 constexpr int QC_LPAIR = 2 * QC_LMAX;   // highest pair angular momentum
 constexpr int QC_LTOT = 4 * QC_LMAX;    // highest Hermite order of an ERI
+constexpr int QC_SLOT_ITMAX = 16;       // primitive quartets per slot
+constexpr int QC_NREP = 32;             // replicas of the Fock accumulation buffer
+constexpr int QC_NSTREAMS = 8;          // class kernels of one build run concurrently on this many streams
 
 __host__ __device__ constexpr int qc_nherm(int L) { return (L + 1) * (L + 2) * (L + 3) / 6; }
 __host__ __device__ constexpr int qc_ncart(int L) { return (L + 1) * (L + 2) / 2; }
@@ -40,12 +43,15 @@ struct QcPairDesc {
 };
 
 struct QcTask { int bra, ket; };  // pair indices; (bra|ket) is one unique shell quartet
+struct QcSlot { int bra, ket, lo, hi; };  // a quartet restricted to primitive quartets [lo, hi): the kernels' work unit
 
 struct QcClass {
-    int LAB, LCD;                 // Hermite orders of bra / ket pairs
-    std::vector<QcTask> tasks;    // all unique quartets of this class (full list)
+    int LAB, LCD, LGC;            // Hermite orders of bra / ket pairs; log2 of the lane-group width C
+    std::vector<QcTask> tasks;    // all unique quartets of this launch bucket (full list)
     std::vector<QcTask> shard;    // the ones this rank digests
-    QcTask *d_tasks = nullptr;    // device copy of `shard`
+    std::vector<QcSlot> slots;    // `shard` cut into primitive-quartet ranges of at most QC_SLOT_ITMAX, longest first
+    QcSlot *d_slots = nullptr;    // device copy of `slots`
+    int slot_words = 0;           // LDS doubles per lane group
     int lds_bytes = 0;
     // work model of `shard`
     int64_t prim_quartets = 0;
@@ -69,12 +75,15 @@ struct qc_system {
     int device = -1;
     hipStream_t stream = nullptr;
     bool own_stream = false;
+    hipStream_t side[QC_NSTREAMS] = {};
+    hipEvent_t ev_fork = nullptr, ev_join[QC_NSTREAMS] = {};
     double *d_pairdata = nullptr;
     QcPairDesc *d_pairs = nullptr;
     double *d_boys = nullptr;
     double *d_D = nullptr, *d_G = nullptr;   // 2 * n*n each (alpha/beta or Dj/Dk)
     double *d_Gtmp = nullptr;                // 2 * n*n accumulation target
     double *d_Dj = nullptr;
+    int *d_flag = nullptr;
     void *comm = nullptr;                    // ncclComm_t
     std::string last_error;
 };
@@ -102,7 +111,10 @@ struct QcFockArgs {
     double *G0, *G1;      // accumulation targets (pre-zeroed), unsymmetrised
     double cK;            // K prefactor (0.5 RHF, 1.0 UHF)
     double *eri_out;      // if non-null: store the integrals into the n^4 tensor instead of digesting
+    int nrep;             // accumulation replicas behind G0/G1
+    size_t rep_stride;    // doubles between replicas
 };
+int qc_launch_eri_full(qc_system *S, double *d_out);
 int qc_launch_fock_classes(qc_system *S, const QcFockArgs &a, float *class_ms /*nullable*/);
 int qc_fock_build_device(qc_system *S, const double *dDa, const double *dDb, double *dGa, double *dGb, bool uhf);
 
@@ -110,9 +122,14 @@ int qc_fock_build_device(qc_system *S, const double *dDa, const double *dDb, dou
 void qc_gemm(hipStream_t st, int m, int n, int k, double alpha, const double *A, int lda, bool ta, const double *B,
              int ldb, bool tb, double beta, double *C, int ldc);
 int qc_eig_device(hipStream_t st, int n, double *dA /*destroyed*/, double *dV, double *dw, double *d_work);
+int qc_eig_device_warm(hipStream_t st, int n, double *dA, const double *dV0, double *dV, double *dw, double *d_work, double *t1, double *t2);
 void qc_axpby(hipStream_t st, int n, double a, const double *x, double b, const double *y, double *out);
 void qc_sub_transpose(hipStream_t st, int n, const double *M, double *out);              // out = M - M^T
 void qc_symmetrize_add(hipStream_t st, int n, const double *Gt, double *G);              // G = Gt + Gt^T
+void qc_reduce_replicas(hipStream_t st, size_t count, int nrep, size_t stride, double *Gt);  // Gt[0] += sum_r>0 Gt[r]
+void qc_count_diff(hipStream_t st, size_t count, const double *a, const double *b, int *flag);
+int qc_lgc_for(int lcd, int ncd);
+void qc_make_slots(const qc_system *S, const std::vector<QcTask> &tasks, int itmax, std::vector<QcSlot> &out);
 void qc_dots(hipStream_t st, int n, const double *x, const double *const *ys, int ny, double *out);  // device ptr list
 void qc_lincomb(hipStream_t st, int n, const double *const *Fs, const double *c, int m, double *out);   // out = sum c_i Fs_i
 void qc_scale_cols_invsqrt(hipStream_t st, int n, const double *U, const double *Lam, double *out);

@@ -52,134 +52,147 @@ void qc_gemm(hipStream_t st, int m, int n, int k, double alpha, const double *A,
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// Symmetric eigensolver: parallel cyclic two-sided Jacobi, one workgroup, matrix resident in LDS.
-// Round-robin ("chess tournament") ordering gives m/2 disjoint rotations per step, m-1 steps per sweep.
-// Output: eigenvalues ascending in w, eigenvectors as the columns of V (sorted alongside).
+// Symmetric eigensolver: parallel cyclic two-sided Jacobi in ONE workgroup, matrix (and, when it fits, the
+// eigenvector matrix) resident in LDS.  Round-robin ("chess tournament") ordering gives m/2 disjoint rotations per
+// step and m-1 steps per sweep.  Each step is two phases separated by one barrier each:
+//   A. m/2 threads compute the rotations (c_k, s_k) of the step's pairs (p_k, q_k);
+//   B. the similarity transform J^T A J is applied as (m/2)^2 independent 2x2 blocks - block (k,l) = rows {p_k,q_k} x
+//      columns {p_l,q_l} gets J_k^T . B . J_l - and V <- V J as n x m/2 independent row pairs.
+// Output: eigenvalues ascending in w, eigenvectors as the columns of Vout (utils::sorted_eigs, hf/utils.rs:20-36).
 constexpr int QC_EIG_THREADS = 1024;
 
-__global__ __launch_bounds__(QC_EIG_THREADS) void qc_jacobi_kernel(int n, const double *__restrict__ Ain, double *__restrict__ V,
-                                                                   double *__restrict__ Vs, double *__restrict__ w, int max_sweeps) {
+__device__ __forceinline__ void qc_rr_pair(int step, int k, int m, int &p, int &q) {
+    if (k == 0) { p = m - 1; q = step; return; }
+    p = step + k; if (p >= m - 1) p -= m - 1;
+    q = step - k; if (q < 0) q += m - 1;
+}
+
+template <bool V_IN_LDS>
+__global__ __launch_bounds__(QC_EIG_THREADS) void qc_jacobi_kernel(int n, const double *__restrict__ Ain, double *__restrict__ Vg,
+                                                                   double *__restrict__ Vout, double *__restrict__ w, int max_sweeps) {
     extern __shared__ double sm[];
-    const int ld = n | 1;
-    const int m = (n + 1) & ~1, half = m / 2;
-    double *A = sm;                       // n x ld
-    double *cs = A + (size_t)n * ld;      // 2 * half
-    int *pq = (int *)(cs + 2 * half);     // 2 * half
-    double *red = (double *)(pq + 2 * half + (half & 1 ? 0 : 0));  // 32 partials (+2)
-    red = (double *)(((uintptr_t)red + 7) & ~(uintptr_t)7);
+    const int m = (n + 1) & ~1, half = m / 2, ld = m | 1;
+    double *A = sm;                                         // m x ld (padding row/column stay zero => identity rotations)
+    double *V = V_IN_LDS ? A + (size_t)m * ld : Vg;         // m x ldv
+    const int ldv = V_IN_LDS ? ld : n;
+    double *cs = A + (size_t)m * ld * (V_IN_LDS ? 2 : 1);   // 2 * half
+    double *red = cs + 2 * half;                            // 32
+    int *rank = (int *)(red + 32);                          // m
     const int tid = threadIdx.x, nt = blockDim.x;
 
-    for (int x = tid; x < n * n; x += nt) {
-        const int i = x / n, j = x - i * n;
-        A[i * ld + j] = Ain[x];
-        V[x] = (i == j) ? 1.0 : 0.0;
+    double fro = 0.0;
+    for (int x = tid; x < m * m; x += nt) {
+        const int i = x / m, j = x - i * m;
+        const double v = (i < n && j < n) ? Ain[(size_t)i * n + j] : 0.0;
+        A[i * ld + j] = v;
+        fro = fma(v, v, fro);
+        if (V_IN_LDS) V[i * ldv + j] = (i == j) ? 1.0 : 0.0;
+        else if (i < n && j < n) V[(size_t)i * ldv + j] = (i == j) ? 1.0 : 0.0;
     }
+    for (int o = 32; o > 0; o >>= 1) fro += __shfl_down(fro, o, 64);
+    if ((tid & 63) == 0) red[tid >> 6] = fro;
+    __syncthreads();
+    double normF2 = 0.0;
+    for (int k = 0; k < nt / 64; ++k) normF2 += red[k];
     __syncthreads();
 
     for (int sweep = 0; sweep < max_sweeps; ++sweep) {
-        // convergence: off-diagonal Frobenius mass relative to the whole matrix
-        double off = 0.0, tot = 0.0;
-        for (int x = tid; x < n * n; x += nt) {
-            const int i = x / n, j = x - i * n;
-            const double v = A[i * ld + j];
-            tot += v * v;
-            if (i != j) off += v * v;
-        }
-        for (int o = 32; o > 0; o >>= 1) { off += __shfl_down(off, o, 64); tot += __shfl_down(tot, o, 64); }
-        if ((tid & 63) == 0) { red[2 * (tid >> 6)] = off; red[2 * (tid >> 6) + 1] = tot; }
-        __syncthreads();
-        if (tid == 0) {
-            double so = 0.0, stt = 0.0;
-            for (int k = 0; k < nt / 64; ++k) { so += red[2 * k]; stt += red[2 * k + 1]; }
-            red[40] = so; red[41] = stt;
-        }
-        __syncthreads();
-        const double soff = red[40], stot = red[41];
-        __syncthreads();
-        if (soff <= 1e-30 * stot || soff == 0.0) break;
-
+        double seen = 0.0;                                  // sum of a_pq^2 at the moment each pair is rotated
         for (int step = 0; step < m - 1; ++step) {
-            // phase 1: the rotations of this step
-            if (tid < half) {
+            if (tid < half) {                               // phase A
                 int p, q;
-                if (tid == 0) { p = m - 1; q = step; }
-                else { p = (step + tid) % (m - 1); q = (step - tid + (m - 1)) % (m - 1); }
-                if (p > q) { const int t = p; p = q; q = t; }
+                qc_rr_pair(step, tid, m, p, q);
+                const double apq = A[p * ld + q];
                 double c = 1.0, s = 0.0;
-                if (q < n) {
-                    const double apq = A[p * ld + q];
-                    if (apq != 0.0) {
-                        const double theta = (A[q * ld + q] - A[p * ld + p]) / (2.0 * apq);
-                        const double t = (theta >= 0.0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
-                        c = 1.0 / sqrt(t * t + 1.0);
-                        s = t * c;
-                    }
-                } else {
-                    p = -1;   // padding pair
+                if (apq != 0.0) {
+                    const double theta = (A[q * ld + q] - A[p * ld + p]) / (2.0 * apq);
+                    const double t = (theta >= 0.0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(fma(theta, theta, 1.0)));
+                    c = 1.0 / sqrt(fma(t, t, 1.0));
+                    s = t * c;
+                    seen = fma(apq, apq, seen);
                 }
-                pq[2 * tid] = p; pq[2 * tid + 1] = q;
                 cs[2 * tid] = c; cs[2 * tid + 1] = s;
             }
             __syncthreads();
-            // phase 2: columns  A <- A J,  V <- V J
-            for (int x = tid; x < n * half; x += nt) {
-                const int i = x / half, k = x - i * half;
-                const int p = pq[2 * k], q = pq[2 * k + 1];
-                if (p < 0) continue;
-                const double c = cs[2 * k], s = cs[2 * k + 1];
-                if (s == 0.0) continue;
-                const double aip = A[i * ld + p], aiq = A[i * ld + q];
-                A[i * ld + p] = c * aip - s * aiq;
-                A[i * ld + q] = s * aip + c * aiq;
-                const double vip = V[i * n + p], viq = V[i * n + q];
-                V[i * n + p] = c * vip - s * viq;
-                V[i * n + q] = s * vip + c * viq;
+            for (int b = tid; b < half * half; b += nt) {   // phase B: 2x2 blocks of J^T A J
+                const int k = b / half, l = b - k * half;
+                const double ck = cs[2 * k], sk = cs[2 * k + 1], cl = cs[2 * l], sl = cs[2 * l + 1];
+                if (sk == 0.0 && sl == 0.0) continue;
+                int pk, qk, pl, ql;
+                qc_rr_pair(step, k, m, pk, qk);
+                qc_rr_pair(step, l, m, pl, ql);
+                const double b00 = A[pk * ld + pl], b01 = A[pk * ld + ql], b10 = A[qk * ld + pl], b11 = A[qk * ld + ql];
+                const double r00 = ck * b00 - sk * b10, r01 = ck * b01 - sk * b11;      // J_k^T B
+                const double r10 = sk * b00 + ck * b10, r11 = sk * b01 + ck * b11;
+                A[pk * ld + pl] = cl * r00 - sl * r01; A[pk * ld + ql] = sl * r00 + cl * r01;   // (.) J_l
+                A[qk * ld + pl] = cl * r10 - sl * r11; A[qk * ld + ql] = sl * r10 + cl * r11;
             }
-            __syncthreads();
-            // phase 3: rows  A <- J^T A
-            for (int x = tid; x < half * n; x += nt) {
-                const int k = x / n, j = x - k * n;
-                const int p = pq[2 * k], q = pq[2 * k + 1];
-                if (p < 0) continue;
-                const double c = cs[2 * k], s = cs[2 * k + 1];
-                if (s == 0.0) continue;
-                const double apj = A[p * ld + j], aqj = A[q * ld + j];
-                A[p * ld + j] = c * apj - s * aqj;
-                A[q * ld + j] = s * apj + c * aqj;
+            for (int x = tid; x < n * half; x += nt) {      // V <- V J
+                const int i = x / half, l = x - i * half;
+                const double cl = cs[2 * l], sl = cs[2 * l + 1];
+                if (sl == 0.0) continue;
+                int pl, ql;
+                qc_rr_pair(step, l, m, pl, ql);
+                const double vp = V[(size_t)i * ldv + pl], vq = V[(size_t)i * ldv + ql];
+                V[(size_t)i * ldv + pl] = cl * vp - sl * vq;
+                V[(size_t)i * ldv + ql] = sl * vp + cl * vq;
             }
             __syncthreads();
         }
+        // off-diagonal mass met during this sweep; the sweep itself reduced it (quadratically, once small)
+        for (int o = 32; o > 0; o >>= 1) seen += __shfl_down(seen, o, 64);
+        if ((tid & 63) == 0) red[tid >> 6] = seen;
+        __syncthreads();
+        double off2 = 0.0;
+        for (int k = 0; k < nt / 64; ++k) off2 += red[k];
+        __syncthreads();
+        if (2.0 * off2 <= 1e-26 * normF2) break;
     }
     // ascending order (utils.rs:28): rank sort, then permute columns
-    __syncthreads();
     for (int i = tid; i < n; i += nt) {
         const double wi = A[i * ld + i];
-        int rank = 0;
+        int r = 0;
         for (int j = 0; j < n; ++j) {
             const double wj = A[j * ld + j];
-            rank += (wj < wi || (wj == wi && j < i)) ? 1 : 0;
+            r += (wj < wi || (wj == wi && j < i)) ? 1 : 0;
         }
-        pq[i] = rank;     // pq has 2*half >= n entries
-        w[rank] = wi;
+        rank[i] = r;
+        w[r] = wi;
     }
     __syncthreads();
     for (int x = tid; x < n * n; x += nt) {
         const int i = x / n, j = x - i * n;
-        Vs[i * n + pq[j]] = V[x];
+        Vout[(size_t)i * n + rank[j]] = V[(size_t)i * ldv + j];
     }
 }
 
 // dA: input (left intact), dV: sorted eigenvectors, dw: eigenvalues, d_work: n*n scratch
 int qc_eig_device(hipStream_t st, int n, double *dA, double *dV, double *dw, double *d_work) {
-    const int ld = n | 1, m = (n + 1) & ~1;
-    const size_t lds = ((size_t)n * ld + 2 * (m / 2)) * sizeof(double) + 2 * (m / 2) * sizeof(int) + 64 * sizeof(double);
-    if (lds > 160 * 1024) return QC_ERR_UNSUPPORTED;   // n <= 141; larger n needs the multi-workgroup solver (next round)
+    const int m = (n + 1) & ~1, ld = m | 1;
+    const size_t tail = (2 * (m / 2) + 32) * sizeof(double) + (size_t)m * sizeof(int) + 16;
+    const size_t lds2 = 2 * (size_t)m * ld * sizeof(double) + tail, lds1 = (size_t)m * ld * sizeof(double) + tail;
+    const bool v_in_lds = lds2 <= 160 * 1024;
+    const size_t lds = v_in_lds ? lds2 : lds1;
+    if (lds > 160 * 1024) return QC_ERR_UNSUPPORTED;   // n <= 140; larger n needs the multi-workgroup solver (next round)
+    auto kern = v_in_lds ? qc_jacobi_kernel<true> : qc_jacobi_kernel<false>;
     if (lds > 48 * 1024) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(qc_jacobi_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return QC_ERR_HIP;
     }
-    hipLaunchKernelGGL(qc_jacobi_kernel, dim3(1), dim3(QC_EIG_THREADS), lds, st, n, dA, d_work, dV, dw, 60);
+    hipLaunchKernelGGL(kern, dim3(1), dim3(QC_EIG_THREADS), lds, st, n, dA, d_work, dV, dw, 40);
     return hipGetLastError() == hipSuccess ? QC_OK : QC_ERR_HIP;
+}
+
+// Warm-started variant for the SCF loop: with V0 the eigenvectors of the previous iteration's matrix,
+// B = V0^T A V0 is nearly diagonal, Jacobi needs 1-3 sweeps instead of ~8, and V = V0 Q.  The three products are
+// f64 MFMA GEMMs.  t1/t2: n*n scratch each.
+int qc_eig_device_warm(hipStream_t st, int n, double *dA, const double *dV0, double *dV, double *dw, double *d_work, double *t1, double *t2) {
+    qc_gemm(st, n, n, n, 1.0, dA, n, false, dV0, n, false, 0.0, t1, n);        // A V0
+    qc_gemm(st, n, n, n, 1.0, dV0, n, true, t1, n, false, 0.0, t2, n);         // V0^T (A V0)
+    int rc = qc_eig_device(st, n, t2, t1, dw, d_work);                         // Q -> t1
+    if (rc != QC_OK) return rc;
+    qc_gemm(st, n, n, n, 1.0, dV0, n, false, t1, n, false, 0.0, dV, n);        // V = V0 Q
+    return QC_OK;
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -210,6 +223,30 @@ __global__ void qc_symmetrize_add_kernel(int n, const double *Gt, double *G) {
 }
 void qc_symmetrize_add(hipStream_t st, int n, const double *Gt, double *G) {
     hipLaunchKernelGGL(qc_symmetrize_add_kernel, dim3((n * n + 255) / 256), dim3(256), 0, st, n, Gt, G);
+}
+
+// flag[0] = number of positions where a and b differ bitwise (spin-symmetry test of the UHF build)
+__global__ void qc_count_diff_kernel(size_t count, const double *a, const double *b, int *flag) {
+    int d = 0;
+    for (size_t x = blockIdx.x * (size_t)blockDim.x + threadIdx.x; x < count; x += (size_t)gridDim.x * blockDim.x)
+        d += (__double_as_longlong(a[x]) != __double_as_longlong(b[x])) ? 1 : 0;
+    if (d) atomicAdd(flag, d);
+}
+void qc_count_diff(hipStream_t st, size_t count, const double *a, const double *b, int *flag) {
+    hipLaunchKernelGGL(qc_count_diff_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, st, count, a, b, flag);
+}
+
+// Gt[0][x] += sum_{r>0} Gt[r][x]: folds the accumulation replicas of the Fock build
+__global__ void qc_reduce_replicas_kernel(size_t count, int nrep, size_t stride, double *Gt) {
+    for (size_t x = blockIdx.x * (size_t)blockDim.x + threadIdx.x; x < count; x += (size_t)gridDim.x * blockDim.x) {
+        double s = Gt[x];
+        for (int r = 1; r < nrep; ++r) s += Gt[r * stride + x];
+        Gt[x] = s;
+    }
+}
+void qc_reduce_replicas(hipStream_t st, size_t count, int nrep, size_t stride, double *Gt) {
+    if (nrep <= 1) return;
+    hipLaunchKernelGGL(qc_reduce_replicas_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, st, count, nrep, stride, Gt);
 }
 
 __device__ __forceinline__ double block_sum_256(double v, double *sh) {

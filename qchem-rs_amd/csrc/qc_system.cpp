@@ -206,42 +206,71 @@ void qc_build_model(qc_system *S) {
                 }
             S->pairs.push_back(d); S->pairA.push_back(a); S->pairB.push_back(b);
         }
-    // unique quartets (pair P >= pair Q), oriented so the wider pair is the ket (column side), bucketed by class
+    // unique quartets (pair P >= pair Q), oriented so the wider pair is the ket (column side), bucketed by
+    // launch class (LAB, LCD, lane-group width)
     const int np = (int)S->pairs.size();
     S->nquartets = (int64_t)np * (np + 1) / 2;
-    std::vector<std::vector<QcTask>> bucket((QC_LPAIR + 1) * (QC_LPAIR + 1));
+    const int NB = (QC_LPAIR + 1) * (QC_LPAIR + 1) * 7;
+    std::vector<std::vector<QcTask>> bucket(NB);
     for (int P = 0; P < np; ++P)
         for (int Q = 0; Q <= P; ++Q) {
             const QcPairDesc &dp = S->pairs[P], &dq = S->pairs[Q];
             const int np_ = dp.na * dp.nb, nq_ = dq.na * dq.nb;
             const bool p_is_ket = (np_ > nq_) || (np_ == nq_ && dp.L >= dq.L);
             QcTask t = p_is_ket ? QcTask{Q, P} : QcTask{P, Q};
-            bucket[S->pairs[t.bra].L * (QC_LPAIR + 1) + S->pairs[t.ket].L].push_back(t);
+            const QcPairDesc &k = S->pairs[t.ket];
+            bucket[(S->pairs[t.bra].L * (QC_LPAIR + 1) + k.L) * 7 + qc_lgc_for(k.L, k.na * k.nb)].push_back(t);
         }
     S->classes.clear();
-    for (int lab = 0; lab <= QC_LPAIR; ++lab)
-        for (int lcd = 0; lcd <= QC_LPAIR; ++lcd) {
-            auto &v = bucket[lab * (QC_LPAIR + 1) + lcd];
-            if (v.empty()) continue;
-            // heaviest first: primitive-quartet count is the dominant cost inside a class
-            std::stable_sort(v.begin(), v.end(), [&](const QcTask &x, const QcTask &y) {
-                return (int64_t)S->pairs[x.bra].K * S->pairs[x.ket].K > (int64_t)S->pairs[y.bra].K * S->pairs[y.ket].K;
-            });
-            QcClass c; c.LAB = lab; c.LCD = lcd; c.tasks = std::move(v);
-            S->classes.push_back(std::move(c));
-        }
+    for (int b = 0; b < NB; ++b) {
+        auto &v = bucket[b];
+        if (v.empty()) continue;
+        QcClass c;
+        c.LGC = b % 7; c.LCD = (b / 7) % (QC_LPAIR + 1); c.LAB = b / 7 / (QC_LPAIR + 1);
+        c.tasks = std::move(v);
+        S->classes.push_back(std::move(c));
+    }
     qc_build_shards(S);
 }
 
-// Static shard: inside every class the cost-sorted task list is dealt round-robin to the ranks, so each rank holds
-// the same mix of classes and (to within one task per class) the same modelled cost.  Data-only; no communication.
+// Lane-group widths the kernels are instantiated for, per ket Hermite order (gen_step2.py emits the same table).
+int qc_lgc_for(int lcd, int ncd) {
+    static const int allowed[QC_LPAIR + 1][4] = {{0, -1, -1, -1}, {2, -1, -1, -1}, {3, 4, -1, -1}, {3, 4, 5, -1}, {5, 6, -1, -1}, {6, -1, -1, -1}, {6, -1, -1, -1}};
+    for (int i = 0; i < 4 && allowed[lcd][i] >= 0; ++i)
+        if ((1 << allowed[lcd][i]) >= ncd) return allowed[lcd][i];
+    return 6;   // wider than a wave: the kernel makes several column passes
+}
+
+// Cut quartets into slots of at most `itmax` primitive quartets; longest first so the slots batched into one wave
+// have (nearly) equal trip counts.
+void qc_make_slots(const qc_system *S, const std::vector<QcTask> &tasks, int itmax, std::vector<QcSlot> &out) {
+    out.clear();
+    for (const auto &t : tasks) {
+        const int npq = S->pairs[t.bra].K * S->pairs[t.ket].K;
+        const int step = itmax > 0 ? itmax : npq;
+        const int nparts = (npq + step - 1) / step;
+        for (int s = 0; s < nparts; ++s) {   // equal-length parts
+            const int lo = (int)((int64_t)npq * s / nparts), hi = (int)((int64_t)npq * (s + 1) / nparts);
+            out.push_back(QcSlot{t.bra, t.ket, lo, hi});
+        }
+    }
+    std::stable_sort(out.begin(), out.end(), [](const QcSlot &x, const QcSlot &y) { return x.hi - x.lo > y.hi - y.lo; });
+}
+
+// Static shard: inside every launch class the quartet list is dealt round-robin to the ranks, so each rank holds the
+// same mix of classes and (to within one quartet per class) the same modelled cost.  Data-only; no communication.
 void qc_build_shards(qc_system *S) {
     for (auto &c : S->classes) {
+        // heaviest first: the primitive-quartet count is the dominant cost inside a class
+        std::stable_sort(c.tasks.begin(), c.tasks.end(), [&](const QcTask &x, const QcTask &y) {
+            return (int64_t)S->pairs[x.bra].K * S->pairs[x.ket].K > (int64_t)S->pairs[y.bra].K * S->pairs[y.ket].K;
+        });
         c.shard.clear();
         for (size_t i = 0; i < c.tasks.size(); ++i)
             if ((int)(i % S->nranks) == S->rank) c.shard.push_back(c.tasks[i]);
+        qc_make_slots(S, c.shard, QC_SLOT_ITMAX, c.slots);
         c.prim_quartets = 0; c.bytes_alg = 0; c.flops_alg = 0;
-        int lds = 0;
+        int words = 0;
         for (const auto &t : c.shard) {
             const QcPairDesc &b = S->pairs[t.bra], &k = S->pairs[t.ket];
             const QcShell &A = S->shells[S->pairA[t.bra]], &B = S->shells[S->pairB[t.bra]];
@@ -255,14 +284,13 @@ void qc_build_shards(qc_system *S) {
             c.bytes_alg += 8.0 * (5.0 * (Kab + Kcd) + 3.0 * (na * nb + nc * nd + na * nc + na * nd + nb * nc + nb * nd));
             c.flops_alg += Kab * Kcd * (40.0 * (L + 1) + 3.0 * qc_rwork((int)L) + 2.0 * hab * hcd) + 2.0 * ca * cb * hab * hcd +
                            2.0 * ca * cb * cc * cd * hcd + 12.0 * na * nb * nc * nd;
-            // LDS need of the kernel for this task (see qc_fock.hip: layout_lds)
+            // LDS doubles one lane group needs for this quartet (layout in qc_fock_kernel.h)
             const int ncd = k.na * k.nb, nab = b.na * b.nb;
-            int C2 = 1; while (C2 < ncd && C2 < 64) C2 <<= 1;
-            const int G = 64 / C2;
-            const int words = G * qc_rwork(b.L + k.L) + nab * ncd + 2 * (nab + ncd) + 2 * (b.na * k.na + b.na * k.nb + b.nb * k.na + b.nb * k.nb);
-            lds = std::max(lds, words * 8);
+            const int w = qc_rwork(b.L + k.L) + nab * ncd + nab + ncd + 2 * (b.na * k.na + b.na * k.nb + b.nb * k.na + b.nb * k.nb);
+            words = std::max(words, w);
         }
-        c.lds_bytes = lds;
+        c.slot_words = words;
+        c.lds_bytes = words * 8 * (64 >> c.LGC);
     }
 }
 
