@@ -75,6 +75,9 @@ def roofline(torch, sysh, D_host, reps):
     gbs = float(prof["bytes"][k]) / (ms * 1e-3) / 1e9
     tfs = float(prof["flops"][k]) / (ms * 1e-3) / 1e12
     ws = sysh.work_stats()
+    order = prof["class_ms"].argsort()[::-1][:10]
+    top = [{"class": "<%d,%d>" % (int(prof["class_id"][i]) >> 4, int(prof["class_id"][i]) & 15), "ms": float(prof["class_ms"][i]),
+            "quartets": int(prof["quartets"][i]), "GF": float(prof["flops"][i]) / 1e9} for i in order]
     tot_ms = float(prof["total_ms"])
     sum_ms = float(prof["class_ms"].sum())
     return {
@@ -88,7 +91,7 @@ def roofline(torch, sysh, D_host, reps):
                        "alg_bytes": float(ws.bytes_alg), "alg_flops": float(ws.flops_alg),
                        "achieved_GBs": float(ws.bytes_alg) / (tot_ms * 1e-3) / 1e9,
                        "achieved_TFLOPs": float(ws.flops_alg) / (tot_ms * 1e-3) / 1e12,
-                       "quartets_per_s": float(ws.quartets) / (tot_ms * 1e-3)},
+                       "quartets_per_s": float(ws.quartets) / (tot_ms * 1e-3), "top_classes_serial": top},
     }
 
 

@@ -41,6 +41,10 @@ struct QcKernelArgs {
 template <int LAB, int LCD>
 __device__ __forceinline__ void qc_step2(double (&W)[qc_nherm(LAB)], const double (&e)[qc_nherm(LCD)], const double *__restrict__ R);
 
+constexpr int QC_LREG = 6;   // total Hermite orders up to this keep the R table in registers (no LDS, no barriers)
+template <int L>
+__device__ __forceinline__ void qc_rtab(double alpha, double X, double Y, double Z, const double (&F)[L + 1], double (&R)[qc_nherm(L)]);
+
 // (t,u,v) of every Hermite index up to order QC_LTOT
 struct QcTuvTable { unsigned char t[qc_nherm(QC_LTOT)], u[qc_nherm(QC_LTOT)], v[qc_nherm(QC_LTOT)]; };
 __host__ __device__ constexpr QcTuvTable qc_make_tuv() {
@@ -96,6 +100,8 @@ __host__ __device__ constexpr int qc_roff(int n) {
 
 // Cooperative Hermite-Coulomb table R^0_{tuv}, t+u+v <= L, by the `C` lanes of a group (lane-in-group `li`), in LDS.
 // On return Rw[0 .. nherm(L)) holds R^0.  Every lane of the workgroup must call this (it contains barriers).
+// Entry (n; t,u,v) of stage N = t+u+v is decoded from its flat index arithmetically (no table lookups):
+// position r inside order N: s = u+v = floor((sqrt(8r+1)-1)/2), v = r - s(s+1)/2; level offset = rwork(L) - rwork(L-n).
 template <int L>
 __device__ __forceinline__ void qc_build_r(double *__restrict__ Rw, int li, int C, double alpha, double X, double Y, double Z,
                                            const double (&F)[L + 1]) {
@@ -104,35 +110,30 @@ __device__ __forceinline__ void qc_build_r(double *__restrict__ Rw, int li, int 
 #pragma unroll
         for (int n = 0; n <= L; ++n) { Rw[qc_roff<L>(n)] = f * F[n]; f *= -2.0 * alpha; }
     }
-    if constexpr (L > 0) {
-        __syncthreads();
+    __syncthreads();
 #pragma unroll
-        for (int N = 1; N <= L; ++N) {
-            const int cnt = (N + 1) * (N + 2) / 2, total = (L - N + 1) * cnt, base = qc_nherm(N - 1);
-            for (int e = li; e < total; e += C) {
-                const int n = e / cnt, idx = base + (e - n * cnt);
-                const int t = qc_tuv.t[idx], u = qc_tuv.u[idx], v = qc_tuv.v[idx];
-                // level offsets: qc_roff<L>(n) for runtime n
-                int o1 = 0;
-                for (int m = 0; m <= n; ++m) o1 += qc_nherm(L - m);     // offset of level n+1
-                const int o0 = o1 - qc_nherm(L - n);
-                const double *up = Rw + o1;
-                double val;
-                if (t > 0) {
-                    val = X * up[qc_hidx(t - 1, u, v)];
-                    if (t > 1) val = fma((double)(t - 1), up[qc_hidx(t - 2, u, v)], val);
-                } else if (u > 0) {
-                    val = Y * up[qc_hidx(t, u - 1, v)];
-                    if (u > 1) val = fma((double)(u - 1), up[qc_hidx(t, u - 2, v)], val);
-                } else {
-                    val = Z * up[qc_hidx(t, u, v - 1)];
-                    if (v > 1) val = fma((double)(v - 1), up[qc_hidx(t, u, v - 2)], val);
-                }
-                Rw[o0 + idx] = val;
+    for (int N = 1; N <= L; ++N) {
+        constexpr int RWL = qc_rwork(L);
+        const int cnt = (N + 1) * (N + 2) / 2, total = (L - N + 1) * cnt, base = qc_nherm(N - 1);
+        for (int e = li; e < total; e += C) {
+            const int n = e / cnt, r = e - n * cnt;
+            const int s = (int)((sqrtf(8.0f * r + 1.0f) - 1.0f) * 0.5f + 1e-3f);
+            const int v = r - s * (s + 1) / 2, u = s - v, t = N - s;
+            const int o0 = RWL - qc_rwork(L - n), o1 = RWL - qc_rwork(L - n - 1);   // offsets of levels n, n+1
+            const double *up = Rw + o1;
+            double val;
+            if (t > 0) {
+                val = X * up[qc_hidx(t - 1, u, v)];
+                if (t > 1) val = fma((double)(t - 1), up[qc_hidx(t - 2, u, v)], val);
+            } else if (u > 0) {
+                val = Y * up[qc_hidx(t, u - 1, v)];
+                if (u > 1) val = fma((double)(u - 1), up[qc_hidx(t, u - 2, v)], val);
+            } else {
+                val = Z * up[qc_hidx(t, u, v - 1)];
+                if (v > 1) val = fma((double)(v - 1), up[qc_hidx(t, u, v - 2)], val);
             }
-            __syncthreads();
+            Rw[o0 + base + r] = val;
         }
-    } else {
         __syncthreads();
     }
 }
@@ -160,6 +161,7 @@ __global__ __launch_bounds__(64) void qc_fock_class_kernel(const QcKernelArgs a)
         double *tDj_ab = Iblk + nab * ncd, *tDj_cd = tDj_ab + nab;
         double *tK = tDj_cd + ncd;   // per spin: Dk_ac, Dk_ad, Dk_bc, Dk_bd
         const int ktile = na * nc + na * nd + nb * nc + nb * nd;
+        double *Es = tK + 2 * ktile; // staged bra expansion block [ab][h]
 
         if (active) {
             for (int i = li; i < nab * ncd; i += C) Iblk[i] = 0.0;
@@ -193,11 +195,24 @@ __global__ __launch_bounds__(64) void qc_fock_class_kernel(const QcKernelArgs a)
             int cur_ij = -1;
 
             auto flush = [&](int ij) {   // step 3: I[ab][col] += sum_h E_ab,ij[h][ab] W[h]
+                // The bra expansion block is staged transposed ([ab][h]) in the group's LDS region by coalesced loads,
+                // then read back as broadcasts.  Writer and reader lanes are the same lanes of one wave (this code runs
+                // under a group-uniform, possibly wave-divergent condition), DS operations of a wave execute in order,
+                // so wavefront-scope fences (compiler ordering only) are sufficient - no s_barrier here.
                 const double *Eab = braBase + (size_t)ij * strideB + 4;
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");   // earlier readers of Es are done (program order)
+                for (int x = li; x < HAB * nab; x += C) {
+                    const int h = x / nab, ab = x - h * nab;
+                    Es[ab * HAB + h] = Eab[x];
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
                 for (int ab = 0; ab < nab; ++ab) {
+                    const double *row = Es + ab * HAB;
                     double acc = 0.0;
 #pragma unroll
-                    for (int h = 0; h < HAB; ++h) acc = fma(Eab[h * nab + ab], W[h], acc);
+                    for (int h = 0; h < HAB; ++h) acc = fma(row[h], W[h], acc);
                     if (colok) Iblk[ab * ncd + col] += acc;      // column `col` of this slot belongs to this lane alone
                 }
             };
@@ -219,14 +234,20 @@ __global__ __launch_bounds__(64) void qc_fock_class_kernel(const QcKernelArgs a)
                 const double pref = 1.0 / sqrt(pq_sum);
                 double F[L + 1];
                 qc_boys<L>(alpha * (X * X + Y * Y + Z * Z), a.boys, F);
-                __syncthreads();                      // previous iteration's readers of Rw are done
-                qc_build_r<L>(Rw, li, C, alpha, X, Y, Z, F);
                 double e[HCD];
                 const double sc = (valid && colok) ? pref : 0.0;
                 const double *Ecd = ket + 4 + (colok ? col : 0);
 #pragma unroll
                 for (int h = 0; h < HCD; ++h) e[h] = Ecd[h * ncd] * sc;
-                qc_step2<LAB, LCD>(W, e, Rw);
+                if constexpr (L <= QC_LREG) {         // small tables: every lane keeps its own copy in registers
+                    double Rr[qc_nherm(L)];
+                    qc_rtab<L>(alpha, X, Y, Z, F, Rr);
+                    qc_step2<LAB, LCD>(W, e, Rr);
+                } else {
+                    __syncthreads();                  // previous iteration's readers of Rw are done
+                    qc_build_r<L>(Rw, li, C, alpha, X, Y, Z, F);
+                    qc_step2<LAB, LCD>(W, e, Rw);
+                }
             }
             if (cur_ij >= 0) flush(cur_ij);
         }

@@ -12,9 +12,9 @@
 constexpr int QC_LMAX = 3;              // highest shell angular momentum with kernels (f)
 constexpr int QC_LPAIR = 2 * QC_LMAX;   // highest pair angular momentum
 constexpr int QC_LTOT = 4 * QC_LMAX;    // highest Hermite order of an ERI
-constexpr int QC_SLOT_ITMAX = 16;       // primitive quartets per slot
+constexpr int QC_SLOT_ITMAX = 32;       // primitive quartets per slot
 constexpr int QC_NREP = 32;             // replicas of the Fock accumulation buffer
-constexpr int QC_NSTREAMS = 8;          // class kernels of one build run concurrently on this many streams
+constexpr int QC_NSTREAMS = 16;         // class kernels of one build run concurrently on this many streams
 
 __host__ __device__ constexpr int qc_nherm(int L) { return (L + 1) * (L + 2) * (L + 3) / 6; }
 __host__ __device__ constexpr int qc_ncart(int L) { return (L + 1) * (L + 2) / 2; }

@@ -268,7 +268,12 @@ void qc_build_shards(qc_system *S) {
         c.shard.clear();
         for (size_t i = 0; i < c.tasks.size(); ++i)
             if ((int)(i % S->nranks) == S->rank) c.shard.push_back(c.tasks[i]);
-        qc_make_slots(S, c.shard, QC_SLOT_ITMAX, c.slots);
+        // slot length: long enough to amortise the per-slot digestion, short enough that the class still fills the chip
+        int64_t tot_pq = 0;
+        for (const auto &t : c.shard) tot_pq += (int64_t)S->pairs[t.bra].K * S->pairs[t.ket].K;
+        const int64_t want_waves = 256 * 8, G = 64 >> c.LGC;
+        int itmax = (int)std::min<int64_t>(QC_SLOT_ITMAX, std::max<int64_t>(2, tot_pq / (want_waves * G)));
+        qc_make_slots(S, c.shard, itmax, c.slots);
         c.prim_quartets = 0; c.bytes_alg = 0; c.flops_alg = 0;
         int words = 0;
         for (const auto &t : c.shard) {
@@ -286,7 +291,8 @@ void qc_build_shards(qc_system *S) {
                            2.0 * ca * cb * cc * cd * hcd + 12.0 * na * nb * nc * nd;
             // LDS doubles one lane group needs for this quartet (layout in qc_fock_kernel.h)
             const int ncd = k.na * k.nb, nab = b.na * b.nb;
-            const int w = qc_rwork(b.L + k.L) + nab * ncd + nab + ncd + 2 * (b.na * k.na + b.na * k.nb + b.nb * k.na + b.nb * k.nb);
+            const int w = qc_rwork(b.L + k.L) + nab * ncd + nab + ncd + 2 * (b.na * k.na + b.na * k.nb + b.nb * k.na + b.nb * k.nb) +
+                          nab * qc_nherm(b.L);
             words = std::max(words, w);
         }
         c.slot_words = words;
