@@ -68,8 +68,12 @@ int qc_device_init(qc_system *S) {
     QC_HIP_CHECK(hipMemcpy(S->d_pairdata, S->pairdata.data(), S->pairdata.size() * sizeof(double), hipMemcpyHostToDevice));
     QC_HIP_CHECK(hipMalloc(&S->d_pairs, S->pairs.size() * sizeof(QcPairDesc)));
     QC_HIP_CHECK(hipMemcpy(S->d_pairs, S->pairs.data(), S->pairs.size() * sizeof(QcPairDesc), hipMemcpyHostToDevice));
-    std::vector<double> tab((size_t)QC_BOYS_NGRID * QC_BOYS_NORD);
-    for (int k = 0; k < QC_BOYS_NGRID; ++k) qc_boys_host(QC_BOYS_NORD - 1, k * QC_BOYS_DX, &tab[(size_t)k * QC_BOYS_NORD]);
+    std::vector<double> tab((size_t)(QC_LTOT + 1) * QC_BOYS_NGRID * 8), row(QC_BOYS_NORD);
+    for (int k = 0; k < QC_BOYS_NGRID; ++k) {
+        qc_boys_host(QC_BOYS_NORD - 1, k * QC_BOYS_DX, row.data());
+        for (int L = 0; L <= QC_LTOT; ++L)
+            for (int j = 0; j < 8; ++j) tab[((size_t)L * QC_BOYS_NGRID + k) * 8 + j] = row[L + j];
+    }
     QC_HIP_CHECK(hipMalloc(&S->d_boys, tab.size() * sizeof(double)));
     QC_HIP_CHECK(hipMemcpy(S->d_boys, tab.data(), tab.size() * sizeof(double), hipMemcpyHostToDevice));
     QC_HIP_CHECK(hipMalloc(&S->d_D, 2 * nn * sizeof(double)));

@@ -64,15 +64,16 @@ __device__ __forceinline__ void qc_boys(double x, const double *__restrict__ tab
     if (x < QC_BOYS_XMAX) {
         const int k = (int)(x * (1.0 / QC_BOYS_DX) + 0.5);
         const double d = k * QC_BOYS_DX - x;
-        const double *row = tab + k * QC_BOYS_NORD + L;
-        double f = row[7] * (1.0 / 5040.0);
-        f = fma(f, d, row[6] * (1.0 / 720.0));
-        f = fma(f, d, row[5] * (1.0 / 120.0));
-        f = fma(f, d, row[4] * (1.0 / 24.0));
-        f = fma(f, d, row[3] * (1.0 / 6.0));
-        f = fma(f, d, row[2] * 0.5);
-        f = fma(f, d, row[1]);
-        f = fma(f, d, row[0]);
+        const double4 *row = reinterpret_cast<const double4 *>(tab + ((size_t)L * QC_BOYS_NGRID + k) * 8);   // 64-byte aligned row
+        const double4 lo = row[0], hi = row[1];
+        double f = hi.w * (1.0 / 5040.0);
+        f = fma(f, d, hi.z * (1.0 / 720.0));
+        f = fma(f, d, hi.y * (1.0 / 120.0));
+        f = fma(f, d, hi.x * (1.0 / 24.0));
+        f = fma(f, d, lo.w * (1.0 / 6.0));
+        f = fma(f, d, lo.z * 0.5);
+        f = fma(f, d, lo.y);
+        f = fma(f, d, lo.x);
         F[L] = f;
         if constexpr (L > 0) {
             const double ex = exp(-x), x2 = 2.0 * x;
@@ -178,7 +179,7 @@ __global__ __launch_bounds__(64) void qc_fock_class_kernel(const QcKernelArgs a)
                 }
             }
         }
-        const int strideB = 4 + HAB * nab, strideK = 4 + HCD * ncd;
+        const int strideB = qc_pair_stride(LAB, nab), strideK = qc_pair_stride(LCD, ncd);
         const int len = active ? sl.hi - sl.lo : 0;
         int maxlen = len;                                   // uniform trip count: the longest slot of this wave
 #pragma unroll
@@ -217,21 +218,35 @@ __global__ __launch_bounds__(64) void qc_fock_class_kernel(const QcKernelArgs a)
                 }
             };
 
+            // primitive-quartet loop of this slot: (ij, kl) advances incrementally; the 32-byte headers [p, P] of the next
+            // primitive pair are requested one iteration ahead
+            const int K_cd = pk.K;
+            int ij = sl.lo / K_cd, kl = sl.lo - ij * K_cd;
+            double4 hb = *reinterpret_cast<const double4 *>(braBase + (size_t)ij * strideB);
+            double4 hk = *reinterpret_cast<const double4 *>(ketBase + (size_t)kl * strideK);
             for (int it = 0; it < maxlen; ++it) {
                 const bool valid = it < len;
-                const int pq = valid ? sl.lo + it : sl.lo;
-                const int ij = pq / pk.K, kl = pq - ij * pk.K;
                 if (valid && ij != cur_ij) {
                     if (cur_ij >= 0) flush(cur_ij);
 #pragma unroll
                     for (int h = 0; h < HAB; ++h) W[h] = 0.0;
                     cur_ij = ij;
                 }
-                const double *bra = braBase + (size_t)ij * strideB, *ket = ketBase + (size_t)kl * strideK;
-                const double p = bra[0], q = ket[0];
-                const double X = bra[1] - ket[1], Y = bra[2] - ket[2], Z = bra[3] - ket[3];
-                const double pq_sum = p + q, alpha = p * q / pq_sum;
-                const double pref = 1.0 / sqrt(pq_sum);
+                const double4 cb = hb, ck = hk;
+                const double *ket = ketBase + (size_t)kl * strideK;
+                // advance to the next primitive quartet and prefetch its headers (stay in range on the last pass)
+                int nij = ij, nkl = kl + 1;
+                if (nkl == K_cd) { nkl = 0; ++nij; }
+                if (it + 1 < len) {
+                    ij = nij; kl = nkl;
+                    hb = *reinterpret_cast<const double4 *>(braBase + (size_t)ij * strideB);
+                    hk = *reinterpret_cast<const double4 *>(ketBase + (size_t)kl * strideK);
+                }
+                const double p = cb.x, q = ck.x;
+                const double X = cb.y - ck.y, Y = cb.z - ck.z, Z = cb.w - ck.w;
+                const double pq_sum = p + q;
+                const double pref = rsqrt(pq_sum);                 // 1 / sqrt(p + q)
+                const double alpha = p * q * (pref * pref);
                 double F[L + 1];
                 qc_boys<L>(alpha * (X * X + Y * Y + Z * Z), a.boys, F);
                 double e[HCD];

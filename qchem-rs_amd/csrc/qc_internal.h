@@ -12,7 +12,7 @@
 constexpr int QC_LMAX = 3;              // highest shell angular momentum with kernels (f)
 constexpr int QC_LPAIR = 2 * QC_LMAX;   // highest pair angular momentum
 constexpr int QC_LTOT = 4 * QC_LMAX;    // highest Hermite order of an ERI
-constexpr int QC_SLOT_ITMAX = 32;       // primitive quartets per slot
+constexpr int QC_SLOT_ITMAX = 128;      // primitive quartets per slot
 constexpr int QC_NREP = 32;             // replicas of the Fock accumulation buffer
 constexpr int QC_NSTREAMS = 16;         // class kernels of one build run concurrently on this many streams
 
@@ -23,6 +23,8 @@ __host__ __device__ constexpr int qc_hidx(int t, int u, int v) {
     return (t + u + v) * (t + u + v + 1) * (t + u + v + 2) / 6 + (u + v) * (u + v + 1) / 2 + v;
 }
 // size of the Hermite-Coulomb work array sum_{n=0..L} nherm(L-n) = C(L+4,4)
+// doubles per primitive-pair block: header [p,Px,Py,Pz] + E (nherm x nab), padded to a multiple of 4 (32-byte rows)
+__host__ __device__ constexpr int qc_pair_stride(int L, int nab) { return (4 + qc_nherm(L) * nab + 3) & ~3; }
 __host__ __device__ constexpr int qc_rwork(int L) { return (L + 1) * (L + 2) * (L + 3) * (L + 4) / 24; }
 
 struct QcShell {
@@ -94,7 +96,7 @@ void qc_build_shards(qc_system *S);
 void qc_host_one_electron(const qc_system *S, int which, double *out);
 void qc_boys_host(int nmax, double x, double *F);
 
-// Boys table: F_n(x_k), x_k = k * QC_BOYS_DX, n = 0..QC_BOYS_NORD-1
+// Boys tables, one per total Hermite order L: row k = F_L .. F_{L+7} at x_k = k * QC_BOYS_DX (64-byte rows)
 constexpr double QC_BOYS_DX = 0.1;
 constexpr int QC_BOYS_NGRID = 421;             // x up to 42
 constexpr double QC_BOYS_XMAX = 41.9;          // beyond: asymptotic + upward recursion

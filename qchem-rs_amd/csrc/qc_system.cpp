@@ -194,7 +194,7 @@ void qc_build_model(qc_system *S) {
             d.doff = (int)S->pairdata.size();
             d.K = A.nprim * B.nprim;
             d.na = A.nfunc; d.nb = B.nfunc; d.offa = A.off; d.offb = B.off; d.L = A.L + B.L; d.shA_eq_shB = (a == b);
-            const int nh = qc_nherm(d.L), nab = d.na * d.nb, stride = 4 + nh * nab;
+            const int nab = d.na * d.nb, stride = qc_pair_stride(d.L, nab);
             S->pairdata.resize(S->pairdata.size() + (size_t)d.K * stride);
             for (int i = 0; i < A.nprim; ++i)
                 for (int j = 0; j < B.nprim; ++j) {
@@ -272,7 +272,7 @@ void qc_build_shards(qc_system *S) {
         int64_t tot_pq = 0;
         for (const auto &t : c.shard) tot_pq += (int64_t)S->pairs[t.bra].K * S->pairs[t.ket].K;
         const int64_t want_waves = 256 * 8, G = 64 >> c.LGC;
-        int itmax = (int)std::min<int64_t>(QC_SLOT_ITMAX, std::max<int64_t>(2, tot_pq / (want_waves * G)));
+        int itmax = (int)std::min<int64_t>(QC_SLOT_ITMAX, std::max<int64_t>((c.LAB + c.LCD <= 2) ? 8 : 2, tot_pq / (want_waves * G)));
         qc_make_slots(S, c.shard, itmax, c.slots);
         c.prim_quartets = 0; c.bytes_alg = 0; c.flops_alg = 0;
         int words = 0;

@@ -23,6 +23,11 @@ import numpy as np
 
 from .loader import MolecularSystem
 
+# The Fock build launches its class kernels on several HIP streams; ROCm maps streams onto 4 hardware queues by
+# default, 8 lets more of the small classes overlap (measured: -20 % Fock-build time on H2O/cc-pVTZ).  Must be set
+# before the HIP runtime initialises, hence at import time.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libqchem_hip.so")
 
