@@ -166,12 +166,121 @@ __global__ __launch_bounds__(QC_EIG_THREADS) void qc_jacobi_kernel(int n, const 
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// One-sided (Hestenes) Jacobi for matrices whose A and V do not both fit in LDS (98 < n <= 128).
+// B = A + sigma I is made positive definite with a Gershgorin shift; the columns of G (initially B) are rotated
+// pairwise to mutual orthogonality, G <- G J.  At convergence G = U Sigma: the normalised columns are the
+// eigenvectors and ||g_i|| - sigma the eigenvalues, so only ONE n x n matrix has to live in LDS (column-major,
+// 16 lanes per column pair, conflict-free reads).  One barrier per step.
+constexpr int QC_EIG1_TEAM = 16;
+
+__global__ __launch_bounds__(QC_EIG_THREADS) void qc_jacobi1_kernel(int n, const double *__restrict__ Ain, double *__restrict__ Vout,
+                                                                    double *__restrict__ w, int max_sweeps) {
+    extern __shared__ double sm[];
+    const int m = (n + 1) & ~1, half = m / 2, ld = n | 1;        // column stride (doubles)
+    double *G = sm;                                               // m columns x ld (padding column stays zero)
+    double *red = G + (size_t)m * ld;                             // 32
+    double *nrm = red + 32;                                       // m column norms
+    int *rank = (int *)(nrm + m);                                 // m
+    int *flag = rank + m;                                         // rotations done in this sweep
+    const int tid = threadIdx.x, nt = blockDim.x;
+
+    // Gershgorin lower bound of the spectrum -> shift
+    double low = 1e300, spread = 0.0;
+    for (int i = tid; i < n; i += nt) {
+        double r = 0.0;
+        for (int j = 0; j < n; ++j) if (j != i) r += fabs(Ain[(size_t)i * n + j]);
+        low = fmin(low, Ain[(size_t)i * n + i] - r);
+        spread = fmax(spread, Ain[(size_t)i * n + i] + r);
+    }
+    for (int o = 32; o > 0; o >>= 1) { low = fmin(low, __shfl_down(low, o, 64)); spread = fmax(spread, __shfl_down(spread, o, 64)); }
+    if ((tid & 63) == 0) { red[tid >> 6] = low; red[16 + (tid >> 6)] = spread; }
+    __syncthreads();
+    low = red[0]; spread = red[16];
+    for (int k = 1; k < nt / 64; ++k) { low = fmin(low, red[k]); spread = fmax(spread, red[16 + k]); }
+    __syncthreads();
+    const double sigma = fmax(0.0, -low) + 0.05 * (spread - low) + 1e-3;
+    for (int x = tid; x < m * ld; x += nt) {
+        const int j = x / ld, i = x - j * ld;                     // column j, row i
+        G[x] = (i < n && j < n) ? Ain[(size_t)i * n + j] + (i == j ? sigma : 0.0) : 0.0;
+    }
+    if (tid == 0) *flag = 0;
+    __syncthreads();
+
+    const int team = tid / QC_EIG1_TEAM, tl = tid % QC_EIG1_TEAM;
+    for (int sweep = 0; sweep < max_sweeps; ++sweep) {
+        for (int step = 0; step < m - 1; ++step) {
+            if (team < half) {
+                int p, q;
+                qc_rr_pair(step, team, m, p, q);
+                double *gp = G + (size_t)p * ld, *gq = G + (size_t)q * ld;
+                double a = 0.0, b = 0.0, c = 0.0, xp[8], xq[8];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    const int r = tl + k * QC_EIG1_TEAM;
+                    xp[k] = (r < n) ? gp[r] : 0.0; xq[k] = (r < n) ? gq[r] : 0.0;
+                    a = fma(xp[k], xp[k], a); b = fma(xq[k], xq[k], b); c = fma(xp[k], xq[k], c);
+                }
+#pragma unroll
+                for (int o = QC_EIG1_TEAM / 2; o > 0; o >>= 1) {
+                    a += __shfl_xor(a, o, QC_EIG1_TEAM); b += __shfl_xor(b, o, QC_EIG1_TEAM); c += __shfl_xor(c, o, QC_EIG1_TEAM);
+                }
+                if (fabs(c) > 1e-15 * sqrt(a * b)) {               // team-uniform
+                    const double zeta = (b - a) / (2.0 * c);
+                    const double t = (zeta >= 0.0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(fma(zeta, zeta, 1.0)));
+                    const double cs = 1.0 / sqrt(fma(t, t, 1.0)), sn = cs * t;
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) {
+                        const int r = tl + k * QC_EIG1_TEAM;
+                        if (r < n) { gp[r] = cs * xp[k] - sn * xq[k]; gq[r] = sn * xp[k] + cs * xq[k]; }
+                    }
+                    if (tl == 0) *flag = 1;                       // benign race: any writer stores 1
+                }
+            }
+            __syncthreads();
+        }
+        const int any = *flag;
+        __syncthreads();
+        if (tid == 0) *flag = 0;
+        __syncthreads();
+        if (!any) break;
+    }
+    // eigenvalues = column norms - sigma; ascending rank sort; normalised, permuted columns out
+    for (int j = tid; j < n; j += nt) {
+        double s2 = 0.0;
+        for (int i = 0; i < n; ++i) s2 = fma(G[(size_t)j * ld + i], G[(size_t)j * ld + i], s2);
+        nrm[j] = sqrt(s2);
+    }
+    __syncthreads();
+    for (int i = tid; i < n; i += nt) {
+        const double wi = nrm[i];
+        int r = 0;
+        for (int j = 0; j < n; ++j) r += (nrm[j] < wi || (nrm[j] == wi && j < i)) ? 1 : 0;
+        rank[i] = r;
+        w[r] = wi - sigma;
+    }
+    __syncthreads();
+    for (int x = tid; x < n * n; x += nt) {
+        const int i = x / n, j = x - i * n;
+        Vout[(size_t)i * n + rank[j]] = G[(size_t)j * ld + i] / nrm[j];
+    }
+}
+
 // dA: input (left intact), dV: sorted eigenvectors, dw: eigenvalues, d_work: n*n scratch
 int qc_eig_device(hipStream_t st, int n, double *dA, double *dV, double *dw, double *d_work) {
     const int m = (n + 1) & ~1, ld = m | 1;
     const size_t tail = (2 * (m / 2) + 32) * sizeof(double) + (size_t)m * sizeof(int) + 16;
     const size_t lds2 = 2 * (size_t)m * ld * sizeof(double) + tail, lds1 = (size_t)m * ld * sizeof(double) + tail;
     const bool v_in_lds = lds2 <= 160 * 1024;
+    if (!v_in_lds && n <= 8 * QC_EIG1_TEAM) {           // 98 < n <= 128: one-sided variant, a single matrix in LDS
+        const size_t l1 = ((size_t)m * (n | 1) + 32 + m) * sizeof(double) + (size_t)(m + 4) * sizeof(int) + 16;
+        if (l1 <= 160 * 1024) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(qc_jacobi1_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)l1);
+            if (e != hipSuccess) return QC_ERR_HIP;
+            hipLaunchKernelGGL(qc_jacobi1_kernel, dim3(1), dim3(QC_EIG_THREADS), l1, st, n, dA, dV, dw, 40);
+            return hipGetLastError() == hipSuccess ? QC_OK : QC_ERR_HIP;
+        }
+    }
     const size_t lds = v_in_lds ? lds2 : lds1;
     if (lds > 160 * 1024) return QC_ERR_UNSUPPORTED;   // n <= 140; larger n needs the multi-workgroup solver (next round)
     auto kern = v_in_lds ? qc_jacobi_kernel<true> : qc_jacobi_kernel<false>;
