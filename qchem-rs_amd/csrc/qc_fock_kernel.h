@@ -41,7 +41,6 @@ struct QcKernelArgs {
 template <int LAB, int LCD>
 __device__ __forceinline__ void qc_step2(double (&W)[qc_nherm(LAB)], const double (&e)[qc_nherm(LCD)], const double *__restrict__ R);
 
-constexpr int QC_LREG = 6;   // total Hermite orders up to this keep the R table in registers (no LDS, no barriers)
 template <int L>
 __device__ __forceinline__ void qc_rtab(double alpha, double X, double Y, double Z, const double (&F)[L + 1], double (&R)[qc_nherm(L)]);
 
@@ -141,15 +140,17 @@ __device__ __forceinline__ void qc_build_r(double *__restrict__ Rw, int li, int 
 
 template <int LAB, int LCD, int LGC>
 __global__ __launch_bounds__(64) void qc_fock_class_kernel(const QcKernelArgs a) {
-    constexpr int L = LAB + LCD, HAB = qc_nherm(LAB), HCD = qc_nherm(LCD), RW = qc_rwork(L);
+    constexpr int L = LAB + LCD, HAB = qc_nherm(LAB), HCD = qc_nherm(LCD);
     constexpr int C = 1 << LGC, G = 64 >> LGC;
     extern __shared__ double lds[];
     const int lane = threadIdx.x, g = lane >> LGC, li = lane & (C - 1);
     const double *__restrict__ pd = a.pairdata;
     const int n = a.n;
     const bool uhf = a.Dk1 != nullptr;
+    constexpr bool HOIST = (L <= QC_LHOIST) && (LGC > 0);
+    constexpr int NHP = qc_nherm(L) | 1;                    // padded table length of the hoisted path
     double *const Rw = lds + (size_t)g * a.slot_words;     // this group's private LDS region
-    double *const Iblk = Rw + RW;
+    double *const Iblk = Rw + qc_region0(L, LGC);
     const size_t rep = (size_t)(blockIdx.x % a.nrep) * a.rep_stride;   // accumulation replica of this workgroup
 
     for (int wave = blockIdx.x; wave * G < a.nslots; wave += gridDim.x) {
@@ -218,9 +219,60 @@ __global__ __launch_bounds__(64) void qc_fock_class_kernel(const QcKernelArgs a)
                 }
             };
 
+            const int K_cd = pk.K;
+            if constexpr (HOIST) {
+                // Low-L classes: Boys + R table are the bulk of a primitive quartet and do not depend on the column, so
+                // the C lanes of a group evaluate C *consecutive* primitive quartets of their slot at once (phase A,
+                // tables in registers, then parked in the group's LDS region) and afterwards walk through them one by
+                // one, every lane contracting its own ket column (phase B).  Same-wave LDS hand-off: wavefront fences.
+                double *const meta = Rw + C * NHP;
+                for (int it0 = 0; it0 < maxlen; it0 += C) {
+                    {
+                        const int itA = it0 + li;
+                        const bool vA = itA < len;
+                        const int pqA = sl.lo + (vA ? itA : 0);
+                        const int ijA = pqA / K_cd, klA = pqA - ijA * K_cd;
+                        const double4 cb = *reinterpret_cast<const double4 *>(braBase + (size_t)ijA * strideB);
+                        const double4 ck = *reinterpret_cast<const double4 *>(ketBase + (size_t)klA * strideK);
+                        const double p = cb.x, q = ck.x;
+                        const double X = cb.y - ck.y, Y = cb.z - ck.z, Z = cb.w - ck.w;
+                        const double pref = rsqrt(p + q);
+                        const double alpha = p * q * (pref * pref);
+                        double F[L + 1], Rr[qc_nherm(L)];
+                        qc_boys<L>(alpha * (X * X + Y * Y + Z * Z), a.boys, F);
+                        qc_rtab<L>(alpha, X, Y, Z, F, Rr);
+                        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");    // phase-B readers of the previous chunk
+                        double *mine = Rw + li * NHP;
+#pragma unroll
+                        for (int h = 0; h < qc_nherm(L); ++h) mine[h] = Rr[h];
+                        meta[2 * li] = vA ? pref : 0.0;
+                        reinterpret_cast<int2 *>(meta)[2 * li + 1] = make_int2(ijA, klA);
+                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                        __builtin_amdgcn_wave_barrier();
+                        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                    }
+                    const int nB = min(C, maxlen - it0);
+                    for (int s = 0; s < nB; ++s) {
+                        const bool valid = it0 + s < len;
+                        const double pref = meta[2 * s];
+                        const int2 ik = reinterpret_cast<const int2 *>(meta)[2 * s + 1];
+                        if (valid && ik.x != cur_ij) {
+                            if (cur_ij >= 0) flush(cur_ij);
+#pragma unroll
+                            for (int h = 0; h < HAB; ++h) W[h] = 0.0;
+                            cur_ij = ik.x;
+                        }
+                        double e[HCD];
+                        const double sc = (valid && colok) ? pref : 0.0;
+                        const double *Ecd = ketBase + (size_t)ik.y * strideK + 4 + (colok ? col : 0);
+#pragma unroll
+                        for (int h = 0; h < HCD; ++h) e[h] = Ecd[h * ncd] * sc;
+                        qc_step2<LAB, LCD>(W, e, Rw + s * NHP);
+                    }
+                }
+            } else {
             // primitive-quartet loop of this slot: (ij, kl) advances incrementally; the 32-byte headers [p, P] of the next
             // primitive pair are requested one iteration ahead
-            const int K_cd = pk.K;
             int ij = sl.lo / K_cd, kl = sl.lo - ij * K_cd;
             double4 hb = *reinterpret_cast<const double4 *>(braBase + (size_t)ij * strideB);
             double4 hk = *reinterpret_cast<const double4 *>(ketBase + (size_t)kl * strideK);
@@ -263,6 +315,7 @@ __global__ __launch_bounds__(64) void qc_fock_class_kernel(const QcKernelArgs a)
                     qc_build_r<L>(Rw, li, C, alpha, X, Y, Z, F);
                     qc_step2<LAB, LCD>(W, e, Rw);
                 }
+            }
             }
             if (cur_ij >= 0) flush(cur_ij);
         }

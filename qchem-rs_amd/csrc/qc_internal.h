@@ -12,7 +12,16 @@
 constexpr int QC_LMAX = 3;              // highest shell angular momentum with kernels (f)
 constexpr int QC_LPAIR = 2 * QC_LMAX;   // highest pair angular momentum
 constexpr int QC_LTOT = 4 * QC_LMAX;    // highest Hermite order of an ERI
-constexpr int QC_SLOT_ITMAX = 128;      // primitive quartets per slot
+constexpr int QC_SLOT_ITMAX = 128;
+constexpr int QC_LREG = 6;               // total Hermite orders up to this keep the R table in registers
+constexpr int QC_LHOIST = 4;             // ... and up to this the C lanes of a group evaluate C primitive quartets' tables at once
+// doubles at the head of a lane group's LDS region: cooperative R work array (L > QC_LREG), or the C hoisted
+// register tables + their (pref, ij/kl) records (L <= QC_LHOIST, C > 1)
+__host__ __device__ constexpr int qc_region0(int L, int lgc) {
+    return L > QC_LREG ? (L + 1) * (L + 2) * (L + 3) * (L + 4) / 24
+                       : ((L <= QC_LHOIST && lgc > 0) ? (1 << lgc) * ((((L + 1) * (L + 2) * (L + 3) / 6) | 1) + 2) : 0);
+}
+      // primitive quartets per slot
 constexpr int QC_NREP = 32;             // replicas of the Fock accumulation buffer
 constexpr int QC_NSTREAMS = 16;         // class kernels of one build run concurrently on this many streams
 

@@ -291,7 +291,7 @@ void qc_build_shards(qc_system *S) {
                            2.0 * ca * cb * cc * cd * hcd + 12.0 * na * nb * nc * nd;
             // LDS doubles one lane group needs for this quartet (layout in qc_fock_kernel.h)
             const int ncd = k.na * k.nb, nab = b.na * b.nb;
-            const int w = qc_rwork(b.L + k.L) + nab * ncd + nab + ncd + 2 * (b.na * k.na + b.na * k.nb + b.nb * k.na + b.nb * k.nb) +
+            const int w = qc_region0(b.L + k.L, c.LGC) + nab * ncd + nab + ncd + 2 * (b.na * k.na + b.na * k.nb + b.nb * k.na + b.nb * k.nb) +
                           nab * qc_nherm(b.L);
             words = std::max(words, w);
         }
