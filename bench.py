@@ -76,13 +76,14 @@ def roofline(torch, sysh, D_host, reps):
     tfs = float(prof["flops"][k]) / (ms * 1e-3) / 1e12
     ws = sysh.work_stats()
     order = prof["class_ms"].argsort()[::-1][:10]
-    top = [{"class": "<%d,%d>" % (int(prof["class_id"][i]) >> 4, int(prof["class_id"][i]) & 15), "ms": float(prof["class_ms"][i]),
+    cname = lambda c: "<%d, %d, %d>" % (int(c) >> 8, (int(c) >> 4) & 15, int(c) & 15)
+    top = [{"class": cname(prof["class_id"][i]), "ms": float(prof["class_ms"][i]),
             "quartets": int(prof["quartets"][i]), "GF": float(prof["flops"][i]) / 1e9} for i in order]
     tot_ms = float(prof["total_ms"])
     sum_ms = float(prof["class_ms"].sum())
     return {
         "bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS, "traffic": None,
-        "kernel": "qc_fock_class_kernel<%d,%d>" % (cid >> 4, cid & 15), "kernel_ms": ms,
+        "kernel": "qc_fock_class_kernel" + cname(cid), "kernel_ms": ms,
         "kernel_quartets": int(prof["quartets"][k]), "kernel_alg_bytes": float(prof["bytes"][k]),
         "kernel_alg_flops": float(prof["flops"][k]),
         "note": "f64 gather-compute-scatter on the FP64 ridge (SURVEY 8d): both roofs are given; the binding one is fp64_valu",

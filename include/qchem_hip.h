@@ -149,7 +149,8 @@ typedef struct {
 } qc_work_stats;
 int qc_work_stats_get(qc_system *sys, qc_work_stats *out);
 /* Time `reps` Fock builds (RHF digestion of dD) per kernel class with hipEvents on the handle's stream.
- * class_ms: caller buffer of `nclasses` floats (average ms per launch of each class kernel); class_id: LAB*16+LCD. */
+ * class_ms: caller buffer of `nclasses` floats (average ms per launch of each class kernel); class_id: (LAB << 8) | (LCD << 4) | LGC,
+ * i.e. the template arguments of qc_fock_class_kernel<LAB, LCD, LGC>. */
 int qc_fock_profile(qc_system *sys, const double *dD, double *dG, int reps, float *class_ms, int32_t *class_id,
                     int64_t *class_quartets, double *class_bytes, double *class_flops, float *total_ms);
 

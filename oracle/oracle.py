@@ -51,6 +51,7 @@ def lib():
         L.orc_antisym_tensor.argtypes = [C.c_int, _dp, _dp]
         L.orc_g_rhf.argtypes = [C.c_int, _dp, _dp, _dp]
         L.orc_g_uhf.argtypes = [C.c_int, _dp, _dp, _dp, _dp]
+        L.orc_g_rhf_quartets.argtypes = [C.c_void_p, C.c_long, _ip, _dp, _dp]
         L.orc_qr_solve.argtypes = [C.c_int, _dp, _dp, _dp]; L.orc_qr_solve.restype = C.c_int
         L.orc_core_guess.argtypes = [C.c_void_p, _dp, _dp, _dp, _dp]
         L.orc_boys.argtypes = [C.c_int, C.c_double, _dp]
@@ -117,6 +118,13 @@ class Oracle:
         n = self.n
         T4 = np.zeros(n ** 4); lib().orc_antisym_tensor(n, np.ascontiguousarray(eri).reshape(-1), T4)
         G = np.zeros((n, n)); lib().orc_g_rhf(n, np.ascontiguousarray(D), T4, G); return G
+
+    def g_rhf_quartets(self, D, abcd):
+        """G = J - K/2 from a list of unique shell quartets (int32 array, shape (nq, 4))."""
+        G = np.zeros((self.n, self.n))
+        abcd = np.ascontiguousarray(abcd, np.int32).reshape(-1)
+        lib().orc_g_rhf_quartets(self.h, len(abcd) // 4, abcd, np.ascontiguousarray(D, np.float64), G)
+        return G
 
     def g_uhf(self, D1, D2, eri):
         n = self.n

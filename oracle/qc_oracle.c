@@ -9,7 +9,7 @@
  * /root/reference/Cargo.toml:12).  What pins this oracle instead (tests/test_oracle_known_answers.py):
  *   - Szabo & Ostlund H2/STO-3G integrals and energy on the reference's own data/mol/hydrogen.json + STO-3G.json,
  *   - T.D. Crawford's published H2O/STO-3G SCF energy (-74.942079928192 Eh) and E_nuc,
- *   - an independent numpy/scipy implementation (tools/gen_golden.py -> tests/golden/*.json),
+ *   - an independent numpy/scipy implementation (tools/gen_golden.py writes tests/golden/integrals_golden.json),
  *   - structural invariants (8-fold ERI symmetry, tr(DS)=N, rotation invariance).
  *
  * Two parts:
@@ -563,7 +563,7 @@ static void updated_density(int n, const double *C, int nocc, double factor, dou
 /* compute_hückel_density (rhf.rs:133-150 / uhf.rs:191-208) */
 static void huckel_density(int n, const double *H, const double *S, const double *X, int nocc, double factor, double *D) {
     double *He = (double *)malloc(sizeof(double) * n * n), *t = (double *)malloc(sizeof(double) * n * n);
-    double *M = (double *)malloc(sizeof(double) * n * n), *Cp = (double *)malloc(sizeof(double) * n * n);
+    double *M = (double *)calloc((size_t)n * n, sizeof(double)), *Cp = (double *)malloc(sizeof(double) * n * n);
     double *C = (double *)malloc(sizeof(double) * n * n), *w = (double *)malloc(sizeof(double) * n);
     for (int i = 0; i < n; i++)
         for (int j = i; j < n; j++) He[i * n + j] = He[j * n + i] = 1.75 * S[i * n + j] * (H[i * n + i] + H[j * n + j]) / 2.0;
@@ -679,6 +679,40 @@ void orc_g_uhf(int n, const double *D1, const double *D2, const double *I, doubl
                      - D1[k * n + l] * I[i * n3 + k * n2 + j * n + l];
             G[i * n + j] = G[j * n + i] = sum;
         }
+}
+
+/* Direct digestion of a LIST of unique shell quartets (A>=B, C>=D, AB>=CD) into G = J - 1/2 K: the checker for the
+ * product's work-sharding (tests/test_sharding_gloo.py).  Each quartet's block is expanded to its <=8 distinct index
+ * images and contracted exactly like the dense loop of rhf.rs:152-167, so summing over a partition of all unique
+ * quartets reproduces orc_g_rhf on the full tensor. */
+void orc_g_rhf_quartets(const Basis *B, long nq, const int *abcd, const double *D, double *G) {
+    int n = B->nbasis;
+    double *buf = (double *)malloc(sizeof(double) * 15 * 15 * 15 * 15);
+    memset(G, 0, sizeof(double) * n * n);
+    for (long t = 0; t < nq; t++) {
+        int sa = abcd[4 * t], sb = abcd[4 * t + 1], sc = abcd[4 * t + 2], sd = abcd[4 * t + 3];
+        const Shell *SA = &B->sh[sa], *SB = &B->sh[sb], *SC = &B->sh[sc], *SD = &B->sh[sd];
+        orc_eri_shell_quartet(B, sa, sb, sc, sd, buf);
+        for (int fa = 0; fa < SA->nfunc; fa++) for (int fb = 0; fb < SB->nfunc; fb++)
+        for (int fc = 0; fc < SC->nfunc; fc++) for (int fd = 0; fd < SD->nfunc; fd++) {
+            double v = buf[((fa * SB->nfunc + fb) * SC->nfunc + fc) * SD->nfunc + fd];
+            int i = SA->off + fa, j = SB->off + fb, k = SC->off + fc, l = SD->off + fd;
+            int cand[8][4] = {{i,j,k,l},{j,i,k,l},{i,j,l,k},{j,i,l,k},{k,l,i,j},{l,k,i,j},{k,l,j,i},{l,k,j,i}};
+            /* all 8 index images are taken; images that coincide because SHELLS coincide are compensated by the
+             * shell-level weight (an element and its in-shell transposes are separate loop iterations) */
+            double shellw = 1.0;
+            if (sa == sb) shellw *= 0.5;
+            if (sc == sd) shellw *= 0.5;
+            if (sa == sc && sb == sd) shellw *= 0.5;
+            /* with shell-level weights every one of the 8 images counts once: */
+            for (int c = 0; c < 8; c++) {
+                int *x = cand[c];
+                G[x[0] * n + x[1]] += shellw * D[x[2] * n + x[3]] * v;             /* J */
+                G[x[0] * n + x[2]] -= 0.5 * shellw * D[x[1] * n + x[3]] * v;       /* K */
+            }
+        }
+    }
+    free(buf);
 }
 
 static double energy_half_trace(int n, const double *D, const double *H, const double *G) {

@@ -293,19 +293,51 @@ int qc_fock_build_device(qc_system *S, const double *dDa, const double *dDb, dou
     }
     const bool two = uhf && !twin;
     const int nspin = two ? 2 : 1;
-    QC_HIP_CHECK(hipMemsetAsync(S->d_Gtmp, 0, (size_t)QC_NREP * nspin * nn * sizeof(double), st));
-    QcFockArgs a{};
-    a.nrep = QC_NREP; a.rep_stride = nspin * nn;
-    if (uhf) {
-        qc_axpby(st, n, 1.0, dDa, 1.0, dDb, S->d_Dj);
-        a.Dj = S->d_Dj; a.Dk0 = dDa; a.Dk1 = two ? dDb : nullptr; a.cK = 1.0;
-    } else {
-        a.Dj = dDa; a.Dk0 = dDa; a.Dk1 = nullptr; a.cK = 0.5;
+    // The accumulation phase (memset, density sum, every class kernel on the side streams, replica fold) is captured
+    // into a hipGraph the first time it runs with a given set of operand pointers and replayed afterwards: the eager
+    // form costs ~10 us of host time per launch, which for the ~35 small class kernels of a build is most of its time.
+    auto enqueue = [&]() -> int {
+        QC_HIP_CHECK(hipMemsetAsync(S->d_Gtmp, 0, (size_t)QC_NREP * nspin * nn * sizeof(double), st));
+        QcFockArgs a{};
+        a.nrep = QC_NREP; a.rep_stride = nspin * nn;
+        if (uhf) {
+            qc_axpby(st, n, 1.0, dDa, 1.0, dDb, S->d_Dj);
+            a.Dj = S->d_Dj; a.Dk0 = dDa; a.Dk1 = two ? dDb : nullptr; a.cK = 1.0;
+        } else {
+            a.Dj = dDa; a.Dk0 = dDa; a.Dk1 = nullptr; a.cK = 0.5;
+        }
+        a.G0 = S->d_Gtmp; a.G1 = S->d_Gtmp + nn;
+        int rc_ = qc_launch_fock_classes(S, a, nullptr);
+        if (rc_ != QC_OK) return rc_;
+        qc_reduce_replicas(st, nspin * nn, QC_NREP, nspin * nn, S->d_Gtmp);
+        return QC_OK;
+    };
+    const int mode = uhf ? (two ? 2 : 1) : 0;
+    hipGraphExec_t exec = nullptr;
+    if (S->use_graphs) {
+        for (auto &g : S->graphs) if (g.Da == dDa && g.Db == dDb && g.mode == mode) exec = g.exec;
+        if (!exec) {
+            hipGraph_t graph = nullptr;
+            bool ok = hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal) == hipSuccess;
+            int rc_cap = ok ? enqueue() : QC_ERR_HIP;
+            if (ok && hipStreamEndCapture(st, &graph) != hipSuccess) ok = false;
+            if (ok && rc_cap == QC_OK && graph && hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0) == hipSuccess) {
+                if (S->graphs.size() >= 6) qc_drop_graphs(S);
+                S->graphs.push_back({dDa, dDb, mode, exec});
+            } else {
+                exec = nullptr;
+                S->use_graphs = false;                 // capture unsupported here: stay on eager launches
+                (void)hipGetLastError();
+            }
+            if (graph) (void)hipGraphDestroy(graph);
+        }
     }
-    a.G0 = S->d_Gtmp; a.G1 = S->d_Gtmp + nn;
-    int rc = qc_launch_fock_classes(S, a, nullptr);
-    if (rc != QC_OK) return rc;
-    qc_reduce_replicas(st, nspin * nn, QC_NREP, nspin * nn, S->d_Gtmp);
+    if (exec) {
+        QC_HIP_CHECK(hipGraphLaunch(exec, st));
+    } else {
+        int rc = enqueue();
+        if (rc != QC_OK) return rc;
+    }
     if (S->comm) {   // partial Fock matrices -> full, one all-reduce per build ([Ga|Gb] concatenated for UHF)
         if (ncclAllReduce(S->d_Gtmp, S->d_Gtmp, nspin * nn, ncclDouble, ncclSum, (ncclComm_t)S->comm, st) != ncclSuccess) return QC_ERR_RCCL;
     }
@@ -572,9 +604,10 @@ int qc_plan_shard(qc_system *S, int rank, int nranks, int64_t *nquartets, double
 int qc_plan_shard_quartets(qc_system *S, int rank, int nranks, int32_t *abcd /* 4 * nquartets or NULL */, int64_t capacity) {
     if (!S || nranks <= 0 || rank < 0 || rank >= nranks) return QC_ERR_INVALID;
     int64_t k = 0;
-    for (const auto &c : S->classes)
+    for (size_t ci = 0; ci < S->classes.size(); ++ci) {
+        const auto &c = S->classes[ci];
         for (size_t i = 0; i < c.tasks.size(); ++i) {
-            if ((int)(i % nranks) != rank) continue;
+            if (qc_shard_owner(i, nranks, ci) != rank) continue;
             if (abcd) {
                 if (k >= capacity) return QC_ERR_INVALID;
                 abcd[4 * k + 0] = S->pairA[c.tasks[i].bra]; abcd[4 * k + 1] = S->pairB[c.tasks[i].bra];
@@ -582,6 +615,7 @@ int qc_plan_shard_quartets(qc_system *S, int rank, int nranks, int32_t *abcd /* 
             }
             ++k;
         }
+    }
     return (int)k;
 }
 
@@ -627,7 +661,7 @@ int qc_fock_profile(qc_system *S, const double *dD, double *dG, int reps, float 
         const QcClass &c = S->classes[i];
         if (c.shard.empty()) continue;
         if (class_ms) class_ms[k] = acc[i] / reps;
-        if (class_id) class_id[k] = c.LAB * 16 + c.LCD;
+        if (class_id) class_id[k] = (c.LAB << 8) | (c.LCD << 4) | c.LGC;
         if (class_quartets) class_quartets[k] = (int64_t)c.shard.size();
         if (class_bytes) class_bytes[k] = c.bytes_alg;
         if (class_flops) class_flops[k] = c.flops_alg;

@@ -4,23 +4,23 @@
 
 #include "qc_fock_kernel.h"
 
-int qc_launch_class_lab0(int, int, int, size_t, hipStream_t, const QcKernelArgs &);
-int qc_launch_class_lab1(int, int, int, size_t, hipStream_t, const QcKernelArgs &);
-int qc_launch_class_lab2(int, int, int, size_t, hipStream_t, const QcKernelArgs &);
-int qc_launch_class_lab3(int, int, int, size_t, hipStream_t, const QcKernelArgs &);
-int qc_launch_class_lab4(int, int, int, size_t, hipStream_t, const QcKernelArgs &);
-int qc_launch_class_lab5(int, int, int, size_t, hipStream_t, const QcKernelArgs &);
-int qc_launch_class_lab6(int, int, int, size_t, hipStream_t, const QcKernelArgs &);
+int qc_launch_tier_lab0(int, int, size_t, hipStream_t, const QcTierArgs &);
+int qc_launch_tier_lab1(int, int, size_t, hipStream_t, const QcTierArgs &);
+int qc_launch_tier_lab2(int, int, size_t, hipStream_t, const QcTierArgs &);
+int qc_launch_tier_lab3(int, int, size_t, hipStream_t, const QcTierArgs &);
+int qc_launch_tier_lab4(int, int, size_t, hipStream_t, const QcTierArgs &);
+int qc_launch_tier_lab5(int, int, size_t, hipStream_t, const QcTierArgs &);
+int qc_launch_tier_lab6(int, int, size_t, hipStream_t, const QcTierArgs &);
 
-static int launch_class(int lab, int lcd, int lgc, int grid, size_t lds, hipStream_t st, const QcKernelArgs &a) {
+static int launch_tier(int lab, int tier, int grid, size_t lds, hipStream_t st, const QcTierArgs &a) {
     switch (lab) {
-        case 0: return qc_launch_class_lab0(lcd, lgc, grid, lds, st, a);
-        case 1: return qc_launch_class_lab1(lcd, lgc, grid, lds, st, a);
-        case 2: return qc_launch_class_lab2(lcd, lgc, grid, lds, st, a);
-        case 3: return qc_launch_class_lab3(lcd, lgc, grid, lds, st, a);
-        case 4: return qc_launch_class_lab4(lcd, lgc, grid, lds, st, a);
-        case 5: return qc_launch_class_lab5(lcd, lgc, grid, lds, st, a);
-        case 6: return qc_launch_class_lab6(lcd, lgc, grid, lds, st, a);
+        case 0: return qc_launch_tier_lab0(tier, grid, lds, st, a);
+        case 1: return qc_launch_tier_lab1(tier, grid, lds, st, a);
+        case 2: return qc_launch_tier_lab2(tier, grid, lds, st, a);
+        case 3: return qc_launch_tier_lab3(tier, grid, lds, st, a);
+        case 4: return qc_launch_tier_lab4(tier, grid, lds, st, a);
+        case 5: return qc_launch_tier_lab5(tier, grid, lds, st, a);
+        case 6: return qc_launch_tier_lab6(tier, grid, lds, st, a);
     }
     return QC_ERR_UNSUPPORTED;
 }
@@ -41,7 +41,13 @@ static int upload_slots(qc_system *S) {
     return QC_OK;
 }
 
+void qc_drop_graphs(qc_system *S) {
+    for (auto &g : S->graphs) if (g.exec) (void)hipGraphExecDestroy(g.exec);
+    S->graphs.clear();
+}
+
 int qc_device_reshard(qc_system *S) {
+    qc_drop_graphs(S);
     qc_build_shards(S);
     if (!S->device_ready) return QC_OK;
     return upload_slots(S);
@@ -88,6 +94,7 @@ int qc_device_init(qc_system *S) {
 }
 
 void qc_device_free(qc_system *S) {
+    qc_drop_graphs(S);
     for (auto &c : S->classes) if (c.d_slots) { (void)hipFree(c.d_slots); c.d_slots = nullptr; }
     void *ptrs[] = {S->d_pairdata, S->d_pairs, S->d_boys, S->d_D, S->d_G, S->d_Gtmp, S->d_Dj, S->d_flag};
     S->d_flag = nullptr;
@@ -112,50 +119,93 @@ static QcKernelArgs base_args(qc_system *S, const QcFockArgs &fa) {
     return a;
 }
 
-static int launch_one(const QcClass &c, const QcSlot *d_slots, int nslots, hipStream_t st, QcKernelArgs a) {
-    a.slots = d_slots; a.nslots = nslots; a.slot_words = c.slot_words;
-    const int G = 64 >> c.LGC;
-    const int waves = (nslots + G - 1) / G;
-    const int grid = std::min(waves, 256 * 32);
-    return launch_class(c.LAB, c.LCD, c.LGC, grid, (size_t)c.lds_bytes, st, a);
+// segment of one launch: a class bucket with its slots
+struct Seg { const QcClass *c; const QcSlot *d_slots; int nslots; };
+
+static int launch_segments(int lab, int tier, const std::vector<Seg> &segs, hipStream_t st, const QcKernelArgs &base) {
+    QcTierArgs t{};
+    t.base = base;
+    int grid = 0, lds = 0, k = 0;
+    for (const Seg &sg : segs) {
+        const int G = 64 >> sg.c->LGC;
+        const int waves = (sg.nslots + G - 1) / G;
+        grid += std::min(waves, 256 * 32);
+        t.seg_end[k] = grid; t.seg_code[k] = (sg.c->LCD << 4) | sg.c->LGC;
+        t.seg_nslots[k] = sg.nslots; t.seg_words[k] = sg.c->slot_words; t.seg_slots[k] = sg.d_slots;
+        lds = std::max(lds, sg.c->lds_bytes);
+        ++k;
+    }
+    t.nseg = k;
+    return launch_tier(lab, tier, grid, (size_t)lds, st, t);
 }
 
-// One launch per non-empty class.  Normal mode: the launches are independent (they only meet in the atomically
-// accumulated Gt replicas), so they are spread over QC_NSTREAMS side streams forked from / joined to the handle's
-// stream - small classes fill the CUs the big ones leave idle.  Profiling mode (class_ms != nullptr): serial on the
-// handle's stream with a hipEvent between consecutive launches.
-int qc_launch_fock_classes(qc_system *S, const QcFockArgs &fa, float *class_ms) {
+// Launch units of one build: per bra class LAB, tier 0 (LCD <= 3) and tier 1 (LCD >= 4); segments heaviest first.
+static void tier_units(qc_system *S, std::vector<std::vector<int>> &units) {
+    units.assign(2 * (QC_LPAIR + 1), {});
+    for (size_t ci = 0; ci < S->classes.size(); ++ci) {
+        const QcClass &c = S->classes[ci];
+        if (c.slots.empty()) continue;
+        units[2 * c.LAB + (c.LCD >= 4 ? 1 : 0)].push_back((int)ci);
+    }
+    for (auto &u : units)
+        std::stable_sort(u.begin(), u.end(), [&](int x, int y) {
+            const QcClass &a_ = S->classes[x], &b_ = S->classes[y];
+            if (a_.LCD != b_.LCD) return a_.LCD > b_.LCD;              // long serial chains first
+            return a_.flops_alg > b_.flops_alg;
+        });
+}
+
+// Normal mode: the (at most 14) tier launches are independent (they only meet in the atomically accumulated Gt
+// replicas), so each goes to its own side stream forked from / joined to the handle's stream.
+// Profiling mode (class_ms != nullptr): one single-segment launch per class bucket, serial on the handle's stream with
+// a hipEvent between consecutive launches; unit_ms (optional, 14 entries) times the real tier launches the same way.
+int qc_launch_fock_classes(qc_system *S, const QcFockArgs &fa, float *class_ms, float *unit_ms) {
     const QcKernelArgs a = base_args(S, fa);
-    if (class_ms) {
-        std::vector<hipEvent_t> ev(S->classes.size() + 1);
+    std::vector<std::vector<int>> units;
+    tier_units(S, units);
+    auto segs_of = [&](const std::vector<int> &u) {
+        std::vector<Seg> v;
+        for (int ci : u) v.push_back(Seg{&S->classes[ci], S->classes[ci].d_slots, (int)S->classes[ci].slots.size()});
+        return v;
+    };
+    if (class_ms || unit_ms) {
+        const size_t nev = (class_ms ? S->classes.size() : units.size()) + 1;
+        std::vector<hipEvent_t> ev(nev);
         for (auto &e : ev) QC_HIP_CHECK(hipEventCreate(&e));
         QC_HIP_CHECK(hipEventRecord(ev[0], S->stream));
-        for (size_t ci = 0; ci < S->classes.size(); ++ci) {
-            const QcClass &c = S->classes[ci];
-            if (!c.slots.empty()) { int rc = launch_one(c, c.d_slots, (int)c.slots.size(), S->stream, a); if (rc != QC_OK) return rc; }
-            QC_HIP_CHECK(hipEventRecord(ev[ci + 1], S->stream));
+        if (class_ms) {
+            for (size_t ci = 0; ci < S->classes.size(); ++ci) {
+                const QcClass &c = S->classes[ci];
+                if (!c.slots.empty()) {
+                    int rc = launch_segments(c.LAB, c.LCD >= 4 ? 1 : 0, {Seg{&c, c.d_slots, (int)c.slots.size()}}, S->stream, a);
+                    if (rc != QC_OK) return rc;
+                }
+                QC_HIP_CHECK(hipEventRecord(ev[ci + 1], S->stream));
+            }
+        } else {
+            for (size_t u = 0; u < units.size(); ++u) {
+                if (!units[u].empty()) { int rc = launch_segments((int)u / 2, (int)u % 2, segs_of(units[u]), S->stream, a); if (rc != QC_OK) return rc; }
+                QC_HIP_CHECK(hipEventRecord(ev[u + 1], S->stream));
+            }
         }
         QC_HIP_CHECK(hipEventSynchronize(ev.back()));
-        for (size_t ci = 0; ci < S->classes.size(); ++ci) QC_HIP_CHECK(hipEventElapsedTime(&class_ms[ci], ev[ci], ev[ci + 1]));
+        float *out = class_ms ? class_ms : unit_ms;
+        for (size_t i = 0; i + 1 < nev; ++i) QC_HIP_CHECK(hipEventElapsedTime(&out[i], ev[i], ev[i + 1]));
         for (auto &e : ev) (void)hipEventDestroy(e);
         return QC_OK;
     }
     QC_HIP_CHECK(hipEventRecord(S->ev_fork, S->stream));
-    for (int i = 0; i < QC_NSTREAMS; ++i) QC_HIP_CHECK(hipStreamWaitEvent(S->side[i], S->ev_fork, 0));
-    // biggest classes first, round-robin over the side streams
-    std::vector<int> order;
-    for (size_t ci = 0; ci < S->classes.size(); ++ci) if (!S->classes[ci].slots.empty()) order.push_back((int)ci);
-    std::stable_sort(order.begin(), order.end(), [&](int x, int y) { return S->classes[x].flops_alg > S->classes[y].flops_alg; });
+    // heavy tiers (high LAB, tier 1) first
     int k = 0;
-    for (int ci : order) {
-        const QcClass &c = S->classes[ci];
-        int rc = launch_one(c, c.d_slots, (int)c.slots.size(), S->side[k % QC_NSTREAMS], a);
+    for (int u = (int)units.size() - 1; u >= 0; --u) {
+        if (units[u].empty()) continue;
+        hipStream_t st = S->side[k % QC_NSTREAMS];
+        QC_HIP_CHECK(hipStreamWaitEvent(st, S->ev_fork, 0));
+        int rc = launch_segments(u / 2, u % 2, segs_of(units[u]), st, a);
         if (rc != QC_OK) return rc;
+        QC_HIP_CHECK(hipEventRecord(S->ev_join[k % QC_NSTREAMS], st));
+        QC_HIP_CHECK(hipStreamWaitEvent(S->stream, S->ev_join[k % QC_NSTREAMS], 0));
         ++k;
-    }
-    for (int i = 0; i < QC_NSTREAMS; ++i) {
-        QC_HIP_CHECK(hipEventRecord(S->ev_join[i], S->side[i]));
-        QC_HIP_CHECK(hipStreamWaitEvent(S->stream, S->ev_join[i], 0));
     }
     return QC_OK;
 }
@@ -172,7 +222,7 @@ int qc_launch_eri_full(qc_system *S, double *d_out) {
         QcSlot *d = nullptr;
         QC_HIP_CHECK(hipMalloc(&d, slots.size() * sizeof(QcSlot)));
         QC_HIP_CHECK(hipMemcpyAsync(d, slots.data(), slots.size() * sizeof(QcSlot), hipMemcpyHostToDevice, S->stream));
-        int rc = launch_one(c, d, (int)slots.size(), S->stream, a);
+        int rc = launch_segments(c.LAB, c.LCD >= 4 ? 1 : 0, {Seg{&c, d, (int)slots.size()}}, S->stream, a);
         QC_HIP_CHECK(hipStreamSynchronize(S->stream));
         (void)hipFree(d);
         if (rc != QC_OK) return rc;

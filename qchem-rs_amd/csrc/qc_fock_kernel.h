@@ -25,9 +25,6 @@
 struct QcKernelArgs {
     const QcPairDesc *pairs;
     const double *pairdata;
-    const QcSlot *slots;      // work units of this launch: (bra pair, ket pair, primitive-quartet range)
-    int nslots;
-    int slot_words;           // LDS doubles per lane group (R work array + I block + density tiles)
     const double *boys;
     int n;
     const double *Dj, *Dk0, *Dk1;
@@ -139,7 +136,8 @@ __device__ __forceinline__ void qc_build_r(double *__restrict__ Rw, int li, int 
 }
 
 template <int LAB, int LCD, int LGC>
-__global__ __launch_bounds__(64) void qc_fock_class_kernel(const QcKernelArgs a) {
+__device__ __forceinline__ void qc_fock_body(const QcKernelArgs &a, const QcSlot *__restrict__ slots, const int nslots, const int slot_words,
+                                             const int blk, const int nblk) {
     constexpr int L = LAB + LCD, HAB = qc_nherm(LAB), HCD = qc_nherm(LCD);
     constexpr int C = 1 << LGC, G = 64 >> LGC;
     extern __shared__ double lds[];
@@ -149,14 +147,14 @@ __global__ __launch_bounds__(64) void qc_fock_class_kernel(const QcKernelArgs a)
     const bool uhf = a.Dk1 != nullptr;
     constexpr bool HOIST = (L <= QC_LHOIST) && (LGC > 0);
     constexpr int NHP = qc_nherm(L) | 1;                    // padded table length of the hoisted path
-    double *const Rw = lds + (size_t)g * a.slot_words;     // this group's private LDS region
+    double *const Rw = lds + (size_t)g * slot_words;       // this group's private LDS region
     double *const Iblk = Rw + qc_region0(L, LGC);
-    const size_t rep = (size_t)(blockIdx.x % a.nrep) * a.rep_stride;   // accumulation replica of this workgroup
+    const size_t rep = (size_t)(blk % a.nrep) * a.rep_stride;   // accumulation replica of this workgroup
 
-    for (int wave = blockIdx.x; wave * G < a.nslots; wave += gridDim.x) {
+    for (int wave = blk; wave * G < nslots; wave += nblk) {
         const int slot = wave * G + g;
-        const bool active = slot < a.nslots;
-        const QcSlot sl = a.slots[active ? slot : a.nslots - 1];
+        const bool active = slot < nslots;
+        const QcSlot sl = slots[active ? slot : nslots - 1];
         const QcPairDesc pb = a.pairs[sl.bra], pk = a.pairs[sl.ket];
         const int na = pb.na, nb = pb.nb, nc = pk.na, nd = pk.nb;
         const int nab = na * nb, ncd = nc * nd;
@@ -395,12 +393,46 @@ __global__ __launch_bounds__(64) void qc_fock_class_kernel(const QcKernelArgs a)
     }
 }
 
-template <int LAB, int LCD, int LGC>
-int qc_launch_class(int grid, size_t lds, hipStream_t st, const QcKernelArgs &a) {
-    auto kern = qc_fock_class_kernel<LAB, LCD, LGC>;
-    if (lds > 48 * 1024) {
+// One launch = one "tier" of a bra class: all (LCD, LGC) buckets of LAB with LCD <= 3 (tier 0: moderate register
+// footprint, several waves per SIMD) or LCD >= 4 (tier 1).  The grid is the concatenation of the buckets' block
+// ranges ("segments"); a workgroup finds its segment and runs that bucket's body.  Fewer, fuller launches: the eager
+// launch of ~35 separate class kernels was host-launch-bound (~10 us each).
+constexpr int QC_MAXSEG = 8;
+struct QcTierArgs {
+    QcKernelArgs base;
+    int nseg;
+    int seg_end[QC_MAXSEG];        // exclusive prefix of workgroup counts
+    int seg_code[QC_MAXSEG];       // (LCD << 4) | LGC
+    int seg_nslots[QC_MAXSEG];
+    int seg_words[QC_MAXSEG];
+    const QcSlot *seg_slots[QC_MAXSEG];
+};
+
+template <int LAB, int TIER>
+__global__ __launch_bounds__(64) void qc_fock_tier_kernel(const QcTierArgs a) {
+    int s = 0;
+    while (s + 1 < a.nseg && (int)blockIdx.x >= a.seg_end[s]) ++s;
+    const int b0 = s ? a.seg_end[s - 1] : 0;
+    const int blk = blockIdx.x - b0, nblk = a.seg_end[s] - b0;
+    const QcSlot *slots = a.seg_slots[s];
+    const int nslots = a.seg_nslots[s], words = a.seg_words[s];
+#define QC_CASE(LCD, LGC) case ((LCD) << 4 | (LGC)): qc_fock_body<LAB, LCD, LGC>(a.base, slots, nslots, words, blk, nblk); break;
+    if constexpr (TIER == 0) {
+        switch (a.seg_code[s]) { QC_CASE(0, 0) QC_CASE(1, 2) QC_CASE(2, 3) QC_CASE(2, 4) QC_CASE(3, 3) QC_CASE(3, 4) QC_CASE(3, 5) default: break; }
+    } else {
+        switch (a.seg_code[s]) { QC_CASE(4, 5) QC_CASE(4, 6) QC_CASE(5, 6) QC_CASE(6, 6) default: break; }
+    }
+#undef QC_CASE
+}
+
+template <int LAB, int TIER>
+int qc_launch_tier(int grid, size_t lds, hipStream_t st, const QcTierArgs &a) {
+    auto kern = qc_fock_tier_kernel<LAB, TIER>;
+    static size_t lds_allowed = 48 * 1024;      // raise the dynamic-LDS cap once per instantiation, not per launch
+    if (lds > lds_allowed) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return QC_ERR_HIP;
+        lds_allowed = lds;
     }
     hipLaunchKernelGGL(kern, dim3(grid), dim3(64), lds, st, a);
     return hipGetLastError() == hipSuccess ? QC_OK : QC_ERR_HIP;

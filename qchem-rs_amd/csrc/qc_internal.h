@@ -96,6 +96,10 @@ struct qc_system {
     double *d_Dj = nullptr;
     int *d_flag = nullptr;
     void *comm = nullptr;                    // ncclComm_t
+    // captured Fock builds (memset + class kernels on the side streams + replica fold), keyed by operand pointers
+    struct FockGraph { const double *Da, *Db; int mode; hipGraphExec_t exec; };
+    std::vector<FockGraph> graphs;
+    bool use_graphs = false;                 // hipGraph replay of the build measured slower than eager multi-stream launches on ROCm 7.2
     std::string last_error;
 };
 
@@ -126,7 +130,8 @@ struct QcFockArgs {
     size_t rep_stride;    // doubles between replicas
 };
 int qc_launch_eri_full(qc_system *S, double *d_out);
-int qc_launch_fock_classes(qc_system *S, const QcFockArgs &a, float *class_ms /*nullable*/);
+void qc_drop_graphs(qc_system *S);
+int qc_launch_fock_classes(qc_system *S, const QcFockArgs &a, float *class_ms /*nullable*/, float *unit_ms = nullptr /*nullable, 14*/);
 int qc_fock_build_device(qc_system *S, const double *dDa, const double *dDb, double *dGa, double *dGb, bool uhf);
 
 // dense linear algebra on the handle's stream (all row-major n x n, device pointers)
@@ -140,6 +145,12 @@ void qc_symmetrize_add(hipStream_t st, int n, const double *Gt, double *G);     
 void qc_reduce_replicas(hipStream_t st, size_t count, int nrep, size_t stride, double *Gt);  // Gt[0] += sum_r>0 Gt[r]
 void qc_count_diff(hipStream_t st, size_t count, const double *a, const double *b, int *flag);
 int qc_lgc_for(int lcd, int ncd);
+// owner of the i-th (cost-sorted) quartet of launch class `ci`: boustrophedon deal, start rank rotated per class
+inline int qc_shard_owner(size_t i, int nranks, size_t ci) {
+    const size_t round = i / nranks, pos = i % nranks;
+    const size_t r = (round & 1) ? (nranks - 1 - pos) : pos;
+    return (int)((r + ci) % nranks);
+}
 void qc_make_slots(const qc_system *S, const std::vector<QcTask> &tasks, int itmax, std::vector<QcSlot> &out);
 void qc_dots(hipStream_t st, int n, const double *x, const double *const *ys, int ny, double *out);  // device ptr list
 void qc_lincomb(hipStream_t st, int n, const double *const *Fs, const double *c, int m, double *out);   // out = sum c_i Fs_i

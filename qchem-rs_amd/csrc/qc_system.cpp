@@ -257,17 +257,19 @@ void qc_make_slots(const qc_system *S, const std::vector<QcTask> &tasks, int itm
     std::stable_sort(out.begin(), out.end(), [](const QcSlot &x, const QcSlot &y) { return x.hi - x.lo > y.hi - y.lo; });
 }
 
-// Static shard: inside every launch class the quartet list is dealt round-robin to the ranks, so each rank holds the
-// same mix of classes and (to within one quartet per class) the same modelled cost.  Data-only; no communication.
+// Static shard: inside every launch class the cost-sorted quartet list is dealt to the ranks in boustrophedon order
+// (0..N-1, N-1..0, ...; start rank rotated per class), so each rank holds the same mix of classes and nearly the same
+// modelled cost.  Data-only; no communication.
 void qc_build_shards(qc_system *S) {
-    for (auto &c : S->classes) {
+    for (size_t ci = 0; ci < S->classes.size(); ++ci) {
+        auto &c = S->classes[ci];
         // heaviest first: the primitive-quartet count is the dominant cost inside a class
         std::stable_sort(c.tasks.begin(), c.tasks.end(), [&](const QcTask &x, const QcTask &y) {
             return (int64_t)S->pairs[x.bra].K * S->pairs[x.ket].K > (int64_t)S->pairs[y.bra].K * S->pairs[y.ket].K;
         });
         c.shard.clear();
         for (size_t i = 0; i < c.tasks.size(); ++i)
-            if ((int)(i % S->nranks) == S->rank) c.shard.push_back(c.tasks[i]);
+            if (qc_shard_owner(i, S->nranks, ci) == S->rank) c.shard.push_back(c.tasks[i]);
         // slot length: long enough to amortise the per-slot digestion, short enough that the class still fills the chip
         int64_t tot_pq = 0;
         for (const auto &t : c.shard) tot_pq += (int64_t)S->pairs[t.bra].K * S->pairs[t.ket].K;

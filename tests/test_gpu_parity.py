@@ -108,6 +108,32 @@ def test_sharded_fock_sums_to_full():
     assert np.abs(acc - G_full).max() < 1e-11 * np.abs(G_full).max()
 
 
+def test_rccl_path_single_rank_communicator():
+    """The multi-GPU build path (shard + RCCL all-reduce of the partial Fock matrix) with a 1-rank communicator:
+    exercises ncclGetUniqueId / ncclCommInitRank / ncclAllReduce inside libqchem_hip.so on real hardware."""
+    q, s, o = _sys("water", "STO-3G")
+    s.comm_init(q.comm_unique_id(), 0, 1)
+    D = _rand_sym(s.n, 9)
+    assert np.abs(s.fock_rhf(D) - o.g_rhf(D, o.eri())).max() < TOL_INT * 10
+    Ga, Gb = s.fock_uhf(D, 0.5 * D)
+    assert np.abs(Ga - o.g_uhf(D, 0.5 * D, o.eri())).max() < TOL_INT * 10
+
+
+def test_step_api_matches_driver():
+    """qc_scf_begin/iterate/end (the entry points a host-owned convergence loop binds) == qc_scf_rhf."""
+    q, s, o = _sys("water", "cc-pVDZ")
+    st = q.ScfStepper(s)
+    e = rms = None
+    for it in range(100):
+        e, rms = st.iterate()
+        if rms < 1e-10:
+            break
+    out = q.restricted_hartree_fock(s, q.HartreeFockConfig(100, 1e-10))
+    assert out.iterations == it and abs(e - out.electronic_energy) < 1e-9
+    assert np.abs(st.orbital_energies() - np.array(out.orbital_energies)).max() < 1e-9
+    st.close()
+
+
 @pytest.mark.parametrize("n", [2, 7, 24, 58, 114])
 def test_sym_eig(n):
     import qchem_rs_amd as q

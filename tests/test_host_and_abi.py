@@ -1,0 +1,100 @@
+"""CPU tests of the host side: loaders, the C ABI surface (load + exported symbols, no compute), the host-only model
+(one-electron matrices, quartet plan, sharding) and the loud failure when no GPU is present."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+from conftest import ROOT, data, load_system
+
+
+def test_loader_reads_reference_formats():
+    import qchem_rs_amd as q
+    b = q.BasisSet.load(data("basis", "STO-3G.json"))
+    assert [s.L for s in b.elements[8]] == [0, 0, 1]                       # SP shell split into s and p
+    assert b.elements[8][1].exponents == b.elements[8][2].exponents
+    m = q.MolecularSystem.load(data("mol", "water.json"), b)
+    assert [a.ordinal for a in m.atoms] == [1, 8, 1] and m.n_basis() == 7 and m.n_electrons == 10
+    b2 = q.BasisSet.load(data("basis", "6-31G_st_st.json"))
+    assert q.MolecularSystem.load(data("mol", "benzene.json"), b2).n_basis() == 120   # cartesian d
+    b3 = q.BasisSet.load(data("basis", "cc-pVTZ.json"))                    # general contractions split, zeros dropped
+    m3 = q.MolecularSystem.load(data("mol", "water.json"), b3)
+    assert m3.n_basis() == 58 and m3.n_shells == 22
+    with pytest.raises(KeyError):
+        q.MolecularSystem.load(data("mol", "chloroform.json"), b3)         # no Cl in the authored cc-pVTZ
+
+
+def test_library_loads_and_exports_every_declared_symbol():
+    import qchem_rs_amd as q
+    L = q.lib()
+    header = open(os.path.join(ROOT, "include", "qchem_hip.h")).read()
+    declared = set(re.findall(r"\b(qc_[a-z0-9_]+)\s*\(", header))
+    declared -= {"qc_system", "qc_scf_state"}
+    assert declared, "no declarations parsed"
+    missing = [s for s in sorted(declared) if not hasattr(L, s)]
+    assert not missing, missing
+    assert set(q.hf.EXPORTS) <= declared
+
+
+def test_host_model_matches_oracle_without_a_gpu():
+    import qchem_rs_amd as q
+    from oracle.oracle import Oracle
+    m = load_system("water", "cc-pVTZ")
+    s, o = q.System(m), Oracle(m)
+    assert s.n == 58 and s.n_quartets() == 32131 and s.n_electrons() == 10
+    assert abs(s.nuclear_repulsion() - o.nuclear_repulsion()) < 1e-13
+    assert np.abs(s.overlap() - o.overlap()).max() < 1e-13
+    assert np.abs(s.kinetic() - o.kinetic()).max() < 1e-12
+    assert np.abs(s.nuclear() - o.nuclear()).max() < 1e-12
+    ws = s.work_stats()
+    assert ws.quartets == 32131 and ws.prim_quartets > ws.quartets and ws.bytes_alg > 0 and ws.flops_alg > 0
+
+
+@pytest.mark.parametrize("nranks", [2, 3, 8])
+def test_shard_plan_is_a_partition(nranks):
+    import qchem_rs_amd as q
+    s = q.System(load_system("water", "cc-pVDZ"))
+    seen = set()
+    counts, flops = [], []
+    for r in range(nranks):
+        qs = s.plan_shard_quartets(r, nranks)
+        nq, fl = s.plan_shard(r, nranks)
+        assert nq == len(qs)
+        counts.append(nq); flops.append(fl)
+        for a, b, c, d in qs.tolist():
+            assert a >= b and c >= d
+            key = (a, b, c, d) if (a, b) >= (c, d) else (c, d, a, b)
+            assert key not in seen
+            seen.add(key)
+    assert len(seen) == s.n_quartets() == sum(counts)
+    assert max(flops) / min(flops) < 1.25                                  # cost-balanced within 25 %
+
+
+def test_compute_calls_fail_loudly_without_a_gpu():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    import qchem_rs_amd as q
+    s = q.System(load_system("hydrogen", "STO-3G"))
+    assert not q.device_ready()
+    with pytest.raises(q.QcError, match="no CPU fallback"):
+        s.fock_rhf(np.eye(2))
+    with pytest.raises(q.QcError):
+        q.restricted_hartree_fock(s, q.HartreeFockConfig(10, 1e-6))
+    with pytest.raises(q.QcError):
+        s.eri()
+
+
+def test_invalid_inputs_are_rejected():
+    import qchem_rs_amd as q
+    L = q.lib()
+    h = ctypes.c_void_p()
+    Z = np.array([1], np.int32); xyz = np.zeros(3); one = np.array([0], np.int32)
+    bad_L = np.array([5], np.int32); npr = np.array([1], np.int32); e = np.array([1.0]); c = np.array([1.0])
+    rc = L.qc_system_create(1, Z, xyz, 1, one, bad_L, one, npr, e, c, ctypes.byref(h))
+    assert rc == q.hf.QC_ERR_UNSUPPORTED                                    # h shells: no kernels
+    bad_atom = np.array([3], np.int32)
+    rc = L.qc_system_create(1, Z, xyz, 1, bad_atom, one, one, npr, e, c, ctypes.byref(h))
+    assert rc == q.hf.QC_ERR_INVALID
