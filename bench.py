@@ -64,35 +64,40 @@ def timed_steps(torch, dist, stepper, steps, warmup, world):
 
 
 def roofline(torch, sysh, D_host, reps):
-    """Per-class hipEvent timing of the Fock build; report the class kernel that takes the most time."""
+    """hipEvent timing (on the library's stream) of the kernels a Fock build launches.
+
+    A build = at most 14 `qc_fock_tier_kernel<LAB, TIER>` launches (all class buckets of bra class LAB with LCD <= 3 /
+    LCD >= 4) that run concurrently on side streams.  The roofline entry is the tier kernel that takes the longest when
+    each is launched alone; `fock_build` gives the same ratios for the whole (overlapped) build, `classes` the per-bucket
+    view.  Algorithmic bytes/flops: SURVEY.md 8(d) per-quartet model summed over the quartets a launch processes."""
     dD = torch.from_numpy(D_host).cuda()
     dG = torch.zeros_like(dD)
     torch.cuda.synchronize()
-    prof = sysh.fock_profile(dD.data_ptr(), dG.data_ptr(), reps)
-    k = int(prof["class_ms"].argmax())
-    ms = float(prof["class_ms"][k])
-    cid = int(prof["class_id"][k])
-    gbs = float(prof["bytes"][k]) / (ms * 1e-3) / 1e9
-    tfs = float(prof["flops"][k]) / (ms * 1e-3) / 1e12
+    tp = sysh.fock_profile_tiers(dD.data_ptr(), dG.data_ptr(), reps)
+    prof = sysh.fock_profile(dD.data_ptr(), dG.data_ptr(), max(1, reps // 2))
+    k = int(tp["unit_ms"].argmax())
+    ms = float(tp["unit_ms"][k])
+    gbs = float(tp["bytes"][k]) / (ms * 1e-3) / 1e9
+    tfs = float(tp["flops"][k]) / (ms * 1e-3) / 1e12
     ws = sysh.work_stats()
-    order = prof["class_ms"].argsort()[::-1][:10]
     cname = lambda c: "<%d, %d, %d>" % (int(c) >> 8, (int(c) >> 4) & 15, int(c) & 15)
+    order = prof["class_ms"].argsort()[::-1][:10]
     top = [{"class": cname(prof["class_id"][i]), "ms": float(prof["class_ms"][i]),
             "quartets": int(prof["quartets"][i]), "GF": float(prof["flops"][i]) / 1e9} for i in order]
-    tot_ms = float(prof["total_ms"])
-    sum_ms = float(prof["class_ms"].sum())
+    tiers = [{"kernel": "qc_fock_tier_kernel<%d, %d>" % (u // 2, u % 2), "ms": float(tp["unit_ms"][u]), "quartets": int(tp["quartets"][u]),
+              "alg_MB": float(tp["bytes"][u]) / 1e6, "alg_GF": float(tp["flops"][u]) / 1e9} for u in range(14) if tp["quartets"][u] > 0]
+    tot_ms = float(tp["total_ms"])
     return {
         "bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS, "traffic": None,
-        "kernel": "qc_fock_class_kernel" + cname(cid), "kernel_ms": ms,
-        "kernel_quartets": int(prof["quartets"][k]), "kernel_alg_bytes": float(prof["bytes"][k]),
-        "kernel_alg_flops": float(prof["flops"][k]),
+        "kernel": "qc_fock_tier_kernel<%d, %d>" % (k // 2, k % 2), "kernel_ms": ms,
+        "kernel_quartets": int(tp["quartets"][k]), "kernel_alg_bytes": float(tp["bytes"][k]), "kernel_alg_flops": float(tp["flops"][k]),
         "note": "f64 gather-compute-scatter on the FP64 ridge (SURVEY 8d): both roofs are given; the binding one is fp64_valu",
         "fp64_valu": {"achieved": tfs, "peak": FP64_VALU_PEAK_TF, "unit": "TFLOP/s", "frac": tfs / FP64_VALU_PEAK_TF},
-        "fock_build": {"ms": tot_ms, "sum_class_kernels_ms": sum_ms, "launches": int(ws.nclasses),
+        "fock_build": {"ms": tot_ms, "sum_tier_kernels_serial_ms": float(tp["unit_ms"].sum()), "launches": len(tiers),
                        "alg_bytes": float(ws.bytes_alg), "alg_flops": float(ws.flops_alg),
                        "achieved_GBs": float(ws.bytes_alg) / (tot_ms * 1e-3) / 1e9,
                        "achieved_TFLOPs": float(ws.flops_alg) / (tot_ms * 1e-3) / 1e12,
-                       "quartets_per_s": float(ws.quartets) / (tot_ms * 1e-3), "top_classes_serial": top},
+                       "quartets_per_s": float(ws.quartets) / (tot_ms * 1e-3), "tiers_serial": tiers, "top_classes_serial": top},
     }
 
 

@@ -154,6 +154,11 @@ int qc_work_stats_get(qc_system *sys, qc_work_stats *out);
 int qc_fock_profile(qc_system *sys, const double *dD, double *dG, int reps, float *class_ms, int32_t *class_id,
                     int64_t *class_quartets, double *class_bytes, double *class_flops, float *total_ms);
 
+/* Same for the launch units of an un-instrumented build: kernel qc_fock_tier_kernel<LAB, TIER> gathers every class
+ * bucket of bra class LAB with LCD <= 3 (TIER 0) or LCD >= 4 (TIER 1).  All arrays: 14 entries, unit = 2 * LAB + TIER. */
+int qc_fock_profile_tiers(qc_system *sys, const double *dD, double *dG, int reps, float *unit_ms, int64_t *unit_quartets,
+                          double *unit_bytes, double *unit_flops, float *total_ms);
+
 #ifdef __cplusplus
 }
 #endif

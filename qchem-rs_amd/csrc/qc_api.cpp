@@ -671,4 +671,48 @@ int qc_fock_profile(qc_system *S, const double *dD, double *dG, int reps, float 
     return QC_OK;
 }
 
+// Per launch unit ("tier" = (LAB, LCD <= 3 | LCD >= 4), the kernels an un-instrumented build really launches), timed
+// serially with hipEvents on the handle's stream.  Arrays have 14 entries, unit u = 2 * LAB + tier; empty units are 0.
+int qc_fock_profile_tiers(qc_system *S, const double *dD, double *dG, int reps, float *unit_ms, int64_t *unit_quartets,
+                          double *unit_bytes, double *unit_flops, float *total_ms) {
+    if (!S || !dD || !dG || reps <= 0 || !unit_ms) return QC_ERR_INVALID;
+    int rc = qc_device_init(S);
+    if (rc != QC_OK) return rc;
+    const size_t nn = (size_t)S->nbasis * S->nbasis;
+    const int NU = 2 * (QC_LPAIR + 1);
+    std::vector<float> acc(NU, 0.f), one(NU, 0.f);
+    float tot = 0.f;
+    hipEvent_t e0, e1;
+    QC_HIP_CHECK(hipEventCreate(&e0)); QC_HIP_CHECK(hipEventCreate(&e1));
+    for (int r = 0; r < reps; ++r) {
+        QC_HIP_CHECK(hipMemsetAsync(S->d_Gtmp, 0, (size_t)QC_NREP * nn * sizeof(double), S->stream));
+        QcFockArgs a{};
+        a.nrep = QC_NREP; a.rep_stride = nn;
+        a.Dj = dD; a.Dk0 = dD; a.Dk1 = nullptr; a.cK = 0.5; a.G0 = S->d_Gtmp; a.G1 = S->d_Gtmp + nn;
+        if ((rc = qc_launch_fock_classes(S, a, nullptr, one.data())) != QC_OK) return rc;
+        for (int i = 0; i < NU; ++i) acc[i] += one[i];
+        QC_HIP_CHECK(hipEventRecord(e0, S->stream));
+        if ((rc = qc_fock_build_device(S, dD, nullptr, dG, nullptr, false)) != QC_OK) return rc;
+        QC_HIP_CHECK(hipEventRecord(e1, S->stream));
+        QC_HIP_CHECK(hipEventSynchronize(e1));
+        float ms; (void)hipEventElapsedTime(&ms, e0, e1); tot += ms;
+    }
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    for (int u = 0; u < NU; ++u) {
+        unit_ms[u] = acc[u] / reps;
+        if (unit_quartets) unit_quartets[u] = 0;
+        if (unit_bytes) unit_bytes[u] = 0;
+        if (unit_flops) unit_flops[u] = 0;
+    }
+    for (const auto &c : S->classes) {
+        if (c.shard.empty()) continue;
+        const int u = 2 * c.LAB + (c.LCD >= 4 ? 1 : 0);
+        if (unit_quartets) unit_quartets[u] += (int64_t)c.shard.size();
+        if (unit_bytes) unit_bytes[u] += c.bytes_alg;
+        if (unit_flops) unit_flops[u] += c.flops_alg;
+    }
+    if (total_ms) *total_ms = tot / reps;
+    return QC_OK;
+}
+
 }  // extern "C"

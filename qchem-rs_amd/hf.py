@@ -41,7 +41,7 @@ EXPORTS = ["qc_system_create", "qc_system_destroy", "qc_nbasis", "qc_nelectrons"
            "qc_fock_rhf_device", "qc_fock_uhf_device", "qc_sym_eig", "qc_scf_rhf", "qc_scf_uhf", "qc_comm_unique_id",
            "qc_comm_init", "qc_set_shard", "qc_plan_shard", "qc_set_stream", "qc_device_ready", "qc_work_stats_get",
            "qc_fock_profile", "qc_plan_shard_quartets", "qc_scf_begin_rhf", "qc_scf_begin_uhf", "qc_scf_iterate",
-           "qc_scf_orbital_energies", "qc_scf_density", "qc_scf_timings", "qc_scf_end"]
+           "qc_scf_orbital_energies", "qc_scf_density", "qc_scf_timings", "qc_scf_end", "qc_fock_profile_tiers"]
 
 
 class QcError(RuntimeError):
@@ -112,6 +112,7 @@ def lib():
         L.qc_device_ready.argtypes = []
         L.qc_work_stats_get.argtypes = [vp, C.POINTER(WorkStats)]
         L.qc_fock_profile.argtypes = [vp, vp, vp, C.c_int, vp, vp, vp, vp, vp, vp]
+        L.qc_fock_profile_tiers.argtypes = [vp, vp, vp, C.c_int, vp, vp, vp, vp, vp]
         L.qc_scf_begin_rhf.argtypes = [vp, C.POINTER(vp)]
         L.qc_scf_begin_uhf.argtypes = [vp, C.c_int, C.c_int, C.POINTER(vp)]
         L.qc_scf_iterate.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_double)]
@@ -215,6 +216,17 @@ class System:
         _check(lib().qc_fock_profile(self._h, C.c_void_p(dD_ptr), C.c_void_p(dG_ptr), reps, p(ms), p(cid), p(nq), p(by), p(fl),
                                      C.cast(C.byref(tot), C.c_void_p)), "qc_fock_profile")
         return dict(class_ms=ms, class_id=cid, quartets=nq, bytes=by, flops=fl, total_ms=tot.value)
+
+
+def _fock_profile_tiers(self, dD_ptr: int, dG_ptr: int, reps: int):
+    ms = np.zeros(14, np.float32); nq = np.zeros(14, np.int64); by = np.zeros(14); fl = np.zeros(14); tot = C.c_float()
+    p = lambda a: a.ctypes.data_as(C.c_void_p)
+    _check(lib().qc_fock_profile_tiers(self._h, C.c_void_p(dD_ptr), C.c_void_p(dG_ptr), reps, p(ms), p(nq), p(by), p(fl),
+                                       C.cast(C.byref(tot), C.c_void_p)), "qc_fock_profile_tiers")
+    return dict(unit_ms=ms, quartets=nq, bytes=by, flops=fl, total_ms=tot.value)
+
+
+System.fock_profile_tiers = _fock_profile_tiers
 
 
 class ScfStepper:
