@@ -48,6 +48,7 @@ void qc_drop_graphs(qc_system *S) {
 
 int qc_device_reshard(qc_system *S) {
     qc_drop_graphs(S);
+    S->unit_ms.clear(); S->unit_stream.clear();
     qc_build_shards(S);
     if (!S->device_ready) return QC_OK;
     return upload_slots(S);
@@ -194,18 +195,42 @@ int qc_launch_fock_classes(qc_system *S, const QcFockArgs &fa, float *class_ms, 
         for (auto &e : ev) (void)hipEventDestroy(e);
         return QC_OK;
     }
+    // Launch units are independent; they go to QC_NSTREAMS side streams (one hardware queue each next to the main
+    // stream's, GPU_MAX_HW_QUEUES=8).  Kernels on one stream run in order, so the assignment matters: the first build
+    // of a handle times every unit alone (density-independent), then units are placed longest-first on the least
+    // loaded stream.
+    if (S->unit_ms.size() != units.size()) {
+        S->unit_ms.assign(units.size(), 0.f);
+        int rc = qc_launch_fock_classes(S, fa, nullptr, S->unit_ms.data());     // serial, timed (results discarded by caller's memset)
+        if (rc != QC_OK) return rc;
+        if (fa.G0) QC_HIP_CHECK(hipMemsetAsync(fa.G0, 0, (size_t)a.nrep * a.rep_stride * sizeof(double), S->stream));
+        std::vector<int> order;
+        for (size_t u = 0; u < units.size(); ++u) if (!units[u].empty()) order.push_back((int)u);
+        std::stable_sort(order.begin(), order.end(), [&](int x, int y) { return S->unit_ms[x] > S->unit_ms[y]; });
+        std::vector<float> load(QC_NSTREAMS, 0.f);
+        S->unit_stream.assign(units.size(), 0);
+        for (int u : order) {
+            const int k = (int)(std::min_element(load.begin(), load.end()) - load.begin());
+            S->unit_stream[u] = k;
+            load[k] += S->unit_ms[u];
+        }
+    }
     QC_HIP_CHECK(hipEventRecord(S->ev_fork, S->stream));
-    // heavy tiers (high LAB, tier 1) first
-    int k = 0;
-    for (int u = (int)units.size() - 1; u >= 0; --u) {
-        if (units[u].empty()) continue;
-        hipStream_t st = S->side[k % QC_NSTREAMS];
-        QC_HIP_CHECK(hipStreamWaitEvent(st, S->ev_fork, 0));
+    std::vector<int> order;
+    for (size_t u = 0; u < units.size(); ++u) if (!units[u].empty()) order.push_back((int)u);
+    std::stable_sort(order.begin(), order.end(), [&](int x, int y) { return S->unit_ms[x] > S->unit_ms[y]; });
+    bool used[QC_NSTREAMS] = {};
+    for (int u : order) {
+        const int k = S->unit_stream[u];
+        hipStream_t st = S->side[k];
+        if (!used[k]) { QC_HIP_CHECK(hipStreamWaitEvent(st, S->ev_fork, 0)); used[k] = true; }
         int rc = launch_segments(u / 2, u % 2, segs_of(units[u]), st, a);
         if (rc != QC_OK) return rc;
-        QC_HIP_CHECK(hipEventRecord(S->ev_join[k % QC_NSTREAMS], st));
-        QC_HIP_CHECK(hipStreamWaitEvent(S->stream, S->ev_join[k % QC_NSTREAMS], 0));
-        ++k;
+    }
+    for (int k = 0; k < QC_NSTREAMS; ++k) {
+        if (!used[k]) continue;
+        QC_HIP_CHECK(hipEventRecord(S->ev_join[k], S->side[k]));
+        QC_HIP_CHECK(hipStreamWaitEvent(S->stream, S->ev_join[k], 0));
     }
     return QC_OK;
 }

@@ -410,6 +410,9 @@ struct QcTierArgs {
 
 template <int LAB, int TIER>
 __global__ __launch_bounds__(64) void qc_fock_tier_kernel(const QcTierArgs a) {
+    // the high-L tiers are few, long, latency-bound waves: let them win issue arbitration against the many short
+    // low-L waves they share a SIMD with
+    if constexpr (TIER == 1) __builtin_amdgcn_s_setprio(3);
     int s = 0;
     while (s + 1 < a.nseg && (int)blockIdx.x >= a.seg_end[s]) ++s;
     const int b0 = s ? a.seg_end[s - 1] : 0;

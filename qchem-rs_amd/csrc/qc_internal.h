@@ -23,7 +23,7 @@ __host__ __device__ constexpr int qc_region0(int L, int lgc) {
 }
       // primitive quartets per slot
 constexpr int QC_NREP = 32;             // replicas of the Fock accumulation buffer
-constexpr int QC_NSTREAMS = 16;         // class kernels of one build run concurrently on this many streams
+constexpr int QC_NSTREAMS = 7;          // class kernels of one build run concurrently on this many streams
 
 __host__ __device__ constexpr int qc_nherm(int L) { return (L + 1) * (L + 2) * (L + 3) / 6; }
 __host__ __device__ constexpr int qc_ncart(int L) { return (L + 1) * (L + 2) / 2; }
@@ -99,6 +99,8 @@ struct qc_system {
     // captured Fock builds (memset + class kernels on the side streams + replica fold), keyed by operand pointers
     struct FockGraph { const double *Da, *Db; int mode; hipGraphExec_t exec; };
     std::vector<FockGraph> graphs;
+    std::vector<float> unit_ms;              // measured serial time of each launch unit (autotuned once per shard)
+    std::vector<int> unit_stream;            // side stream of each launch unit (longest-processing-time assignment)
     bool use_graphs = false;                 // hipGraph replay of the build measured slower than eager multi-stream launches on ROCm 7.2
     std::string last_error;
 };

@@ -293,7 +293,8 @@ int qc_eig_device(hipStream_t st, int n, double *dA, double *dV, double *dw, dou
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return QC_ERR_HIP;
     }
-    hipLaunchKernelGGL(kern, dim3(1), dim3(QC_EIG_THREADS), lds, st, n, dA, d_work, dV, dw, 40);
+    static const int nthreads = getenv("QC_EIG_THREADS") ? atoi(getenv("QC_EIG_THREADS")) : QC_EIG_THREADS;
+    hipLaunchKernelGGL(kern, dim3(1), dim3(nthreads), lds, st, n, dA, d_work, dV, dw, 40);
     return hipGetLastError() == hipSuccess ? QC_OK : QC_ERR_HIP;
 }
 
