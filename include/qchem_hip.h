@@ -85,6 +85,10 @@ int qc_fock_uhf_device(qc_system *sys, const double *dDa, const double *dDb, dou
 /* ---- symmetric eigensolver: replaces utils::sorted_eigs (hf/utils.rs:20-36).  GPU.  A: n*n symmetric;
  * V: eigenvectors as columns (V[i*n+k] = component i of vector k); w ascending. */
 int qc_sym_eig(qc_system *sys, int n, const double *A, double *V, double *w);
+/* Same, started from the eigenvectors V0 of a nearby matrix (the SCF loop's case from its second pass on): GEMM-based
+ * eigenvector refinement with a Jacobi fallback.  Result identical to qc_sym_eig up to rounding and rotations inside
+ * degenerate subspaces. */
+int qc_sym_eig_warm(qc_system *sys, int n, const double *A, const double *V0, double *V, double *w);
 
 /* ---- SCF drivers: replace restricted_hartree_fock (rhf.rs:32-108) / unrestricted_hartree_fock (uhf.rs:36-167). */
 typedef struct {

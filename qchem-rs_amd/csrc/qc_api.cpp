@@ -110,14 +110,14 @@ struct DeviceDiis {
 
 struct ScfWork {
     int n;
-    DevBuf H, S, X, t1, t2, Fp, Cp, C, w, ework, Fd, scal, CpPrev[2];
+    DevBuf H, S, X, t1, t2, t3, t4, Fp, Cp, C, w, ework, Fd, scal, small, CpPrev[2];
     bool have_prev[2] = {false, false};
     int init(int n_) {
         n = n_;
         const size_t nn = (size_t)n * n;
-        DevBuf *all[] = {&H, &S, &X, &t1, &t2, &Fp, &Cp, &C, &ework, &Fd, &CpPrev[0], &CpPrev[1]};
+        DevBuf *all[] = {&H, &S, &X, &t1, &t2, &t3, &t4, &Fp, &Cp, &C, &ework, &Fd, &CpPrev[0], &CpPrev[1]};
         for (auto b : all) if (b->alloc(nn) != QC_OK) return QC_ERR_HIP;
-        if (w.alloc(n) != QC_OK || scal.alloc(16) != QC_OK) return QC_ERR_HIP;
+        if (w.alloc(n) != QC_OK || scal.alloc(16) != QC_OK || small.alloc(2 * n + 16) != QC_OK) return QC_ERR_HIP;
         return QC_OK;
     }
 };
@@ -182,7 +182,7 @@ int roothaan_step(qc_system *S, ScfWork &W, DeviceDiis &diis, const double *dG, 
     qc_gemm(st, n, n, n, 1.0, W.Fd.p, n, false, W.X.p, n, false, 0.0, W.t1.p, n);        // F X
     qc_gemm(st, n, n, n, 1.0, W.X.p, n, true, W.t1.p, n, false, 0.0, W.Fp.p, n);         // X^T (F X)
     // sorted_eigs (rhf.rs:75), warm-started from this spin's previous eigenvectors once they exist
-    if (W.have_prev[spin]) rc = qc_eig_device_warm(st, n, W.Fp.p, W.CpPrev[spin].p, W.Cp.p, dw_out, W.ework.p, W.t1.p, W.t2.p);
+    if (W.have_prev[spin]) rc = qc_eig_device_refine(st, n, W.Fp.p, W.CpPrev[spin].p, W.Cp.p, dw_out, W.ework.p, W.t1.p, W.t2.p, W.t3.p, W.t4.p, W.small.p);
     else rc = device_sorted_eigs(S, W, W.Fp.p, W.Cp.p, dw_out);
     if (rc != QC_OK) return rc;
     QC_HIP_CHECK(hipMemcpyAsync(W.CpPrev[spin].p, W.Cp.p, sizeof(double) * n * n, hipMemcpyDeviceToDevice, st));
@@ -553,6 +553,26 @@ int qc_scf_timings(qc_scf_state *st, double *ms_setup, double *ms_fock, double *
     return QC_OK;
 }
 void qc_scf_end(qc_scf_state *st) { delete st; }
+
+// sorted_eigs with a starting guess: V0 = eigenvectors of a nearby matrix (what the SCF loop uses from its second pass on)
+int qc_sym_eig_warm(qc_system *S, int n, const double *A, const double *V0, double *V, double *w) {
+    if (!S || n <= 0 || !A || !V0 || !V || !w) return QC_ERR_INVALID;
+    int rc = qc_device_init(S);
+    if (rc != QC_OK) return rc;
+    const size_t nn = (size_t)n * n;
+    DevBuf dA, dV0, dV, dw, wk, t1, t2, t3, t4, sm;
+    DevBuf *all[] = {&dA, &dV0, &dV, &wk, &t1, &t2, &t3, &t4};
+    for (auto b : all) if (b->alloc(nn) != QC_OK) return QC_ERR_HIP;
+    if (dw.alloc(n) != QC_OK || sm.alloc(2 * n + 16) != QC_OK) return QC_ERR_HIP;
+    QC_HIP_CHECK(hipMemcpyAsync(dA.p, A, nn * sizeof(double), hipMemcpyHostToDevice, S->stream));
+    QC_HIP_CHECK(hipMemcpyAsync(dV0.p, V0, nn * sizeof(double), hipMemcpyHostToDevice, S->stream));
+    rc = qc_eig_device_refine(S->stream, n, dA.p, dV0.p, dV.p, dw.p, wk.p, t1.p, t2.p, t3.p, t4.p, sm.p);
+    if (rc != QC_OK) return rc;
+    QC_HIP_CHECK(hipMemcpyAsync(V, dV.p, nn * sizeof(double), hipMemcpyDeviceToHost, S->stream));
+    QC_HIP_CHECK(hipMemcpyAsync(w, dw.p, n * sizeof(double), hipMemcpyDeviceToHost, S->stream));
+    QC_HIP_CHECK(hipStreamSynchronize(S->stream));
+    return QC_OK;
+}
 
 // restricted_hartree_fock (rhf.rs:32-108) / unrestricted_hartree_fock (uhf.rs:36-167)
 int qc_scf_rhf(qc_system *S, const qc_hf_config *cfg, qc_hf_output *out) { return scf_run(S, cfg, out, false); }

@@ -141,6 +141,8 @@ void qc_gemm(hipStream_t st, int m, int n, int k, double alpha, const double *A,
              int ldb, bool tb, double beta, double *C, int ldc);
 int qc_eig_device(hipStream_t st, int n, double *dA /*destroyed*/, double *dV, double *dw, double *d_work);
 int qc_eig_device_warm(hipStream_t st, int n, double *dA, const double *dV0, double *dV, double *dw, double *d_work, double *t1, double *t2);
+int qc_eig_device_refine(hipStream_t st, int n, double *dA, const double *dV0, double *dV, double *dw, double *d_work, double *t1, double *t2,
+                         double *t3, double *t4, double *small);
 void qc_axpby(hipStream_t st, int n, double a, const double *x, double b, const double *y, double *out);
 void qc_sub_transpose(hipStream_t st, int n, const double *M, double *out);              // out = M - M^T
 void qc_symmetrize_add(hipStream_t st, int n, const double *Gt, double *G);              // G = Gt + Gt^T

@@ -5,6 +5,7 @@
 // SymmetricEigen behind utils::sorted_eigs (hf/utils.rs:20-36), the Frobenius dots of diis.rs:43-45 and the
 // trace / diagonal-rms at rhf.rs:84-88.
 #include <cstdlib>
+#include <vector>
 
 #include "qc_internal.h"
 
@@ -308,6 +309,197 @@ int qc_eig_device_warm(hipStream_t st, int n, double *dA, const double *dV0, dou
     if (rc != QC_OK) return rc;
     qc_gemm(st, n, n, n, 1.0, dV0, n, false, t1, n, false, 0.0, dV, n);        // V = V0 Q
     return QC_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Eigenvector refinement (Ogita & Aishima, Japan J. Indust. Appl. Math. 35 (2018) 1007): with X an approximate
+// eigenvector matrix of symmetric A,  R = I - X^T X,  S = X^T A X,  lam_i = S_ii / (1 - R_ii),
+//   E_ij = (S_ij + lam_j R_ij) / (lam_j - lam_i)   (|lam_i - lam_j| > delta),   E_ij = R_ij / 2   (otherwise, and i = j),
+//   X <- X (I + E)   converges quadratically.  Everything O(n^3) is an f64 MFMA GEMM - this is where the matrix cores
+// earn their keep in the SCF loop, whose Fock matrix moves little between iterations once DIIS has kicked in.
+// Pair (i,j) classes, with  a_ij = S_ij + (lam_i + lam_j)/2 R_ij  (coupling),  g = |lam_j - lam_i|,  scale = max|lam|:
+//   negligible : |a_ij| <= 1e-13 scale                       -> E_ij = R_ij / 2        (orthogonality only)
+//   strong     : |a_ij| / max(g, 1e-8 scale) > 1e-3          -> exact 2x2 Jacobi rotation, provided every index has at
+//                most one strong partner (near-degenerate pairs: their eigenvectors turn by finite angles under tiny
+//                changes of A; the first-order formula would need many passes); otherwise the caller goes to Jacobi
+//   degenerate : g <= 1e-8 scale, weak coupling              -> E_ij = R_ij / 2, coupling recorded in stats[4]
+//   regular    :                                             -> E_ij = (S_ij + lam_j R_ij) / (lam_j - lam_i)
+// stats: [0] ||offdiag(S)||_F  [1] ||R||_F  [2] scale  [3] #strong pairs  [4] max coupling left in degenerate pairs
+//        [5] max |a_ij| / g over regular pairs (size of the first-order update)  [6] 1 if some index has > 1 strong partner
+constexpr double QC_REF_TAU = 1e-3, QC_REF_TINY = 1e-13, QC_REF_GFLOOR = 1e-8;
+
+__global__ __launch_bounds__(1024) void qc_refine_stats_kernel(int n, const double *__restrict__ S, const double *__restrict__ XtX,
+                                                                double *__restrict__ lam, double *__restrict__ stats, int *__restrict__ partner) {
+    __shared__ double red[4 * 16];
+    __shared__ double sh_scale;
+    __shared__ int sh_multi, sh_nstrong;
+    const int tid = threadIdx.x;
+    double off = 0.0, rr = 0.0, amax = 0.0;
+    for (int x = tid; x < n * n; x += 1024) {
+        const int i = x / n, j = x - i * n;
+        const double r = (i == j ? 1.0 : 0.0) - XtX[x];
+        rr = fma(r, r, rr);
+        if (i != j) off = fma(S[x], S[x], off);
+        else { const double l = S[x] / (1.0 - r); lam[i] = l; amax = fmax(amax, fabs(l)); }
+    }
+    for (int o = 32; o > 0; o >>= 1) { off += __shfl_down(off, o, 64); rr += __shfl_down(rr, o, 64); amax = fmax(amax, __shfl_down(amax, o, 64)); }
+    if ((tid & 63) == 0) { red[tid >> 6] = off; red[16 + (tid >> 6)] = rr; red[32 + (tid >> 6)] = amax; }
+    if (tid == 0) { sh_multi = 0; sh_nstrong = 0; }
+    __syncthreads();
+    if (tid == 0) {
+        double a = 0.0, b = 0.0, c = 0.0;
+        for (int k = 0; k < 16; ++k) { a += red[k]; b += red[16 + k]; c = fmax(c, red[32 + k]); }
+        stats[0] = sqrt(a); stats[1] = sqrt(b); stats[2] = c;
+        sh_scale = c;
+    }
+    __syncthreads();                                         // lam[] (global, written by this workgroup) is visible
+    const double scale = sh_scale, tiny = QC_REF_TINY * scale, gfloor = QC_REF_GFLOOR * scale;
+    double cmax = 0.0, emax = 0.0;
+    for (int i = tid; i < n; i += 1024) {                    // one row per thread
+        int cnt = 0, who = -1;
+        for (int j = 0; j < n; ++j) {
+            if (j == i) continue;
+            const double r = -XtX[(size_t)i * n + j];
+            const double sij = 0.5 * (S[(size_t)i * n + j] + S[(size_t)j * n + i]);   // A is symmetric only to rounding
+            const double a = fabs(sij + 0.5 * (lam[i] + lam[j]) * r), g = fabs(lam[j] - lam[i]);
+            if (a <= tiny) continue;
+            if (a > QC_REF_TAU * fmax(g, gfloor)) { ++cnt; who = j; }
+            else if (g <= gfloor) cmax = fmax(cmax, a);
+            else emax = fmax(emax, a / g);
+        }
+        partner[i] = cnt == 0 ? -1 : (cnt == 1 ? who : -2);
+        if (cnt > 1) sh_multi = 1;
+        if (cnt == 1) atomicAdd(&sh_nstrong, 1);
+    }
+    for (int o = 32; o > 0; o >>= 1) { cmax = fmax(cmax, __shfl_down(cmax, o, 64)); emax = fmax(emax, __shfl_down(emax, o, 64)); }
+    __syncthreads();
+    if ((tid & 63) == 0) { red[tid >> 6] = cmax; red[16 + (tid >> 6)] = emax; }
+    __syncthreads();
+    if (tid == 0) {
+        double a = 0.0, b = 0.0;
+        for (int k = 0; k < 16; ++k) { a = fmax(a, red[k]); b = fmax(b, red[16 + k]); }
+        // a strong pair must be mutual (i's only strong partner is j and vice versa)
+        int multi = sh_multi;
+        for (int i = 0; i < n && !multi; ++i) if (partner[i] >= 0 && partner[partner[i]] != i) multi = 1;
+        stats[3] = 0.5 * sh_nstrong; stats[4] = a; stats[5] = b; stats[6] = multi;
+    }
+}
+
+// M = I + E with exact rotations on the strong pairs
+__global__ void qc_refine_update_kernel(int n, const double *__restrict__ S, const double *__restrict__ XtX, const double *__restrict__ lam,
+                                        const double *__restrict__ stats, const int *__restrict__ partner, double *__restrict__ M) {
+    const double scale = stats[2], tiny = QC_REF_TINY * scale, gfloor = QC_REF_GFLOOR * scale;
+    for (int x = blockIdx.x * blockDim.x + threadIdx.x; x < n * n; x += gridDim.x * blockDim.x) {
+        const int i = x / n, j = x - i * n;
+        const double r = (i == j ? 1.0 : 0.0) - XtX[x];
+        double m;
+        if (i == j) {
+            m = 1.0 + 0.5 * r;
+            const int pj = partner[i];
+            if (pj >= 0) {                                   // cosine of this index's rotation
+                const double a = 0.5 * (S[(size_t)i * n + pj] + S[(size_t)pj * n + i]) - 0.5 * (lam[i] + lam[pj]) * XtX[(size_t)i * n + pj];
+                const double theta = (lam[pj] - lam[i]) / (2.0 * a);
+                const double t = (theta >= 0.0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(fma(theta, theta, 1.0)));
+                m = 1.0 / sqrt(fma(t, t, 1.0)) + 0.5 * r;
+            }
+        } else {
+            const double sij = 0.5 * (S[x] + S[(size_t)j * n + i]);      // A is symmetric only to rounding: use the symmetric part
+            const double a = sij + 0.5 * (lam[i] + lam[j]) * r, g = lam[j] - lam[i];
+            if (partner[i] == j) {                           // sine: x_j' = c x_j + s x_i
+                const double theta = g / (2.0 * a);
+                const double t = (theta >= 0.0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(fma(theta, theta, 1.0)));
+                m = t / sqrt(fma(t, t, 1.0));
+            } else if (fabs(a) <= tiny || fabs(g) <= gfloor) m = 0.5 * r;
+            else m = (sij + lam[j] * r) / g;
+        }
+        M[x] = m;
+    }
+}
+
+// ascending eigenvalues + columns permuted alongside (utils.rs:28)
+__global__ __launch_bounds__(1024) void qc_sort_columns_kernel(int n, const double *__restrict__ lam, const double *__restrict__ X,
+                                                                double *__restrict__ w, double *__restrict__ Xs) {
+    extern __shared__ int rank_s[];
+    const int tid = threadIdx.x;
+    for (int i = tid; i < n; i += 1024) {
+        const double wi = lam[i];
+        int r = 0;
+        for (int j = 0; j < n; ++j) r += (lam[j] < wi || (lam[j] == wi && j < i)) ? 1 : 0;
+        rank_s[i] = r;
+        w[r] = wi;
+    }
+    __syncthreads();
+    for (int x = tid; x < n * n; x += 1024) {
+        const int i = x / n, j = x - i * n;
+        Xs[(size_t)i * n + rank_s[j]] = X[x];
+    }
+}
+
+// Eigen-decomposition of dA starting from the eigenvectors dV0 of a nearby matrix.
+//   pass: S = X^T A X, X^T X, stats -> host (one small sync).
+//     * update size max|E| > 0.1 (not perturbative), orthogonality lost, or passes exhausted -> Jacobi kernel on S
+//       (nearly diagonal => few sweeps), V = X Q;
+//     * max|E| <= 1e-7: one more update leaves ~1e-14 (quadratic) - unless a cluster still carries coupling, which only
+//       rotations can remove -> Jacobi on S;
+//     * otherwise apply X <- X (I + E) and take another pass.
+// Scratch: t1..t4, d_work (n*n each), small (n + 8 doubles).
+int qc_eig_device_refine(hipStream_t st, int n, double *dA, const double *dV0, double *dV, double *dw, double *d_work, double *t1, double *t2,
+                         double *t3, double *t4, double *small) {
+    const size_t nn = (size_t)n * n;
+    double *lam = small, *stats = small + n;
+    double *X = t4;                                            // current eigenvector estimate
+    if (hipMemcpyAsync(X, dV0, nn * sizeof(double), hipMemcpyDeviceToDevice, st) != hipSuccess) return QC_ERR_HIP;
+    double hs[8];
+    int *partner = reinterpret_cast<int *>(small + n + 8);
+    if (const char *dump = getenv("QC_EIG_DUMP")) {           // debugging aid: append (n, A, V0) of every call to a file
+        static int ncall = 0;
+        std::vector<double> h(2 * nn);
+        (void)hipMemcpy(h.data(), dA, nn * sizeof(double), hipMemcpyDeviceToHost);
+        (void)hipMemcpy(h.data() + nn, dV0, nn * sizeof(double), hipMemcpyDeviceToHost);
+        if (FILE *f = fopen(dump, ncall++ ? "ab" : "wb")) { double dn = n; fwrite(&dn, 8, 1, f); fwrite(h.data(), 8, 2 * nn, f); fclose(f); }
+    }
+    constexpr int MAXPASS = 5;
+    static const bool dbg = getenv("QC_EIG_DEBUG") != nullptr;
+    for (int pass = 0; pass < MAXPASS; ++pass) {
+        qc_gemm(st, n, n, n, 1.0, dA, n, false, X, n, false, 0.0, t1, n);          // A X
+        qc_gemm(st, n, n, n, 1.0, X, n, true, t1, n, false, 0.0, t2, n);           // S = X^T A X
+        qc_gemm(st, n, n, n, 1.0, X, n, true, X, n, false, 0.0, t3, n);            // X^T X
+        hipLaunchKernelGGL(qc_refine_stats_kernel, dim3(1), dim3(1024), 0, st, n, t2, t3, lam, stats, partner);
+        if (hipMemcpyAsync(hs, stats, 7 * sizeof(double), hipMemcpyDeviceToHost, st) != hipSuccess) return QC_ERR_HIP;
+        if (hipStreamSynchronize(st) != hipSuccess) return QC_ERR_HIP;
+        const double scale = fmax(hs[2], 1e-300), orth = hs[1], nstrong = hs[3], cmax = hs[4], emax = hs[5], multi = hs[6];
+        if (dbg) fprintf(stderr, "[eig n=%d pass %d] off %.2e orth %.2e scale %.1f strong %.0f multi %.0f cmax %.2e emax %.2e\n", n, pass, hs[0], orth, scale, nstrong, multi, cmax, emax);
+        if (!(emax <= 0.1) || !(orth <= 1e-3) || multi != 0.0 || pass == MAXPASS - 1) {
+            // not perturbative (or not converging): rotations.  Always from the orthonormal start V0.
+            if (pass > 0) {
+                qc_gemm(st, n, n, n, 1.0, dA, n, false, dV0, n, false, 0.0, t1, n);
+                qc_gemm(st, n, n, n, 1.0, dV0, n, true, t1, n, false, 0.0, t2, n);
+            }
+            int rc = qc_eig_device(st, n, t2, t1, dw, d_work);                     // Q -> t1 (sorted), eigenvalues -> dw
+            if (rc != QC_OK) return rc;
+            qc_gemm(st, n, n, n, 1.0, dV0, n, false, t1, n, false, 0.0, dV, n);    // V = V0 Q
+            return QC_OK;
+        }
+        const bool last = emax <= 1e-7 && orth <= 1e-7 && nstrong == 0.0;
+        hipLaunchKernelGGL(qc_refine_update_kernel, dim3((unsigned)((nn + 255) / 256)), dim3(256), 0, st, n, t2, t3, lam, stats, partner, t1);
+        qc_gemm(st, n, n, n, 1.0, X, n, false, t1, n, false, 0.0, d_work, n);      // X (I + E): error now ~ emax^2
+        if (last && cmax <= 1e-12 * scale) {   // lam is second-order accurate already; d_work holds the final vectors
+            hipLaunchKernelGGL(qc_sort_columns_kernel, dim3(1), dim3(1024), n * sizeof(int), st, n, lam, d_work, dw, dV);
+            return hipGetLastError() == hipSuccess ? QC_OK : QC_ERR_HIP;
+        }
+        if (hipMemcpyAsync(X, d_work, nn * sizeof(double), hipMemcpyDeviceToDevice, st) != hipSuccess) return QC_ERR_HIP;
+        if (last) {
+            // converged except for coupling left inside degenerate pairs, which only rotations remove:
+            // X is orthonormal to ~1e-14 now, so Jacobi on X^T A X (a handful of non-trivial rotations) finishes the job
+            qc_gemm(st, n, n, n, 1.0, dA, n, false, X, n, false, 0.0, t1, n);
+            qc_gemm(st, n, n, n, 1.0, X, n, true, t1, n, false, 0.0, t2, n);
+            int rc = qc_eig_device(st, n, t2, t1, dw, d_work);
+            if (rc != QC_OK) return rc;
+            qc_gemm(st, n, n, n, 1.0, X, n, false, t1, n, false, 0.0, dV, n);
+            return QC_OK;
+        }
+    }
+    return QC_ERR_HIP;   // not reached
 }
 
 // ---------------------------------------------------------------------------------------------------------------

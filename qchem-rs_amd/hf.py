@@ -41,7 +41,7 @@ EXPORTS = ["qc_system_create", "qc_system_destroy", "qc_nbasis", "qc_nelectrons"
            "qc_fock_rhf_device", "qc_fock_uhf_device", "qc_sym_eig", "qc_scf_rhf", "qc_scf_uhf", "qc_comm_unique_id",
            "qc_comm_init", "qc_set_shard", "qc_plan_shard", "qc_set_stream", "qc_device_ready", "qc_work_stats_get",
            "qc_fock_profile", "qc_plan_shard_quartets", "qc_scf_begin_rhf", "qc_scf_begin_uhf", "qc_scf_iterate",
-           "qc_scf_orbital_energies", "qc_scf_density", "qc_scf_timings", "qc_scf_end", "qc_fock_profile_tiers"]
+           "qc_scf_orbital_energies", "qc_scf_density", "qc_scf_timings", "qc_scf_end", "qc_fock_profile_tiers", "qc_sym_eig_warm"]
 
 
 class QcError(RuntimeError):
@@ -101,6 +101,7 @@ def lib():
         L.qc_fock_rhf_device.argtypes = [vp, vp, vp]
         L.qc_fock_uhf_device.argtypes = [vp, vp, vp, vp, vp]
         L.qc_sym_eig.argtypes = [vp, C.c_int, _dp, _dp, _dp]
+        L.qc_sym_eig_warm.argtypes = [vp, C.c_int, _dp, _dp, _dp, _dp]
         L.qc_scf_rhf.argtypes = [vp, C.POINTER(_Config), C.POINTER(_Output)]
         L.qc_scf_uhf.argtypes = [vp, C.POINTER(_Config), C.POINTER(_Output)]
         L.qc_comm_unique_id.argtypes = [C.c_char_p]
@@ -183,6 +184,11 @@ class System:
         A = np.ascontiguousarray(A, np.float64); n = A.shape[0]
         V = np.zeros((n, n)); w = np.zeros(n)
         _check(lib().qc_sym_eig(self._h, n, A, V, w), "qc_sym_eig"); return V, w
+
+    def sym_eig_warm(self, A, V0):
+        A = np.ascontiguousarray(A, np.float64); n = A.shape[0]
+        V = np.zeros((n, n)); w = np.zeros(n)
+        _check(lib().qc_sym_eig_warm(self._h, n, A, np.ascontiguousarray(V0, np.float64), V, w), "qc_sym_eig_warm"); return V, w
 
     def set_shard(self, rank, nranks): _check(lib().qc_set_shard(self._h, rank, nranks), "qc_set_shard")
 
