@@ -51,7 +51,40 @@ __host__ __device__ constexpr QcTuvTable qc_make_tuv() {
             for (int u = N - t; u >= 0; --u) { T.t[k] = (unsigned char)t; T.u[k] = (unsigned char)u; T.v[k] = (unsigned char)(N - t - u); ++k; }
     return T;
 }
-__device__ constexpr QcTuvTable qc_tuv = qc_make_tuv();
+
+// Step 2 as loops, for the classes whose R table lives in LDS (LAB + LCD > QC_LREG).  The ket Hermite index
+// h2 = (t2,u2,v2) runs in wave-uniform scalar loops; for every h2 the HAB accumulators are updated by an unrolled body whose
+// R offset  hidx(h1 + h2) = T3(N1 + N2) + T2(s1 + s2) + v1 + v2  (T3(N) = N(N+1)(N+2)/6, T2(s) = s(s+1)/2, s = u + v) is
+// two scalar table look-ups plus constants.  A lane keeps only W[HAB] live - the fully unrolled form needed 512
+// registers and scratch for every class with a wide ket, and its code did not fit the instruction cache.
+template <int LAB, int LCD>
+__device__ __forceinline__ void qc_step2_rolled(double (&W)[qc_nherm(LAB)], const double *__restrict__ Ecd, int ncd, double sc,
+                                                const double *__restrict__ R) {
+    constexpr QcTuvTable T = qc_make_tuv();
+    const double *e_ptr = Ecd;
+    for (int N2 = 0; N2 <= LCD; ++N2) {
+        const double sgn = (N2 & 1) ? -sc : sc;
+        int off3[LAB + 1];
+#pragma unroll
+        for (int k = 0; k <= LAB; ++k) off3[k] = (k + N2) * (k + N2 + 1) * (k + N2 + 2) / 6;
+        for (int t2 = N2; t2 >= 0; --t2) {
+            for (int u2 = N2 - t2; u2 >= 0; --u2) {
+                const int v2 = N2 - t2 - u2, s2 = N2 - t2;
+                const double e = *e_ptr * sgn;
+                e_ptr += ncd;
+                int off2[LAB + 1];
+#pragma unroll
+                for (int k = 0; k <= LAB; ++k) off2[k] = (k + s2) * (k + s2 + 1) / 2 + v2;
+#pragma unroll
+                for (int h1 = 0; h1 < qc_nherm(LAB); ++h1) {
+                    const int N1 = T.t[h1] + T.u[h1] + T.v[h1], s1 = T.u[h1] + T.v[h1], v1 = T.v[h1];
+                    W[h1] = fma(e, R[off3[N1] + off2[s1] + v1], W[h1]);
+                }
+            }
+        }
+    }
+}
+
 
 // Boys function F_0..F_L at x: 8-term Taylor expansion about the nearest grid point of the pre-tabulated
 // F_n(x_k) for the top order, downward recursion below it; asymptotic form + upward recursion beyond the table.
@@ -299,19 +332,19 @@ __device__ __forceinline__ void qc_fock_body(const QcKernelArgs &a, const QcSlot
                 const double alpha = p * q * (pref * pref);
                 double F[L + 1];
                 qc_boys<L>(alpha * (X * X + Y * Y + Z * Z), a.boys, F);
-                double e[HCD];
                 const double sc = (valid && colok) ? pref : 0.0;
                 const double *Ecd = ket + 4 + (colok ? col : 0);
-#pragma unroll
-                for (int h = 0; h < HCD; ++h) e[h] = Ecd[h * ncd] * sc;
                 if constexpr (L <= QC_LREG) {         // small tables: every lane keeps its own copy in registers
+                    double e[HCD];
+#pragma unroll
+                    for (int h = 0; h < HCD; ++h) e[h] = Ecd[h * ncd] * sc;
                     double Rr[qc_nherm(L)];
                     qc_rtab<L>(alpha, X, Y, Z, F, Rr);
                     qc_step2<LAB, LCD>(W, e, Rr);
                 } else {
                     __syncthreads();                  // previous iteration's readers of Rw are done
                     qc_build_r<L>(Rw, li, C, alpha, X, Y, Z, F);
-                    qc_step2<LAB, LCD>(W, e, Rw);
+                    qc_step2_rolled<LAB, LCD>(W, Ecd, ncd, sc, Rw);
                 }
             }
             }

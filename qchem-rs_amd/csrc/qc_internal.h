@@ -13,7 +13,7 @@ constexpr int QC_LMAX = 3;              // highest shell angular momentum with k
 constexpr int QC_LPAIR = 2 * QC_LMAX;   // highest pair angular momentum
 constexpr int QC_LTOT = 4 * QC_LMAX;    // highest Hermite order of an ERI
 constexpr int QC_SLOT_ITMAX = 128;
-constexpr int QC_LREG = 6;               // total Hermite orders up to this keep the R table in registers
+constexpr int QC_LREG = 4;               // total Hermite orders up to this keep the R table in registers
 constexpr int QC_LHOIST = 4;             // ... and up to this the C lanes of a group evaluate C primitive quartets' tables at once
 // doubles at the head of a lane group's LDS region: cooperative R work array (L > QC_LREG), or the C hoisted
 // register tables + their (pref, ij/kl) records (L <= QC_LHOIST, C > 1)

@@ -195,14 +195,15 @@ def test_uhf_reference_rule_matches_oracle(mol, basis):
 def test_uhf_triplet_oxygen_extension():
     """BASELINE config 4: O2 triplet (n_alpha = 9, n_beta = 7) - an extension, checked against the oracle's same extension."""
     q, s, o = _sys("oxygen", "cc-pVDZ")
-    # This SCF has a noise floor near 1e-10 in the reference algorithm itself (never-reset DIIS(2,8) on a spectrum with
-    # exactly degenerate pi shells): the oracle needs 95 passes to dip below 1e-10 and run-to-run rounding of the atomic
-    # accumulation moves the GPU between 55 and >200.  epsilon = 1e-9 is reached reproducibly; the reported (stale-G)
-    # energy is then within a few 1e-9 Eh on both sides.
-    out = q.unrestricted_hartree_fock(s, q.HartreeFockConfig(300, 1e-9, n_alpha=9, n_beta=7))
-    ref = o.uhf(300, 1e-9, n_alpha=9, n_beta=7)
+    # This SCF crawls: with the never-reset DIIS(2,8) of uhf.rs:76-78 on a spectrum with exactly degenerate pi shells the
+    # density rms wanders around 1e-9..1e-10 for dozens of passes (the oracle needs 95 to dip below 1e-10; run-to-run
+    # rounding of the atomic accumulation moves the GPU between ~50 and ~200), and the reported stale-G energy
+    # (SURVEY fact 7) is first-order in that residual.  At epsilon = 1e-10 both sides agree to a few 1e-9 Eh whenever they
+    # stop; the iteration cap is generous so the comparison itself is deterministic.
+    out = q.unrestricted_hartree_fock(s, q.HartreeFockConfig(2000, 1e-10, n_alpha=9, n_beta=7))
+    ref = o.uhf(2000, 1e-10, n_alpha=9, n_beta=7)
     assert out is not None and ref["status"] == 0
-    assert abs(out.total_energy() - ref["total_energy"]) < 2e-8
+    assert abs(out.total_energy() - ref["total_energy"]) < TOL_E
 
 
 def test_not_converged_returns_none():
