@@ -207,6 +207,7 @@ def main():
             line["cpu_baseline"] = cpu_baseline(mol)
     if rank == 0:
         print(json.dumps(line), flush=True)
+    sysh.close()                                    # releases the RCCL communicator before torch tears its own down
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

@@ -146,10 +146,13 @@ class System:
                                       C.byref(self._h)), "qc_system_create")
         self.n = lib().qc_nbasis(self._h)
 
+    def close(self):
+        if self._h:
+            lib().qc_system_destroy(self._h); self._h = None
+
     def __del__(self):
         try:
-            if self._h:
-                lib().qc_system_destroy(self._h); self._h = None
+            self.close()
         except Exception:
             pass
 
