@@ -22,6 +22,7 @@ __host__ __device__ constexpr int qc_region0(int L, int lgc) {
                        : ((L <= QC_LHOIST && lgc > 0) ? (1 << lgc) * ((((L + 1) * (L + 2) * (L + 3) / 6) | 1) + 2) : 0);
 }
       // primitive quartets per slot
+constexpr double QC_PRIM_CUTOFF = 1e-17; // primitive pairs whose Hermite expansion block is entirely below this are dropped
 constexpr int QC_NREP = 32;             // replicas of the Fock accumulation buffer
 constexpr int QC_NSTREAMS = 7;          // class kernels of one build run concurrently on this many streams
 
@@ -76,7 +77,7 @@ struct qc_system {
     std::vector<QcShell> shells;
     // pairs
     std::vector<QcPairDesc> pairs;
-    std::vector<int> pairA, pairB;
+    std::vector<int> pairA, pairB, pairKfull;   // shells of each stored pair; its primitive-pair count before the cut-off
     std::vector<double> pairdata;
     std::vector<QcClass> classes;
     int64_t nquartets = 0;

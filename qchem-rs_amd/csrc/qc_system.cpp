@@ -186,30 +186,44 @@ void qc_build_model(qc_system *S) {
     // shell pairs A >= B, with per-primitive-pair blocks [p, Px, Py, Pz, E(nherm x nab)].
     // The pair part of the ERI prefactor 2 pi^{5/2} / (p q sqrt(p+q)) is folded in as sqrt(2) pi^{5/4} / p.
     const double half_pref = std::sqrt(2.0) * std::pow(M_PI, 1.25);
-    S->pairs.clear(); S->pairA.clear(); S->pairB.clear(); S->pairdata.clear();
+    S->pairs.clear(); S->pairA.clear(); S->pairB.clear(); S->pairKfull.clear(); S->pairdata.clear();
+    // Primitive pairs whose whole expansion block is below QC_PRIM_CUTOFF are not stored: with the Gaussian-product
+    // factor exp(-mu R^2) and the coefficients folded into E, an integral is bounded by max|E_ab| max|E_cd| (times
+    // O(10)), so a dropped primitive pair changes no integral by more than ~1e-16 - five orders below the 1e-10 parity
+    // bar - while two-centre pairs of deeply contracted s/p shells lose a third to two thirds of their primitives.
+    // (The reference evaluates them all; counts quoted as "enumerated" keep the full numbers.)
+    int64_t npairs_all = 0;
+    std::vector<double> blkbuf;
     for (int a = 0; a < S->nshells; ++a)
         for (int b = 0; b <= a; ++b) {
             const QcShell &A = S->shells[a], &B = S->shells[b];
+            ++npairs_all;
             QcPairDesc d;
             d.doff = (int)S->pairdata.size();
-            d.K = A.nprim * B.nprim;
+            d.K = 0;
             d.na = A.nfunc; d.nb = B.nfunc; d.offa = A.off; d.offb = B.off; d.L = A.L + B.L; d.shA_eq_shB = (a == b);
-            const int nab = d.na * d.nb, stride = qc_pair_stride(d.L, nab);
-            S->pairdata.resize(S->pairdata.size() + (size_t)d.K * stride);
+            const int nab = d.na * d.nb, stride = qc_pair_stride(d.L, nab), ne = qc_nherm(d.L) * nab;
+            blkbuf.assign(stride, 0.0);
             for (int i = 0; i < A.nprim; ++i)
                 for (int j = 0; j < B.nprim; ++j) {
-                    double *blk = &S->pairdata[d.doff + (size_t)(i * B.nprim + j) * stride];
                     double p, P[3];
                     const double pp = A.exps[i] + B.exps[j];
-                    pair_hermite_matrix(A, B, i, j, half_pref / pp, blk + 4, &p, P);
-                    blk[0] = p; blk[1] = P[0]; blk[2] = P[1]; blk[3] = P[2];
+                    std::fill(blkbuf.begin(), blkbuf.end(), 0.0);
+                    pair_hermite_matrix(A, B, i, j, half_pref / pp, blkbuf.data() + 4, &p, P);
+                    double mx = 0.0;
+                    for (int k = 0; k < ne; ++k) mx = std::max(mx, std::fabs(blkbuf[4 + k]));
+                    if (mx < QC_PRIM_CUTOFF) continue;
+                    blkbuf[0] = p; blkbuf[1] = P[0]; blkbuf[2] = P[1]; blkbuf[3] = P[2];
+                    S->pairdata.insert(S->pairdata.end(), blkbuf.begin(), blkbuf.end());
+                    ++d.K;
                 }
-            S->pairs.push_back(d); S->pairA.push_back(a); S->pairB.push_back(b);
+            if (d.K == 0) continue;                       // the whole shell pair is negligible
+            S->pairs.push_back(d); S->pairA.push_back(a); S->pairB.push_back(b); S->pairKfull.push_back(A.nprim * B.nprim);
         }
     // unique quartets (pair P >= pair Q), oriented so the wider pair is the ket (column side), bucketed by
     // launch class (LAB, LCD, lane-group width)
     const int np = (int)S->pairs.size();
-    S->nquartets = (int64_t)np * (np + 1) / 2;
+    S->nquartets = npairs_all * (npairs_all + 1) / 2;      // enumerated (unscreened) count, as the reference would visit
     const int NB = (QC_LPAIR + 1) * (QC_LPAIR + 1) * 7;
     std::vector<std::vector<QcTask>> bucket(NB);
     for (int P = 0; P < np; ++P)
@@ -282,11 +296,11 @@ void qc_build_shards(qc_system *S) {
             const QcPairDesc &b = S->pairs[t.bra], &k = S->pairs[t.ket];
             const QcShell &A = S->shells[S->pairA[t.bra]], &B = S->shells[S->pairB[t.bra]];
             const QcShell &C = S->shells[S->pairA[t.ket]], &D = S->shells[S->pairB[t.ket]];
-            const double Kab = b.K, Kcd = k.K, L = b.L + k.L;
+            const double Kab = S->pairKfull[t.bra], Kcd = S->pairKfull[t.ket], L = b.L + k.L;   // model on enumerated primitives
             const double hab = qc_nherm(b.L), hcd = qc_nherm(k.L);
             const double na = b.na, nb = b.nb, nc = k.na, nd = k.nb;
             const double ca = A.ncart, cb = B.ncart, cc = C.ncart, cd = D.ncart;
-            c.prim_quartets += (int64_t)(Kab * Kcd);
+            c.prim_quartets += (int64_t)b.K * k.K;          // evaluated (after the primitive-pair cut-off)
             // SURVEY.md 8(d) work model, verbatim
             c.bytes_alg += 8.0 * (5.0 * (Kab + Kcd) + 3.0 * (na * nb + nc * nd + na * nc + na * nd + nb * nc + nb * nd));
             c.flops_alg += Kab * Kcd * (40.0 * (L + 1) + 3.0 * qc_rwork((int)L) + 2.0 * hab * hcd) + 2.0 * ca * cb * hab * hcd +
