@@ -257,14 +257,15 @@ __device__ __forceinline__ void qc_fock_body(const QcKernelArgs &a, const QcSlot
                 // tables in registers, then parked in the group's LDS region) and afterwards walk through them one by
                 // one, every lane contracting its own ket column (phase B).  Same-wave LDS hand-off: wavefront fences.
                 double *const meta = Rw + C * NHP;
+                // this lane's primitive quartet of the current chunk: starts at sl.lo + li, advances by C per chunk
+                int ijA, klA;
+                { const int pq0 = sl.lo + li; ijA = pq0 / K_cd; klA = pq0 - ijA * K_cd; }
                 for (int it0 = 0; it0 < maxlen; it0 += C) {
                     {
-                        const int itA = it0 + li;
-                        const bool vA = itA < len;
-                        const int pqA = sl.lo + (vA ? itA : 0);
-                        const int ijA = pqA / K_cd, klA = pqA - ijA * K_cd;
-                        const double4 cb = *reinterpret_cast<const double4 *>(braBase + (size_t)ijA * strideB);
-                        const double4 ck = *reinterpret_cast<const double4 *>(ketBase + (size_t)klA * strideK);
+                        const bool vA = it0 + li < len;
+                        const int ijC = vA ? ijA : 0, klC = vA ? klA : 0;      // stay inside the pair blocks when idle
+                        const double4 cb = *reinterpret_cast<const double4 *>(braBase + (size_t)ijC * strideB);
+                        const double4 ck = *reinterpret_cast<const double4 *>(ketBase + (size_t)klC * strideK);
                         const double p = cb.x, q = ck.x;
                         const double X = cb.y - ck.y, Y = cb.z - ck.z, Z = cb.w - ck.w;
                         const double pref = rsqrt(p + q);
@@ -277,28 +278,32 @@ __device__ __forceinline__ void qc_fock_body(const QcKernelArgs &a, const QcSlot
 #pragma unroll
                         for (int h = 0; h < qc_nherm(L); ++h) mine[h] = Rr[h];
                         meta[2 * li] = vA ? pref : 0.0;
-                        reinterpret_cast<int2 *>(meta)[2 * li + 1] = make_int2(ijA, klA);
+                        reinterpret_cast<int2 *>(meta)[2 * li + 1] = make_int2(ijC, klC * strideK + 4);   // ket block offset
                         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                         __builtin_amdgcn_wave_barrier();
                         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                        klA += C;
+                        while (klA >= K_cd) { klA -= K_cd; ++ijA; }
                     }
                     const int nB = min(C, maxlen - it0);
                     for (int s = 0; s < nB; ++s) {
-                        const bool valid = it0 + s < len;
-                        const double pref = meta[2 * s];
-                        const int2 ik = reinterpret_cast<const int2 *>(meta)[2 * s + 1];
-                        if (valid && ik.x != cur_ij) {
-                            if (cur_ij >= 0) flush(cur_ij);
+                        {
+                            const bool valid = it0 + s < len;
+                            const double pref = meta[2 * s];
+                            const int2 ik = reinterpret_cast<const int2 *>(meta)[2 * s + 1];
+                            if (valid && ik.x != cur_ij) {
+                                if (cur_ij >= 0) flush(cur_ij);
 #pragma unroll
-                            for (int h = 0; h < HAB; ++h) W[h] = 0.0;
-                            cur_ij = ik.x;
+                                for (int h = 0; h < HAB; ++h) W[h] = 0.0;
+                                cur_ij = ik.x;
+                            }
+                            double e[HCD];
+                            const double sc = (valid && colok) ? pref : 0.0;
+                            const double *Ecd = ketBase + ik.y + (colok ? col : 0);
+#pragma unroll
+                            for (int h = 0; h < HCD; ++h) e[h] = Ecd[h * ncd] * sc;
+                            qc_step2<LAB, LCD>(W, e, Rw + s * NHP);
                         }
-                        double e[HCD];
-                        const double sc = (valid && colok) ? pref : 0.0;
-                        const double *Ecd = ketBase + (size_t)ik.y * strideK + 4 + (colok ? col : 0);
-#pragma unroll
-                        for (int h = 0; h < HCD; ++h) e[h] = Ecd[h * ncd] * sc;
-                        qc_step2<LAB, LCD>(W, e, Rw + s * NHP);
                     }
                 }
             } else {
