@@ -271,6 +271,91 @@ __global__ __launch_bounds__(QC_EIG_THREADS) void qc_jacobi1_kernel(int n, const
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// One-sided Jacobi for n > 128: same algorithm as qc_jacobi1_kernel with G in global memory (d_work, n columns of
+// stride n) and the pairs of a step spread over the 64 teams of one workgroup in a loop.  Slow (global read-modify-write
+// behind a workgroup barrier per step) but only the cold start and the rare fallback of the refinement use it; the SCF
+// loop's eigensolves are GEMMs (qc_eig_device_refine).  Keeps every shipped basis (benzene/6-311++G**: n = 180) usable.
+__global__ __launch_bounds__(QC_EIG_THREADS) void qc_jacobi1g_kernel(int n, const double *__restrict__ Ain, double *__restrict__ G,
+                                                                     double *__restrict__ Vout, double *__restrict__ w, int max_sweeps) {
+    extern __shared__ double sm[];
+    __shared__ double red[32];
+    __shared__ int flag;
+    double *nrm = sm;                                       // n column norms
+    int *rank = reinterpret_cast<int *>(sm + n);            // n ranks
+    const int m = (n + 1) & ~1, half = m / 2;
+    const int tid = threadIdx.x, nt = blockDim.x;
+    double low = 1e300, spread = 0.0;
+    for (int i = tid; i < n; i += nt) {
+        double r = 0.0;
+        for (int j = 0; j < n; ++j) if (j != i) r += fabs(Ain[(size_t)i * n + j]);
+        low = fmin(low, Ain[(size_t)i * n + i] - r);
+        spread = fmax(spread, Ain[(size_t)i * n + i] + r);
+    }
+    for (int o = 32; o > 0; o >>= 1) { low = fmin(low, __shfl_down(low, o, 64)); spread = fmax(spread, __shfl_down(spread, o, 64)); }
+    if ((tid & 63) == 0) { red[tid >> 6] = low; red[16 + (tid >> 6)] = spread; }
+    __syncthreads();
+    low = red[0]; spread = red[16];
+    for (int k = 1; k < nt / 64; ++k) { low = fmin(low, red[k]); spread = fmax(spread, red[16 + k]); }
+    __syncthreads();
+    const double sigma = fmax(0.0, -low) + 0.05 * (spread - low) + 1e-3;
+    for (int x = tid; x < n * n; x += nt) {               // column-major copy of the (symmetric) shifted matrix
+        const int j = x / n, i = x - j * n;
+        G[x] = 0.5 * (Ain[(size_t)i * n + j] + Ain[(size_t)j * n + i]) + (i == j ? sigma : 0.0);
+    }
+    if (tid == 0) flag = 0;
+    __syncthreads();
+    const int team = tid / QC_EIG1_TEAM, tl = tid % QC_EIG1_TEAM, nteams = nt / QC_EIG1_TEAM;
+    for (int sweep = 0; sweep < max_sweeps; ++sweep) {
+        for (int step = 0; step < m - 1; ++step) {
+            for (int pr = team; pr < half; pr += nteams) {
+                int p, q;
+                qc_rr_pair(step, pr, m, p, q);
+                if (p >= n || q >= n) continue;           // padding index of an odd n
+                double *gp = G + (size_t)p * n, *gq = G + (size_t)q * n;
+                double a = 0.0, b = 0.0, c = 0.0;
+                for (int r = tl; r < n; r += QC_EIG1_TEAM) { const double xp = gp[r], xq = gq[r]; a = fma(xp, xp, a); b = fma(xq, xq, b); c = fma(xp, xq, c); }
+#pragma unroll
+                for (int o = QC_EIG1_TEAM / 2; o > 0; o >>= 1) {
+                    a += __shfl_xor(a, o, QC_EIG1_TEAM); b += __shfl_xor(b, o, QC_EIG1_TEAM); c += __shfl_xor(c, o, QC_EIG1_TEAM);
+                }
+                const double rel = fabs(c) / sqrt(a * b);
+                if (rel > 1e-16) {
+                    const double zeta = (b - a) / (2.0 * c);
+                    const double t = (zeta >= 0.0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(fma(zeta, zeta, 1.0)));
+                    const double cs = 1.0 / sqrt(fma(t, t, 1.0)), sn = cs * t;
+                    for (int r = tl; r < n; r += QC_EIG1_TEAM) { const double xp = gp[r], xq = gq[r]; gp[r] = cs * xp - sn * xq; gq[r] = sn * xp + cs * xq; }
+                    if (tl == 0 && rel > 1e-9) flag = 1;
+                }
+            }
+            __syncthreads();
+        }
+        const int any = flag;
+        __syncthreads();
+        if (tid == 0) flag = 0;
+        __syncthreads();
+        if (!any) break;
+    }
+    for (int j = tid; j < n; j += nt) {
+        double s2 = 0.0;
+        for (int i = 0; i < n; ++i) s2 = fma(G[(size_t)j * n + i], G[(size_t)j * n + i], s2);
+        nrm[j] = sqrt(s2);
+    }
+    __syncthreads();
+    for (int i = tid; i < n; i += nt) {
+        const double wi = nrm[i];
+        int r = 0;
+        for (int j = 0; j < n; ++j) r += (nrm[j] < wi || (nrm[j] == wi && j < i)) ? 1 : 0;
+        rank[i] = r;
+        w[r] = wi - sigma;
+    }
+    __syncthreads();
+    for (int x = tid; x < n * n; x += nt) {
+        const int i = x / n, j = x - i * n;
+        Vout[(size_t)i * n + rank[j]] = G[(size_t)j * n + i] / nrm[j];
+    }
+}
+
 // dA: input (left intact), dV: sorted eigenvectors, dw: eigenvalues, d_work: n*n scratch
 int qc_eig_device(hipStream_t st, int n, double *dA, double *dV, double *dw, double *d_work) {
     const int m = (n + 1) & ~1, ld = m | 1;
@@ -288,7 +373,11 @@ int qc_eig_device(hipStream_t st, int n, double *dA, double *dV, double *dw, dou
         }
     }
     const size_t lds = v_in_lds ? lds2 : lds1;
-    if (lds > 160 * 1024) return QC_ERR_UNSUPPORTED;   // n <= 140; larger n needs the multi-workgroup solver (next round)
+    if (lds > 160 * 1024 || !v_in_lds) {                // n > 128: the global-memory variant
+        if (n > 3000) return QC_ERR_UNSUPPORTED;
+        hipLaunchKernelGGL(qc_jacobi1g_kernel, dim3(1), dim3(QC_EIG_THREADS), (size_t)n * 12 + 16, st, n, dA, d_work, dV, dw, 40);
+        return hipGetLastError() == hipSuccess ? QC_OK : QC_ERR_HIP;
+    }
     auto kern = v_in_lds ? qc_jacobi_kernel<true> : qc_jacobi_kernel<false>;
     if (lds > 48 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);

@@ -134,7 +134,7 @@ def test_step_api_matches_driver():
     st.close()
 
 
-@pytest.mark.parametrize("n", [2, 7, 24, 58, 114])
+@pytest.mark.parametrize("n", [2, 7, 24, 58, 114, 150])
 def test_sym_eig(n):
     import qchem_rs_amd as q
     s = q.System(load_system("hydrogen", "STO-3G"))
@@ -145,6 +145,44 @@ def test_sym_eig(n):
     assert np.abs(w - w_ref).max() < 1e-12 * max(1.0, np.abs(w_ref).max())
     assert np.abs(V.T @ V - np.eye(n)).max() < 1e-12
     assert np.abs(A @ V - V * w).max() < 1e-11 * max(1.0, np.abs(w_ref).max())
+
+
+def test_sym_eig_warm_start_regimes():
+    """qc_sym_eig_warm: GEMM refinement for small perturbations, Jacobi fallback for large ones, (near-)degenerate spectra."""
+    import qchem_rs_amd as q
+    s = q.System(load_system("hydrogen", "STO-3G"))
+    rng = np.random.default_rng(2)
+    n = 40
+    for split in (0.0, 1e-9, 1e-5):
+        d = np.sort(rng.uniform(-10, 10, n)); d[1] = d[0] + split; d[11] = d[10] + split; d[21] = d[20] + split; d[22] = d[20] + 2 * split
+        Q, _ = np.linalg.qr(rng.standard_normal((n, n)))
+        A = (Q * d) @ Q.T; A = 0.5 * (A + A.T)
+        _, V0 = np.linalg.eigh(A)
+        for eps in (0.0, 1e-9, 1e-6, 1e-3, 0.3):
+            P = rng.standard_normal((n, n)); B = A + eps * (P + P.T)
+            V, w = s.sym_eig_warm(B, V0)
+            assert np.all(np.diff(w) >= 0)
+            assert np.abs(w - np.linalg.eigvalsh(B)).max() < 1e-11
+            assert np.abs(V.T @ V - np.eye(n)).max() < 1e-12
+            assert np.abs(B @ V - V * w).max() < 1e-10
+
+
+def test_rhf_chloroform_sto3g_third_row_and_large_basis():
+    """Cl (6-primitive contractions, 33 functions) and a basis beyond the in-LDS eigensolver limit (benzene/6-311++G**, n = 174)."""
+    q, s, o = _sys("chloroform", "STO-3G")
+    out = q.restricted_hartree_fock(s, q.HartreeFockConfig(200, 1e-9))
+    ref = o.rhf(200, 1e-9)
+    assert out is not None and ref["status"] == 0 and abs(out.total_energy() - ref["total_energy"]) < TOL_E
+    q, s, o = _sys("benzene", "6-311++G_st_st")
+    assert s.n > 128
+    D = _rand_sym(s.n, 12)
+    G1, G2 = s.fock_rhf(D), s.fock_rhf(2.0 * D)
+    assert np.abs(G2 - 2.0 * G1).max() < 1e-10 * np.abs(G2).max()
+    st = q.ScfStepper(s)
+    e0, r0 = st.iterate()
+    e1, r1 = st.iterate()
+    assert np.isfinite(e0) and np.isfinite(e1) and r1 < r0
+    st.close()
 
 
 def test_sym_eig_degenerate():
