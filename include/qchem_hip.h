@@ -128,6 +128,13 @@ int qc_scf_density(qc_scf_state *st, int spin, double *out_nxn);
 int qc_scf_timings(qc_scf_state *st, double *ms_setup, double *ms_fock, double *ms_linalg);
 void qc_scf_end(qc_scf_state *st);
 
+/* ---- Fock mode of the SCF drivers on this handle.  0 (default): direct - quartets are evaluated and digested every pass.
+ * 1: stored - the reference's own conventional algorithm with the tensor resident in HBM: molint::eri once (rhf.rs:45),
+ * electron_terms (rhf.rs:58-62), then one streaming GEMV per pass (rhf.rs:152-167 / uhf.rs:216-226).  Needs ~18 n^4 bytes
+ * during set-up (QC_ERR_UNSUPPORTED if the device cannot hold them); single-GPU only. */
+int qc_set_fock_mode(qc_system *sys, int mode);
+double qc_scf_tensor_ms(qc_scf_state *st);   /* wall time of the tensor build of a stored-mode state */
+
 /* ---- multi-GPU (not in the reference, which is single-threaded; BASELINE.json north_star).  One process per GPU.
  * Rank 0 calls qc_comm_unique_id, the host distributes the 128 bytes, every rank calls qc_comm_init, which creates
  * an RCCL communicator on the current device and restricts this handle's Fock builds to shard `rank` of `nranks`. */

@@ -416,6 +416,9 @@ struct qc_scf_state {
     int nocc[2] = {0, 0};
     ScfWork W;
     DevBuf D, Dn, G, Cs, ws;
+    DevBuf T4, TK, Dtot;                       // stored mode: RHF T = I - I^x / 2; UHF I and its exchange-permuted copy
+    bool stored = false;
+    double ms_tensor = 0;
     DeviceDiis *diis[2] = {nullptr, nullptr};
     hipEvent_t ev0 = nullptr, ev1 = nullptr, ev2 = nullptr;
     double ms_fock = 0, ms_linalg = 0, ms_setup = 0;
@@ -449,6 +452,30 @@ static int scf_begin(qc_system *S, bool uhf, int n_alpha, int n_beta, qc_scf_sta
     if ((rc = scf_setup(S, st->W, h_eht)) != QC_OK) return rc;           // rhf.rs:41-49
     for (int s = 0; s < nspin; ++s)                                       // rhf.rs:50 / uhf.rs:60-63
         if ((rc = huckel_density(S, st->W, h_eht, st->nocc[s], uhf ? 1.0 : 2.0, st->D.p + s * nn)) != QC_OK) return rc;
+    if (S->fock_mode == 1) {
+        // the reference's conventional SCF: ERI tensor once (rhf.rs:45), antisymmetrised copy (rhf.rs:58-62), dense
+        // contraction per pass.  8 n^4 bytes per tensor; two of them live during the build.
+        if (S->comm || S->nranks != 1) return QC_ERR_UNSUPPORTED;        // sharded builds are direct-mode only
+        const size_t n4 = nn * nn;
+        size_t free_b = 0, total_b = 0;
+        QC_HIP_CHECK(hipMemGetInfo(&free_b, &total_b));
+        if ((double)n4 * 8.0 * 2.2 > (double)free_b) return QC_ERR_UNSUPPORTED;
+        const double tt0 = now_ms();
+        DevBuf I;
+        if (I.alloc(n4) != QC_OK || st->T4.alloc(n4) != QC_OK) return QC_ERR_HIP;
+        QC_HIP_CHECK(hipMemsetAsync(I.p, 0, n4 * sizeof(double), S->stream));
+        if ((rc = qc_launch_eri_full(S, I.p)) != QC_OK) return rc;
+        if (uhf) {
+            qc_permute_tensor(S->stream, n, I.p, 0.0, 1.0, st->T4.p);      // TK[i,j,k,l] = I[i,k,j,l]
+            st->TK.p = st->T4.p; st->T4.p = I.p; I.p = nullptr;            // keep I (as T4) and TK
+            if (st->Dtot.alloc(nn) != QC_OK) return QC_ERR_HIP;
+        } else {
+            qc_permute_tensor(S->stream, n, I.p, 1.0, -0.5, st->T4.p);     // electron_terms, rhf.rs:58-62
+        }
+        QC_HIP_CHECK(hipStreamSynchronize(S->stream));
+        st->stored = true;
+        st->ms_tensor = now_ms() - tt0;
+    }
     for (int s = 0; s < nspin; ++s) {                                     // Diis::new(4,6) rhf.rs:65 / (2,8) uhf.rs:76-78
         st->diis[s] = uhf ? new DeviceDiis(2, 8, n) : new DeviceDiis(4, 6, n);
         if ((rc = st->diis[s]->init()) != QC_OK) return rc;
@@ -470,8 +497,18 @@ static int scf_iterate(qc_scf_state *st, double *energy, double *rms_out) {
     const int nspin = st->uhf ? 2 : 1;
     int rc;
     QC_HIP_CHECK(hipEventRecord(st->ev0, sm));
-    // G of every spin from the *old* densities, one pass over the ERIs
-    if ((rc = qc_fock_build_device(S, st->D.p, st->uhf ? st->D.p + nn : nullptr, st->G.p, st->uhf ? st->G.p + nn : nullptr, st->uhf)) != QC_OK) return rc;
+    // G of every spin from the *old* densities
+    if (st->stored) {
+        if (st->uhf) {   // uhf.rs:216-226: G_s = <I, D_s + D_s'> - <I^x, D_s>
+            qc_axpby(sm, n, 1.0, st->D.p, 1.0, st->D.p + nn, st->Dtot.p);
+            qc_axpby(sm, n, -1.0, st->D.p, 0.0, nullptr, st->W.t1.p);
+            qc_tensor_gemv(sm, n, st->T4.p, st->Dtot.p, st->TK.p, st->W.t1.p, st->G.p);
+            qc_axpby(sm, n, -1.0, st->D.p + nn, 0.0, nullptr, st->W.t1.p);
+            qc_tensor_gemv(sm, n, st->T4.p, st->Dtot.p, st->TK.p, st->W.t1.p, st->G.p + nn);
+        } else {
+            qc_tensor_gemv(sm, n, st->T4.p, st->D.p, nullptr, nullptr, st->G.p);   // rhf.rs:152-167
+        }
+    } else if ((rc = qc_fock_build_device(S, st->D.p, st->uhf ? st->D.p + nn : nullptr, st->G.p, st->uhf ? st->G.p + nn : nullptr, st->uhf)) != QC_OK) return rc;
     QC_HIP_CHECK(hipEventRecord(st->ev1, sm));
     for (int s = 0; s < nspin; ++s) {
         if ((rc = roothaan_step(S, st->W, *st->diis[s], st->G.p + s * nn, st->D.p + s * nn, st->ws.p + s * n, s)) != QC_OK) return rc;
@@ -545,6 +582,12 @@ int qc_scf_density(qc_scf_state *st, int spin, double *out) {
     QC_HIP_CHECK(hipMemcpy(out, st->D.p + spin * nn, nn * sizeof(double), hipMemcpyDeviceToHost));
     return QC_OK;
 }
+int qc_set_fock_mode(qc_system *S, int mode) {
+    if (!S || (mode != 0 && mode != 1)) return QC_ERR_INVALID;
+    S->fock_mode = mode;
+    return QC_OK;
+}
+double qc_scf_tensor_ms(qc_scf_state *st) { return st ? st->ms_tensor : 0.0; }
 int qc_scf_timings(qc_scf_state *st, double *ms_setup, double *ms_fock, double *ms_linalg) {
     if (!st) return QC_ERR_INVALID;
     if (ms_setup) *ms_setup = st->ms_setup;

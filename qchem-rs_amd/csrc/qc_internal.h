@@ -102,6 +102,7 @@ struct qc_system {
     std::vector<FockGraph> graphs;
     std::vector<float> unit_ms;              // measured serial time of each launch unit (autotuned once per shard)
     std::vector<int> unit_stream;            // side stream of each launch unit (longest-processing-time assignment)
+    int fock_mode = 0;                       // 0 direct (default), 1 stored tensor (the reference's own algorithm)
     bool use_graphs = false;                 // hipGraph replay of the build measured slower than eager multi-stream launches on ROCm 7.2
     std::string last_error;
 };
@@ -144,6 +145,8 @@ int qc_eig_device(hipStream_t st, int n, double *dA /*destroyed*/, double *dV, d
 int qc_eig_device_warm(hipStream_t st, int n, double *dA, const double *dV0, double *dV, double *dw, double *d_work, double *t1, double *t2);
 int qc_eig_device_refine(hipStream_t st, int n, double *dA, const double *dV0, double *dV, double *dw, double *d_work, double *t1, double *t2,
                          double *t3, double *t4, double *small);
+void qc_permute_tensor(hipStream_t st, int n, const double *I, double c_direct, double c_exch, double *T);
+void qc_tensor_gemv(hipStream_t st, int n, const double *T1, const double *D1, const double *T2, const double *D2, double *G);
 void qc_axpby(hipStream_t st, int n, double a, const double *x, double b, const double *y, double *out);
 void qc_sub_transpose(hipStream_t st, int n, const double *M, double *out);              // out = M - M^T
 void qc_symmetrize_add(hipStream_t st, int n, const double *Gt, double *G);              // G = Gt + Gt^T

@@ -4,6 +4,7 @@
 // Replaces the nalgebra operations in the reference's loop body: the `*` products at rhf.rs:71,74,76,85,
 // SymmetricEigen behind utils::sorted_eigs (hf/utils.rs:20-36), the Frobenius dots of diis.rs:43-45 and the
 // trace / diagonal-rms at rhf.rs:84-88.
+#include <algorithm>
 #include <cstdlib>
 #include <vector>
 
@@ -653,6 +654,53 @@ __device__ __forceinline__ double block_sum_256(double v, double *sh) {
     __syncthreads();
     return r;
 }
+
+// ---------------------------------------------------------------------------------------------------------------
+// Stored-tensor ("conventional") Fock build: the reference's own algorithm with the n^4 tensor resident in HBM
+// (288 GB hold it up to n ~ 400).  K5a: T[i,j,k,l] = I[i,j,k,l] - c I[i,k,j,l] (rhf.rs:58-62 with c = 1/2; c = 1 gives
+// the exchange-permuted copy the UHF contraction of uhf.rs:216-226 needs).  K5b: G[i,j] = sum_kl D[k,l] T[i,j,k,l] for
+// i <= j, mirrored (rhf.rs:152-167) - a GEMV over n(n+1)/2 rows of n^2 doubles: pure HBM streaming, 4 n^4 bytes.
+__global__ void qc_permute_tensor_kernel(int n, const double *__restrict__ I, double c_direct, double c_exch, double *__restrict__ T) {
+    const size_t n1 = n, n2 = n1 * n1, n3 = n2 * n1, n4 = n3 * n1;
+    for (size_t x = blockIdx.x * (size_t)blockDim.x + threadIdx.x; x < n4; x += (size_t)gridDim.x * blockDim.x) {
+        const size_t i = x / n3, r = x - i * n3, j = r / n2, r2 = r - j * n2, k = r2 / n1, l = r2 - k * n1;
+        T[x] = c_direct * I[x] + c_exch * I[i * n3 + k * n2 + j * n1 + l];
+    }
+}
+void qc_permute_tensor(hipStream_t st, int n, const double *I, double c_direct, double c_exch, double *T) {
+    const size_t n4 = (size_t)n * n * n * n;
+    hipLaunchKernelGGL(qc_permute_tensor_kernel, dim3((unsigned)std::min<size_t>((n4 + 255) / 256, 1u << 20)), dim3(256), 0, st, n, I, c_direct, c_exch,
+                       T);
+}
+
+// One workgroup per upper-triangle row (i <= j).  G[i,j] = G[j,i] = <T1[i,j,:], D1> + <T2[i,j,:], D2> (T2/D2 optional).
+__global__ __launch_bounds__(256) void qc_tensor_gemv_kernel(int n, const double *__restrict__ T1, const double *__restrict__ D1,
+                                                             const double *__restrict__ T2, const double *__restrict__ D2, double *__restrict__ G) {
+    __shared__ double sh[4];
+    // row index -> (i, j), i <= j
+    const int row = blockIdx.x;
+    int i = (int)((2.0 * n + 1.0 - sqrt((2.0 * n + 1.0) * (2.0 * n + 1.0) - 8.0 * row)) * 0.5);
+    while (i > 0 && (size_t)i * n - (size_t)i * (i - 1) / 2 > (size_t)row) --i;
+    while ((size_t)(i + 1) * n - (size_t)(i + 1) * i / 2 <= (size_t)row) ++i;
+    const int j = i + (row - (int)((size_t)i * n - (size_t)i * (i - 1) / 2));
+    const size_t nn = (size_t)n * n, base = ((size_t)i * n + j) * nn;
+    const double2 *t1 = reinterpret_cast<const double2 *>(T1 + base), *d1 = reinterpret_cast<const double2 *>(D1);
+    double acc = 0.0;
+    const size_t nv = nn / 2;
+    for (size_t x = threadIdx.x; x < nv; x += 256) { const double2 a = t1[x], b = d1[x]; acc = fma(a.x, b.x, fma(a.y, b.y, acc)); }
+    if ((nn & 1) && threadIdx.x == 0) acc = fma(T1[base + nn - 1], D1[nn - 1], acc);
+    if (T2) {
+        const double2 *t2 = reinterpret_cast<const double2 *>(T2 + base), *d2 = reinterpret_cast<const double2 *>(D2);
+        for (size_t x = threadIdx.x; x < nv; x += 256) { const double2 a = t2[x], b = d2[x]; acc = fma(a.x, b.x, fma(a.y, b.y, acc)); }
+        if ((nn & 1) && threadIdx.x == 0) acc = fma(T2[base + nn - 1], D2[nn - 1], acc);
+    }
+    acc = block_sum_256(acc, sh);
+    if (threadIdx.x == 0) { G[(size_t)i * n + j] = acc; G[(size_t)j * n + i] = acc; }
+}
+void qc_tensor_gemv(hipStream_t st, int n, const double *T1, const double *D1, const double *T2, const double *D2, double *G) {
+    hipLaunchKernelGGL(qc_tensor_gemv_kernel, dim3((unsigned)((size_t)n * (n + 1) / 2)), dim3(256), 0, st, n, T1, D1, T2, D2, G);
+}
+
 
 // out[j] = <x, ys[j]>, one workgroup per j (diis.rs:43-45)
 struct QcPtrList { const double *p[16]; };

@@ -41,7 +41,7 @@ EXPORTS = ["qc_system_create", "qc_system_destroy", "qc_nbasis", "qc_nelectrons"
            "qc_fock_rhf_device", "qc_fock_uhf_device", "qc_sym_eig", "qc_scf_rhf", "qc_scf_uhf", "qc_comm_unique_id",
            "qc_comm_init", "qc_set_shard", "qc_plan_shard", "qc_set_stream", "qc_device_ready", "qc_work_stats_get",
            "qc_fock_profile", "qc_plan_shard_quartets", "qc_scf_begin_rhf", "qc_scf_begin_uhf", "qc_scf_iterate",
-           "qc_scf_orbital_energies", "qc_scf_density", "qc_scf_timings", "qc_scf_end", "qc_fock_profile_tiers", "qc_sym_eig_warm"]
+           "qc_scf_orbital_energies", "qc_scf_density", "qc_scf_timings", "qc_scf_end", "qc_fock_profile_tiers", "qc_sym_eig_warm", "qc_set_fock_mode", "qc_scf_tensor_ms"]
 
 
 class QcError(RuntimeError):
@@ -114,6 +114,8 @@ def lib():
         L.qc_work_stats_get.argtypes = [vp, C.POINTER(WorkStats)]
         L.qc_fock_profile.argtypes = [vp, vp, vp, C.c_int, vp, vp, vp, vp, vp, vp]
         L.qc_fock_profile_tiers.argtypes = [vp, vp, vp, C.c_int, vp, vp, vp, vp, vp]
+        L.qc_set_fock_mode.argtypes = [vp, C.c_int]
+        L.qc_scf_tensor_ms.argtypes = [vp]; L.qc_scf_tensor_ms.restype = C.c_double
         L.qc_scf_begin_rhf.argtypes = [vp, C.POINTER(vp)]
         L.qc_scf_begin_uhf.argtypes = [vp, C.c_int, C.c_int, C.POINTER(vp)]
         L.qc_scf_iterate.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_double)]
@@ -193,6 +195,10 @@ class System:
         V = np.zeros((n, n)); w = np.zeros(n)
         _check(lib().qc_sym_eig_warm(self._h, n, A, np.ascontiguousarray(V0, np.float64), V, w), "qc_sym_eig_warm"); return V, w
 
+    def set_fock_mode(self, mode: str):
+        """'direct' (default) or 'stored' (the reference's conventional algorithm, tensor resident in HBM)."""
+        _check(lib().qc_set_fock_mode(self._h, {"direct": 0, "stored": 1}[mode]), "qc_set_fock_mode")
+
     def set_shard(self, rank, nranks): _check(lib().qc_set_shard(self._h, rank, nranks), "qc_set_shard")
 
     def plan_shard(self, rank, nranks):
@@ -264,6 +270,9 @@ class ScfStepper:
 
     def density(self, spin=0):
         D = np.zeros((self.system.n, self.system.n)); _check(lib().qc_scf_density(self._st, spin, D), "qc_scf_density"); return D
+
+    def tensor_ms(self):
+        return lib().qc_scf_tensor_ms(self._st)
 
     def timings(self):
         a, b, c = C.c_double(), C.c_double(), C.c_double()
