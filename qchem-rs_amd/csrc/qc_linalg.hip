@@ -673,34 +673,83 @@ void qc_permute_tensor(hipStream_t st, int n, const double *I, double c_direct, 
                        T);
 }
 
-// One workgroup per upper-triangle row (i <= j).  G[i,j] = G[j,i] = <T1[i,j,:], D1> + <T2[i,j,:], D2> (T2/D2 optional).
-__global__ __launch_bounds__(256) void qc_tensor_gemv_kernel(int n, const double *__restrict__ T1, const double *__restrict__ D1,
-                                                             const double *__restrict__ T2, const double *__restrict__ D2, double *__restrict__ G) {
-    __shared__ double sh[4];
-    // row index -> (i, j), i <= j
-    const int row = blockIdx.x;
-    int i = (int)((2.0 * n + 1.0 - sqrt((2.0 * n + 1.0) * (2.0 * n + 1.0) - 8.0 * row)) * 0.5);
-    while (i > 0 && (size_t)i * n - (size_t)i * (i - 1) / 2 > (size_t)row) --i;
-    while ((size_t)(i + 1) * n - (size_t)(i + 1) * i / 2 <= (size_t)row) ++i;
-    const int j = i + (row - (int)((size_t)i * n - (size_t)i * (i - 1) / 2));
-    const size_t nn = (size_t)n * n, base = ((size_t)i * n + j) * nn;
-    const double2 *t1 = reinterpret_cast<const double2 *>(T1 + base), *d1 = reinterpret_cast<const double2 *>(D1);
-    double acc = 0.0;
-    const size_t nv = nn / 2;
-    for (size_t x = threadIdx.x; x < nv; x += 256) { const double2 a = t1[x], b = d1[x]; acc = fma(a.x, b.x, fma(a.y, b.y, acc)); }
-    if ((nn & 1) && threadIdx.x == 0) acc = fma(T1[base + nn - 1], D1[nn - 1], acc);
-    if (T2) {
-        const double2 *t2 = reinterpret_cast<const double2 *>(T2 + base), *d2 = reinterpret_cast<const double2 *>(D2);
-        for (size_t x = threadIdx.x; x < nv; x += 256) { const double2 a = t2[x], b = d2[x]; acc = fma(a.x, b.x, fma(a.y, b.y, acc)); }
-        if ((nn & 1) && threadIdx.x == 0) acc = fma(T2[base + nn - 1], D2[nn - 1], acc);
+// Persistent workgroups, each streaming a strided set of upper-triangle rows (i <= j) of the tensor(s) against the
+// density held in LDS (n^2 doubles: 27 KB at n = 58, 104 KB at n = 114; larger n read D through L2 instead).
+// G[i,j] = G[j,i] = <T1[i,j,:], D1> + <T2[i,j,:], D2>   (T2/D2 optional).  16-byte loads.
+constexpr int QC_GEMV_THREADS = 512;
+template <bool D_IN_LDS>
+__global__ __launch_bounds__(QC_GEMV_THREADS) void qc_tensor_gemv_kernel(int n, const double *__restrict__ T1, const double *__restrict__ D1,
+                                                                         const double *__restrict__ T2, const double *__restrict__ D2,
+                                                                         double *__restrict__ G) {
+    extern __shared__ double sd[];
+    __shared__ double sh[QC_GEMV_THREADS / 64];
+    const size_t nn = (size_t)n * n, nv = nn / 2;
+    const int tid = threadIdx.x, nrows = n * (n + 1) / 2;
+    const double2 *d1 = reinterpret_cast<const double2 *>(D1), *d2 = reinterpret_cast<const double2 *>(D2);
+    if (D_IN_LDS) {
+        for (size_t x = tid; x < nn; x += QC_GEMV_THREADS) { sd[x] = D1[x]; if (T2) sd[nn + (nn & 1) + x] = D2[x]; }
+        __syncthreads();
+        d1 = reinterpret_cast<const double2 *>(sd);
+        d2 = reinterpret_cast<const double2 *>(sd + nn + (nn & 1));
     }
-    acc = block_sum_256(acc, sh);
-    if (threadIdx.x == 0) { G[(size_t)i * n + j] = acc; G[(size_t)j * n + i] = acc; }
+    for (int row = blockIdx.x; row < nrows; row += gridDim.x) {
+        int i = (int)((2.0 * n + 1.0 - sqrt((2.0 * n + 1.0) * (2.0 * n + 1.0) - 8.0 * row)) * 0.5);
+        while (i > 0 && (size_t)i * n - (size_t)i * (i - 1) / 2 > (size_t)row) --i;
+        while ((size_t)(i + 1) * n - (size_t)(i + 1) * i / 2 <= (size_t)row) ++i;
+        const int j = i + (row - (int)((size_t)i * n - (size_t)i * (i - 1) / 2));
+        const size_t base = ((size_t)i * n + j) * nn;
+        double acc = 0.0;
+        {
+            const double2 *t1 = reinterpret_cast<const double2 *>(T1 + base);
+            double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+            size_t x = tid;
+            for (; x + 3 * QC_GEMV_THREADS < nv; x += 4 * QC_GEMV_THREADS) {        // 4 independent 16-byte loads in flight per lane
+                const double2 p0 = t1[x], p1 = t1[x + QC_GEMV_THREADS], p2 = t1[x + 2 * QC_GEMV_THREADS], p3 = t1[x + 3 * QC_GEMV_THREADS];
+                const double2 q0 = d1[x], q1 = d1[x + QC_GEMV_THREADS], q2 = d1[x + 2 * QC_GEMV_THREADS], q3 = d1[x + 3 * QC_GEMV_THREADS];
+                a0 = fma(p0.x, q0.x, fma(p0.y, q0.y, a0)); a1 = fma(p1.x, q1.x, fma(p1.y, q1.y, a1));
+                a2 = fma(p2.x, q2.x, fma(p2.y, q2.y, a2)); a3 = fma(p3.x, q3.x, fma(p3.y, q3.y, a3));
+            }
+            for (; x < nv; x += QC_GEMV_THREADS) { const double2 a = t1[x], b = d1[x]; a0 = fma(a.x, b.x, fma(a.y, b.y, a0)); }
+            acc = (a0 + a1) + (a2 + a3);
+            if ((nn & 1) && tid == 0) acc = fma(T1[base + nn - 1], D1[nn - 1], acc);
+        }
+        if (T2) {
+            const double2 *t2 = reinterpret_cast<const double2 *>(T2 + base);
+            double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+            size_t x = tid;
+            for (; x + 3 * QC_GEMV_THREADS < nv; x += 4 * QC_GEMV_THREADS) {
+                const double2 p0 = t2[x], p1 = t2[x + QC_GEMV_THREADS], p2 = t2[x + 2 * QC_GEMV_THREADS], p3 = t2[x + 3 * QC_GEMV_THREADS];
+                const double2 q0 = d2[x], q1 = d2[x + QC_GEMV_THREADS], q2 = d2[x + 2 * QC_GEMV_THREADS], q3 = d2[x + 3 * QC_GEMV_THREADS];
+                a0 = fma(p0.x, q0.x, fma(p0.y, q0.y, a0)); a1 = fma(p1.x, q1.x, fma(p1.y, q1.y, a1));
+                a2 = fma(p2.x, q2.x, fma(p2.y, q2.y, a2)); a3 = fma(p3.x, q3.x, fma(p3.y, q3.y, a3));
+            }
+            for (; x < nv; x += QC_GEMV_THREADS) { const double2 a = t2[x], b = d2[x]; a0 = fma(a.x, b.x, fma(a.y, b.y, a0)); }
+            acc += (a0 + a1) + (a2 + a3);
+            if ((nn & 1) && tid == 0) acc = fma(T2[base + nn - 1], D2[nn - 1], acc);
+        }
+        for (int o = 32; o > 0; o >>= 1) acc += __shfl_down(acc, o, 64);
+        if ((tid & 63) == 0) sh[tid >> 6] = acc;
+        __syncthreads();
+        if (tid == 0) {
+            double r = 0.0;
+            for (int k = 0; k < QC_GEMV_THREADS / 64; ++k) r += sh[k];
+            G[(size_t)i * n + j] = r; G[(size_t)j * n + i] = r;
+        }
+        __syncthreads();
+    }
 }
 void qc_tensor_gemv(hipStream_t st, int n, const double *T1, const double *D1, const double *T2, const double *D2, double *G) {
-    hipLaunchKernelGGL(qc_tensor_gemv_kernel, dim3((unsigned)((size_t)n * (n + 1) / 2)), dim3(256), 0, st, n, T1, D1, T2, D2, G);
+    const size_t nn = (size_t)n * n, lds = (T2 ? 2 : 1) * (nn + 1) * sizeof(double);
+    const int nrows = n * (n + 1) / 2;
+    if (lds <= 150 * 1024) {
+        static size_t allowed = 48 * 1024;
+        if (lds > allowed) { (void)hipFuncSetAttribute(reinterpret_cast<const void *>(qc_tensor_gemv_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); allowed = lds; }
+        const int per_cu = std::max<int>(1, std::min<int>(4, (int)(150 * 1024 / lds)));
+        hipLaunchKernelGGL(qc_tensor_gemv_kernel<true>, dim3(std::min(nrows, 256 * per_cu)), dim3(QC_GEMV_THREADS), lds, st, n, T1, D1, T2, D2, G);
+    } else {
+        hipLaunchKernelGGL(qc_tensor_gemv_kernel<false>, dim3(std::min(nrows, 256 * 4)), dim3(QC_GEMV_THREADS), 0, st, n, T1, D1, T2, D2, G);
+    }
 }
-
 
 // out[j] = <x, ys[j]>, one workgroup per j (diis.rs:43-45)
 struct QcPtrList { const double *p[16]; };
