@@ -49,6 +49,7 @@ def timed_steps(torch, dist, stepper, steps, warmup, world):
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
+    tm0 = stepper.timings()
     t0 = time.perf_counter()
     for _ in range(steps):
         stepper.iterate()          # synchronises the library's stream at the end of every pass
@@ -60,16 +61,19 @@ def timed_steps(torch, dist, stepper, steps, warmup, world):
         t = torch.tensor([dt], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
+    tm1 = stepper.timings()
+    stepper.timed = {k: (tm1[k] - tm0[k]) / steps for k in ("fock", "linalg")}   # hipEvent ms per timed step
     return dt
 
 
 def roofline(torch, sysh, D_host, reps):
     """hipEvent timing (on the library's stream) of the kernels a Fock build launches.
 
-    A build = at most 14 `qc_fock_tier_kernel<LAB, TIER>` launches (all class buckets of bra class LAB with LCD <= 3 /
-    LCD >= 4) that run concurrently on side streams.  The roofline entry is the tier kernel that takes the longest when
+    A build = at most 18 launches: `qc_fock_tier_kernel<LAB, TIER>` (all class buckets of bra class LAB with LCD <= 3 /
+    LCD >= 4) and `qc_fock_bm_kernel<LCD, HI>` (bra-major kernels for ss / ps kets), concurrent on side streams.  The roofline entry is the tier kernel that takes the longest when
     each is launched alone; `fock_build` gives the same ratios for the whole (overlapped) build, `classes` the per-bucket
     view.  Algorithmic bytes/flops: SURVEY.md 8(d) per-quartet model summed over the quartets a launch processes."""
+    import qchem_rs_amd as q
     dD = torch.from_numpy(D_host).cuda()
     dG = torch.zeros_like(dD)
     torch.cuda.synchronize()
@@ -77,14 +81,14 @@ def roofline(torch, sysh, D_host, reps):
     prof = sysh.fock_profile(dD.data_ptr(), dG.data_ptr(), max(1, reps // 2))
     k = int(tp["unit_ms"].argmax())
     ws = sysh.work_stats()
-    cname = lambda c: "<%d, %d, %d>" % (int(c) >> 8, (int(c) >> 4) & 15, int(c) & 15)
+    cname = lambda c: ("bm<%d, %d>" % ((int(c) >> 8) & 15, (int(c) >> 4) & 15)) if int(c) >> 12 else "<%d, %d, %d>" % (int(c) >> 8, (int(c) >> 4) & 15, int(c) & 15)
     order = prof["class_ms"].argsort()[::-1][:10]
     top = [{"class": cname(prof["class_id"][i]), "ms": float(prof["class_ms"][i]),
             "quartets": int(prof["quartets"][i]), "GF": float(prof["flops"][i]) / 1e9} for i in order]
-    tiers = [{"kernel": "qc_fock_tier_kernel<%d, %d>" % (u // 2, u % 2), "ms_alone": float(tp["unit_ms"][u]), "quartets": int(tp["quartets"][u]),
+    tiers = [{"kernel": q.hf.unit_name(u), "ms_alone": float(tp["unit_ms"][u]), "quartets": int(tp["quartets"][u]),
               "alg_MB": float(tp["bytes"][u]) / 1e6, "alg_GF": float(tp["flops"][u]) / 1e9,
               "GBs_alone": float(tp["bytes"][u]) / (float(tp["unit_ms"][u]) * 1e-3) / 1e9,
-              "TFLOPs_alone": float(tp["flops"][u]) / (float(tp["unit_ms"][u]) * 1e-3) / 1e12} for u in range(14) if tp["quartets"][u] > 0]
+              "TFLOPs_alone": float(tp["flops"][u]) / (float(tp["unit_ms"][u]) * 1e-3) / 1e12} for u in range(len(tp["unit_ms"])) if tp["quartets"][u] > 0]
     tot_ms = float(tp["total_ms"])
     gbs = float(ws.bytes_alg) / (tot_ms * 1e-3) / 1e9
     tfs = float(ws.flops_alg) / (tot_ms * 1e-3) / 1e12
@@ -95,13 +99,13 @@ def roofline(torch, sysh, D_host, reps):
     # by itself; profiles/ holds the rocprofv3 --stats summary with the same kernels.
     return {
         "bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS, "traffic": None,
-        "kernel": "qc_fock_tier_kernel<LAB, TIER> x %d concurrent launches = one Fock build" % len(tiers), "kernel_ms": tot_ms,
+        "kernel": "qc_fock_tier_kernel<LAB, TIER> + qc_fock_bm_kernel<LCD, HI>: %d concurrent launches = one Fock build" % len(tiers), "kernel_ms": tot_ms,
         "kernel_quartets": int(ws.quartets), "kernel_alg_bytes": float(ws.bytes_alg), "kernel_alg_flops": float(ws.flops_alg),
         "note": "f64 gather-compute-scatter on the FP64 ridge (SURVEY 8d): both roofs are given; the binding one is fp64_valu",
         "fp64_valu": {"achieved": tfs, "peak": FP64_VALU_PEAK_TF, "unit": "TFLOP/s", "frac": tfs / FP64_VALU_PEAK_TF},
         "fock_build": {"ms": tot_ms, "sum_tier_kernels_serial_ms": float(tp["unit_ms"].sum()), "launches": len(tiers),
                        "quartets_per_s": float(ws.quartets) / (tot_ms * 1e-3),
-                       "slowest_tier_alone": "qc_fock_tier_kernel<%d, %d>" % (k // 2, k % 2),
+                       "slowest_tier_alone": q.hf.unit_name(k),
                        "tiers_alone": tiers, "top_classes_serial": top},
     }
 
@@ -165,8 +169,7 @@ def main():
     stepper = q.ScfStepper(sysh)
     dt = timed_steps(torch, dist, stepper, args.steps, args.warmup, world)
     D = stepper.density(0)
-    tm = stepper.timings()
-    tot_it = args.steps + args.warmup
+    tm = stepper.timed
     line = {
         "metric": "ERI shell-quartets/sec through one SCF iteration (ms_per_step = SCF iter time), RHF",
         "value": nq_total * args.steps / dt, "unit": "shell-quartets/s", "n_gpus": world, "steps": args.steps,
@@ -175,7 +178,7 @@ def main():
         "data": "fixture molecule + basis files under data/ (no randomness); densities are the SCF's own iterates",
         "config": {"workload": WORKLOADS[key][2] + " direct-SCF iteration", "n_basis": sysh.n, "unique_quartets": int(nq_total),
                    "parallelism": "1 GPU" if world == 1 else "quartet shards over %d GPUs + 1 RCCL all-reduce of G per build" % world},
-        "iter_breakdown_ms": {"fock_build": tm["fock"] / tot_it, "diis_eig_density": tm["linalg"] / tot_it},
+        "iter_breakdown_ms": {"fock_build": tm["fock"], "diis_eig_density": tm["linalg"]},
     }
     rf = roofline(torch, sysh, D, reps=5)      # collective when sharded: every rank calls it
     stepper.close()
@@ -198,19 +201,19 @@ def main():
             st2 = q.ScfStepper(s2)
             k2 = max(3, min(args.steps, 5))
             dt2 = timed_steps(torch, dist, st2, k2, 1, 1)
-            tm2 = st2.timings()
+            tm2 = st2.timed
             st2.close()
             line["scaling_reference"] = {"workload": WORKLOADS["c6h6_ccpvdz"][2] + " direct-SCF iteration", "n_gpus": 1,
                                          "value": s2.n_quartets() * k2 / dt2, "ms_per_step": dt2 * 1e3 / k2, "steps": k2,
-                                         "fock_build_ms": tm2["fock"] / (k2 + 1), "unique_quartets": int(s2.n_quartets())}
+                                         "fock_build_ms": tm2["fock"], "unique_quartets": int(s2.n_quartets())}
         if key in ("h2o_ccpvtz", "h2o_sto3g", "c6h6_ccpvdz"):
             # the reference's own (conventional) algorithm on the same GPU: tensor resident in HBM, one streaming GEMV per pass
             s3 = q.System(mol); s3.set_fock_mode("stored")
             st3 = q.ScfStepper(s3)
             dt3 = timed_steps(torch, dist, st3, args.steps, args.warmup, 1)
-            tm3 = st3.timings(); n3 = s3.n
+            tm3 = st3.timed; n3 = s3.n
             gemv_bytes = 8.0 * (n3 * (n3 + 1) // 2) * n3 * n3
-            fock_ms3 = tm3["fock"] / (args.steps + args.warmup)
+            fock_ms3 = tm3["fock"]
             line["stored_mode"] = {"ms_per_step": dt3 * 1e3 / args.steps, "tensor_build_ms": st3.tensor_ms(),
                                    "tensor_build_quartets_per_s": nq_total / (st3.tensor_ms() * 1e-3),
                                    "gemv_ms": fock_ms3, "gemv_alg_bytes": gemv_bytes,

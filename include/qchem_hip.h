@@ -160,13 +160,16 @@ typedef struct {
 } qc_work_stats;
 int qc_work_stats_get(qc_system *sys, qc_work_stats *out);
 /* Time `reps` Fock builds (RHF digestion of dD) per kernel class with hipEvents on the handle's stream.
- * class_ms: caller buffer of `nclasses` floats (average ms per launch of each class kernel); class_id: (LAB << 8) | (LCD << 4) | LGC,
- * i.e. the template arguments of qc_fock_class_kernel<LAB, LCD, LGC>. */
+ * class_ms: caller buffer of `nclasses` floats (average ms per launch of each class bucket); class_id: (BM << 12) | (LAB << 8) |
+ * (LCD << 4) | LGC: Hermite orders of the bra / ket pairs, log2 of the lane-group width, BM = 1 for the bra-major kernels. */
 int qc_fock_profile(qc_system *sys, const double *dD, double *dG, int reps, float *class_ms, int32_t *class_id,
                     int64_t *class_quartets, double *class_bytes, double *class_flops, float *total_ms);
 
-/* Same for the launch units of an un-instrumented build: kernel qc_fock_tier_kernel<LAB, TIER> gathers every class
- * bucket of bra class LAB with LCD <= 3 (TIER 0) or LCD >= 4 (TIER 1).  All arrays: 14 entries, unit = 2 * LAB + TIER. */
+/* Same for the launch units of an un-instrumented build.  Units 0..13: kernel qc_fock_tier_kernel<LAB, TIER> gathers every
+ * class bucket of bra class LAB with LCD <= 3 (TIER 0) or LCD >= 4 (TIER 1), unit = 2 * LAB + TIER.  Units 14..17: the
+ * bra-major kernels qc_fock_bm_kernel<LCD, HI> (ket pair ss / ps, bra class LAB <= 2 / LAB >= 3), unit = 14 + 2 * LCD + HI.
+ * All arrays: QC_PROFILE_UNITS entries. */
+#define QC_PROFILE_UNITS 18
 int qc_fock_profile_tiers(qc_system *sys, const double *dD, double *dG, int reps, float *unit_ms, int64_t *unit_quartets,
                           double *unit_bytes, double *unit_flops, float *total_ms);
 

@@ -666,19 +666,23 @@ int qc_plan_shard(qc_system *S, int rank, int nranks, int64_t *nquartets, double
 // list the quartets of a shard as (shell A, B, C, D) so a host-side checker can digest exactly the same units
 int qc_plan_shard_quartets(qc_system *S, int rank, int nranks, int32_t *abcd /* 4 * nquartets or NULL */, int64_t capacity) {
     if (!S || nranks <= 0 || rank < 0 || rank >= nranks) return QC_ERR_INVALID;
+    const int r0 = S->rank, n0 = S->nranks;
+    S->rank = rank; S->nranks = nranks;
+    qc_build_shards(S);                                   // exactly the lists the device would be given
     int64_t k = 0;
-    for (size_t ci = 0; ci < S->classes.size(); ++ci) {
-        const auto &c = S->classes[ci];
-        for (size_t i = 0; i < c.tasks.size(); ++i) {
-            if (qc_shard_owner(i, nranks, ci) != rank) continue;
+    bool overflow = false;
+    for (const auto &c : S->classes)
+        for (const auto &t : c.shard) {
             if (abcd) {
-                if (k >= capacity) return QC_ERR_INVALID;
-                abcd[4 * k + 0] = S->pairA[c.tasks[i].bra]; abcd[4 * k + 1] = S->pairB[c.tasks[i].bra];
-                abcd[4 * k + 2] = S->pairA[c.tasks[i].ket]; abcd[4 * k + 3] = S->pairB[c.tasks[i].ket];
+                if (k >= capacity) { overflow = true; break; }
+                abcd[4 * k + 0] = S->pairA[t.bra]; abcd[4 * k + 1] = S->pairB[t.bra];
+                abcd[4 * k + 2] = S->pairA[t.ket]; abcd[4 * k + 3] = S->pairB[t.ket];
             }
             ++k;
         }
-    }
+    S->rank = r0; S->nranks = n0;
+    qc_build_shards(S);
+    if (overflow) return QC_ERR_INVALID;
     return (int)k;
 }
 
@@ -724,7 +728,7 @@ int qc_fock_profile(qc_system *S, const double *dD, double *dG, int reps, float 
         const QcClass &c = S->classes[i];
         if (c.shard.empty()) continue;
         if (class_ms) class_ms[k] = acc[i] / reps;
-        if (class_id) class_id[k] = (c.LAB << 8) | (c.LCD << 4) | c.LGC;
+        if (class_id) class_id[k] = (c.bm ? 1 << 12 : 0) | (c.LAB << 8) | (c.LCD << 4) | c.LGC;
         if (class_quartets) class_quartets[k] = (int64_t)c.shard.size();
         if (class_bytes) class_bytes[k] = c.bytes_alg;
         if (class_flops) class_flops[k] = c.flops_alg;
@@ -742,7 +746,7 @@ int qc_fock_profile_tiers(qc_system *S, const double *dD, double *dG, int reps, 
     int rc = qc_device_init(S);
     if (rc != QC_OK) return rc;
     const size_t nn = (size_t)S->nbasis * S->nbasis;
-    const int NU = 2 * (QC_LPAIR + 1);
+    const int NU = QC_NUNITS;
     std::vector<float> acc(NU, 0.f), one(NU, 0.f);
     float tot = 0.f;
     hipEvent_t e0, e1;
@@ -769,7 +773,7 @@ int qc_fock_profile_tiers(qc_system *S, const double *dD, double *dG, int reps, 
     }
     for (const auto &c : S->classes) {
         if (c.shard.empty()) continue;
-        const int u = 2 * c.LAB + (c.LCD >= 4 ? 1 : 0);
+        const int u = qc_unit_of(c.LAB, c.LCD, c.bm);
         if (unit_quartets) unit_quartets[u] += (int64_t)c.shard.size();
         if (unit_bytes) unit_bytes[u] += c.bytes_alg;
         if (unit_flops) unit_flops[u] += c.flops_alg;

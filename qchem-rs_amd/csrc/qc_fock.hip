@@ -3,6 +3,7 @@
 #include <vector>
 
 #include "qc_fock_kernel.h"
+#include "qc_fock_bm.h"
 
 int qc_launch_tier_lab0(int, int, size_t, hipStream_t, const QcTierArgs &);
 int qc_launch_tier_lab1(int, int, size_t, hipStream_t, const QcTierArgs &);
@@ -34,9 +35,18 @@ int qc_device_ready(void) {
 static int upload_slots(qc_system *S) {
     for (auto &c : S->classes) {
         if (c.d_slots) { (void)hipFree(c.d_slots); c.d_slots = nullptr; }
-        if (c.slots.empty()) continue;
-        QC_HIP_CHECK(hipMalloc(&c.d_slots, c.slots.size() * sizeof(QcSlot)));
-        QC_HIP_CHECK(hipMemcpy(c.d_slots, c.slots.data(), c.slots.size() * sizeof(QcSlot), hipMemcpyHostToDevice));
+        if (c.d_bundles) { (void)hipFree(c.d_bundles); c.d_bundles = nullptr; }
+        if (c.d_ketlist) { (void)hipFree(c.d_ketlist); c.d_ketlist = nullptr; }
+        if (!c.slots.empty()) {
+            QC_HIP_CHECK(hipMalloc(&c.d_slots, c.slots.size() * sizeof(QcSlot)));
+            QC_HIP_CHECK(hipMemcpy(c.d_slots, c.slots.data(), c.slots.size() * sizeof(QcSlot), hipMemcpyHostToDevice));
+        }
+        if (!c.bundles.empty()) {
+            QC_HIP_CHECK(hipMalloc(&c.d_bundles, c.bundles.size() * sizeof(QcBundle)));
+            QC_HIP_CHECK(hipMemcpy(c.d_bundles, c.bundles.data(), c.bundles.size() * sizeof(QcBundle), hipMemcpyHostToDevice));
+            QC_HIP_CHECK(hipMalloc(&c.d_ketlist, c.ketlist.size() * sizeof(int)));
+            QC_HIP_CHECK(hipMemcpy(c.d_ketlist, c.ketlist.data(), c.ketlist.size() * sizeof(int), hipMemcpyHostToDevice));
+        }
     }
     return QC_OK;
 }
@@ -73,6 +83,8 @@ int qc_device_init(qc_system *S) {
     const size_t nn = (size_t)S->nbasis * S->nbasis;
     QC_HIP_CHECK(hipMalloc(&S->d_pairdata, S->pairdata.size() * sizeof(double)));
     QC_HIP_CHECK(hipMemcpy(S->d_pairdata, S->pairdata.data(), S->pairdata.size() * sizeof(double), hipMemcpyHostToDevice));
+    QC_HIP_CHECK(hipMalloc(&S->d_pairdataT, S->pairdataT.size() * sizeof(double)));
+    QC_HIP_CHECK(hipMemcpy(S->d_pairdataT, S->pairdataT.data(), S->pairdataT.size() * sizeof(double), hipMemcpyHostToDevice));
     QC_HIP_CHECK(hipMalloc(&S->d_pairs, S->pairs.size() * sizeof(QcPairDesc)));
     QC_HIP_CHECK(hipMemcpy(S->d_pairs, S->pairs.data(), S->pairs.size() * sizeof(QcPairDesc), hipMemcpyHostToDevice));
     std::vector<double> tab((size_t)(QC_LTOT + 1) * QC_BOYS_NGRID * 8), row(QC_BOYS_NORD);
@@ -96,11 +108,15 @@ int qc_device_init(qc_system *S) {
 
 void qc_device_free(qc_system *S) {
     qc_drop_graphs(S);
-    for (auto &c : S->classes) if (c.d_slots) { (void)hipFree(c.d_slots); c.d_slots = nullptr; }
-    void *ptrs[] = {S->d_pairdata, S->d_pairs, S->d_boys, S->d_D, S->d_G, S->d_Gtmp, S->d_Dj, S->d_flag};
+    for (auto &c : S->classes) {
+        if (c.d_slots) { (void)hipFree(c.d_slots); c.d_slots = nullptr; }
+        if (c.d_bundles) { (void)hipFree(c.d_bundles); c.d_bundles = nullptr; }
+        if (c.d_ketlist) { (void)hipFree(c.d_ketlist); c.d_ketlist = nullptr; }
+    }
+    void *ptrs[] = {S->d_pairdata, S->d_pairdataT, S->d_pairs, S->d_boys, S->d_D, S->d_G, S->d_Gtmp, S->d_Dj, S->d_flag};
     S->d_flag = nullptr;
     for (void *p : ptrs) if (p) (void)hipFree(p);
-    S->d_pairdata = nullptr; S->d_pairs = nullptr; S->d_boys = S->d_D = S->d_G = S->d_Gtmp = S->d_Dj = nullptr;
+    S->d_pairdata = S->d_pairdataT = nullptr; S->d_pairs = nullptr; S->d_boys = S->d_D = S->d_G = S->d_Gtmp = S->d_Dj = nullptr;
     for (int i = 0; i < QC_NSTREAMS; ++i) {
         if (S->side[i]) (void)hipStreamDestroy(S->side[i]);
         if (S->ev_join[i]) (void)hipEventDestroy(S->ev_join[i]);
@@ -120,10 +136,29 @@ static QcKernelArgs base_args(qc_system *S, const QcFockArgs &fa) {
     return a;
 }
 
-// segment of one launch: a class bucket with its slots
-struct Seg { const QcClass *c; const QcSlot *d_slots; int nslots; };
+// segment of one launch: a class bucket with its slots (column kernels) or bundles (bra-major kernels)
+struct Seg { const QcClass *c; const QcSlot *d_slots; int nslots; const QcBundle *d_bundles = nullptr; const int *d_ketlist = nullptr; int lds = 0; };
 
-static int launch_segments(int lab, int tier, const std::vector<Seg> &segs, hipStream_t st, const QcKernelArgs &base) {
+static Seg seg_of(const QcClass &c) {
+    if (c.bm) return Seg{&c, nullptr, (int)c.bundles.size(), c.d_bundles, c.d_ketlist, c.lds_bytes};
+    return Seg{&c, c.d_slots, (int)c.slots.size()};
+}
+
+static int launch_segments(qc_system *S, int unit, const std::vector<Seg> &segs, hipStream_t st, const QcKernelArgs &base) {
+    if (unit >= 2 * (QC_LPAIR + 1)) {      // bra-major launch
+        QcBmArgs t{};
+        t.base = base; t.pairdataT = S->d_pairdataT;
+        int grid = 0, lds = 0, k = 0;
+        for (const Seg &sg : segs) {
+            grid += sg.nslots;
+            t.seg_end[k] = grid; t.seg_lab[k] = sg.c->LAB; t.seg_bundles[k] = sg.d_bundles; t.seg_ketlist[k] = sg.d_ketlist;
+            lds = std::max(lds, sg.lds);
+            ++k;
+        }
+        t.nseg = k;
+        const int v = unit - 2 * (QC_LPAIR + 1);
+        return qc_launch_bm(v / 2, v % 2, grid, (size_t)lds, st, t);
+    }
     QcTierArgs t{};
     t.base = base;
     int grid = 0, lds = 0, k = 0;
@@ -137,16 +172,17 @@ static int launch_segments(int lab, int tier, const std::vector<Seg> &segs, hipS
         ++k;
     }
     t.nseg = k;
-    return launch_tier(lab, tier, grid, (size_t)lds, st, t);
+    return launch_tier(unit / 2, unit % 2, grid, (size_t)lds, st, t);
 }
 
-// Launch units of one build: per bra class LAB, tier 0 (LCD <= 3) and tier 1 (LCD >= 4); segments heaviest first.
+// Launch units of one build: per bra class LAB, tier 0 (LCD <= 3) and tier 1 (LCD >= 4) of the column kernels, plus
+// the four bra-major launches (ket type x bra range); segments heaviest first.
 static void tier_units(qc_system *S, std::vector<std::vector<int>> &units) {
-    units.assign(2 * (QC_LPAIR + 1), {});
+    units.assign(QC_NUNITS, {});
     for (size_t ci = 0; ci < S->classes.size(); ++ci) {
         const QcClass &c = S->classes[ci];
-        if (c.slots.empty()) continue;
-        units[2 * c.LAB + (c.LCD >= 4 ? 1 : 0)].push_back((int)ci);
+        if (c.slots.empty() && c.bundles.empty()) continue;
+        units[qc_unit_of(c.LAB, c.LCD, c.bm)].push_back((int)ci);
     }
     for (auto &u : units)
         std::stable_sort(u.begin(), u.end(), [&](int x, int y) {
@@ -166,7 +202,7 @@ int qc_launch_fock_classes(qc_system *S, const QcFockArgs &fa, float *class_ms, 
     tier_units(S, units);
     auto segs_of = [&](const std::vector<int> &u) {
         std::vector<Seg> v;
-        for (int ci : u) v.push_back(Seg{&S->classes[ci], S->classes[ci].d_slots, (int)S->classes[ci].slots.size()});
+        for (int ci : u) v.push_back(seg_of(S->classes[ci]));
         return v;
     };
     if (class_ms || unit_ms) {
@@ -177,15 +213,15 @@ int qc_launch_fock_classes(qc_system *S, const QcFockArgs &fa, float *class_ms, 
         if (class_ms) {
             for (size_t ci = 0; ci < S->classes.size(); ++ci) {
                 const QcClass &c = S->classes[ci];
-                if (!c.slots.empty()) {
-                    int rc = launch_segments(c.LAB, c.LCD >= 4 ? 1 : 0, {Seg{&c, c.d_slots, (int)c.slots.size()}}, S->stream, a);
+                if (!c.slots.empty() || !c.bundles.empty()) {
+                    int rc = launch_segments(S, qc_unit_of(c.LAB, c.LCD, c.bm), {seg_of(c)}, S->stream, a);
                     if (rc != QC_OK) return rc;
                 }
                 QC_HIP_CHECK(hipEventRecord(ev[ci + 1], S->stream));
             }
         } else {
             for (size_t u = 0; u < units.size(); ++u) {
-                if (!units[u].empty()) { int rc = launch_segments((int)u / 2, (int)u % 2, segs_of(units[u]), S->stream, a); if (rc != QC_OK) return rc; }
+                if (!units[u].empty()) { int rc = launch_segments(S, (int)u, segs_of(units[u]), S->stream, a); if (rc != QC_OK) return rc; }
                 QC_HIP_CHECK(hipEventRecord(ev[u + 1], S->stream));
             }
         }
@@ -224,7 +260,7 @@ int qc_launch_fock_classes(qc_system *S, const QcFockArgs &fa, float *class_ms, 
         const int k = S->unit_stream[u];
         hipStream_t st = S->side[k];
         if (!used[k]) { QC_HIP_CHECK(hipStreamWaitEvent(st, S->ev_fork, 0)); used[k] = true; }
-        int rc = launch_segments(u / 2, u % 2, segs_of(units[u]), st, a);
+        int rc = launch_segments(S, u, segs_of(units[u]), st, a);
         if (rc != QC_OK) return rc;
     }
     for (int k = 0; k < QC_NSTREAMS; ++k) {
@@ -241,13 +277,30 @@ int qc_launch_eri_full(qc_system *S, double *d_out) {
     fa.eri_out = d_out;
     const QcKernelArgs a = base_args(S, fa);
     std::vector<QcSlot> slots;
+    std::vector<QcBundle> bundles; std::vector<int> ketlist;
     for (const auto &c : S->classes) {
+        if (c.bm) {
+            qc_make_bundles(S, c.tasks, 0, bundles, ketlist);
+            if (bundles.empty()) continue;
+            QcBundle *db = nullptr; int *dk = nullptr;
+            QC_HIP_CHECK(hipMalloc(&db, bundles.size() * sizeof(QcBundle)));
+            QC_HIP_CHECK(hipMalloc(&dk, ketlist.size() * sizeof(int)));
+            QC_HIP_CHECK(hipMemcpyAsync(db, bundles.data(), bundles.size() * sizeof(QcBundle), hipMemcpyHostToDevice, S->stream));
+            QC_HIP_CHECK(hipMemcpyAsync(dk, ketlist.data(), ketlist.size() * sizeof(int), hipMemcpyHostToDevice, S->stream));
+            int mx = 0;
+            for (const auto &t : c.tasks) mx = std::max(mx, S->pairs[t.bra].na * S->pairs[t.bra].nb * S->pairs[t.ket].na * S->pairs[t.ket].nb);
+            int rc = launch_segments(S, qc_unit_of(c.LAB, c.LCD, true), {Seg{&c, nullptr, (int)bundles.size(), db, dk, mx * 65 * 8}}, S->stream, a);
+            QC_HIP_CHECK(hipStreamSynchronize(S->stream));
+            (void)hipFree(db); (void)hipFree(dk);
+            if (rc != QC_OK) return rc;
+            continue;
+        }
         qc_make_slots(S, c.tasks, 0, slots);
         if (slots.empty()) continue;
         QcSlot *d = nullptr;
         QC_HIP_CHECK(hipMalloc(&d, slots.size() * sizeof(QcSlot)));
         QC_HIP_CHECK(hipMemcpyAsync(d, slots.data(), slots.size() * sizeof(QcSlot), hipMemcpyHostToDevice, S->stream));
-        int rc = launch_segments(c.LAB, c.LCD >= 4 ? 1 : 0, {Seg{&c, d, (int)slots.size()}}, S->stream, a);
+        int rc = launch_segments(S, qc_unit_of(c.LAB, c.LCD, false), {Seg{&c, d, (int)slots.size()}}, S->stream, a);
         QC_HIP_CHECK(hipStreamSynchronize(S->stream));
         (void)hipFree(d);
         if (rc != QC_OK) return rc;

@@ -459,7 +459,7 @@ __global__ __launch_bounds__(64) void qc_fock_tier_kernel(const QcTierArgs a) {
     const int nslots = a.seg_nslots[s], words = a.seg_words[s];
 #define QC_CASE(LCD, LGC) case ((LCD) << 4 | (LGC)): qc_fock_body<LAB, LCD, LGC>(a.base, slots, nslots, words, blk, nblk); break;
     if constexpr (TIER == 0) {
-        switch (a.seg_code[s]) { QC_CASE(0, 0) QC_CASE(1, 2) QC_CASE(2, 3) QC_CASE(2, 4) QC_CASE(3, 3) QC_CASE(3, 4) QC_CASE(3, 5) default: break; }
+        switch (a.seg_code[s]) { QC_CASE(2, 3) QC_CASE(2, 4) QC_CASE(3, 3) QC_CASE(3, 4) QC_CASE(3, 5) default: break; }
     } else {
         switch (a.seg_code[s]) { QC_CASE(4, 5) QC_CASE(4, 6) QC_CASE(5, 6) QC_CASE(6, 6) default: break; }
     }

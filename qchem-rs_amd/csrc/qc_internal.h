@@ -25,6 +25,7 @@ __host__ __device__ constexpr int qc_region0(int L, int lgc) {
 constexpr double QC_PRIM_CUTOFF = 1e-17; // primitive pairs whose Hermite expansion block is entirely below this are dropped
 constexpr int QC_NREP = 32;             // replicas of the Fock accumulation buffer
 constexpr int QC_NSTREAMS = 7;          // class kernels of one build run concurrently on this many streams
+constexpr int QC_NUNITS = 2 * (QC_LPAIR + 1) + 4;   // launch units of one build: (LAB, tier) of the column kernels + 4 bra-major launches
 
 __host__ __device__ constexpr int qc_nherm(int L) { return (L + 1) * (L + 2) * (L + 3) / 6; }
 __host__ __device__ constexpr int qc_ncart(int L) { return (L + 1) * (L + 2) / 2; }
@@ -56,6 +57,9 @@ struct QcPairDesc {
 
 struct QcTask { int bra, ket; };  // pair indices; (bra|ket) is one unique shell quartet
 struct QcSlot { int bra, ket, lo, hi; };  // a quartet restricted to primitive quartets [lo, hi): the kernels' work unit
+// Work unit of the bra-major kernels (narrow kets, qc_fock_bm.hip): one wave = one bra pair restricted to the bra
+// primitive pairs [ij_lo, ij_hi), against up to 64 ket pairs (one per lane) ketlist[first .. first + nket).
+struct QcBundle { int bra, ij_lo, ij_hi, first, nket, maxK, pad0, pad1; };
 
 struct QcClass {
     int LAB, LCD, LGC;            // Hermite orders of bra / ket pairs; log2 of the lane-group width C
@@ -65,6 +69,12 @@ struct QcClass {
     QcSlot *d_slots = nullptr;    // device copy of `slots`
     int slot_words = 0;           // LDS doubles per lane group
     int lds_bytes = 0;
+    // bra-major classes (ket = ss or ps pair, LAB + LCD <= QC_LREG): `bundles` replace `slots`
+    bool bm = false;
+    std::vector<QcBundle> bundles;
+    std::vector<int> ketlist;
+    QcBundle *d_bundles = nullptr;
+    int *d_ketlist = nullptr;
     // work model of `shard`
     int64_t prim_quartets = 0;
     double bytes_alg = 0, flops_alg = 0;
@@ -79,6 +89,7 @@ struct qc_system {
     std::vector<QcPairDesc> pairs;
     std::vector<int> pairA, pairB, pairKfull;   // shells of each stored pair; its primitive-pair count before the cut-off
     std::vector<double> pairdata;
+    std::vector<double> pairdataT;              // same blocks with the expansion stored [ab][h] (bra side of the bra-major kernels)
     std::vector<QcClass> classes;
     int64_t nquartets = 0;
     int rank = 0, nranks = 1;
@@ -89,7 +100,7 @@ struct qc_system {
     bool own_stream = false;
     hipStream_t side[QC_NSTREAMS] = {};
     hipEvent_t ev_fork = nullptr, ev_join[QC_NSTREAMS] = {};
-    double *d_pairdata = nullptr;
+    double *d_pairdata = nullptr, *d_pairdataT = nullptr;
     QcPairDesc *d_pairs = nullptr;
     double *d_boys = nullptr;
     double *d_D = nullptr, *d_G = nullptr;   // 2 * n*n each (alpha/beta or Dj/Dk)
@@ -160,6 +171,9 @@ inline int qc_shard_owner(size_t i, int nranks, size_t ci) {
     return (int)((r + ci) % nranks);
 }
 void qc_make_slots(const qc_system *S, const std::vector<QcTask> &tasks, int itmax, std::vector<QcSlot> &out);
+// group tasks by bra into bundles of <= 64 kets (sorted by primitive count); itmax > 0 also cuts the bra primitive range
+void qc_make_bundles(const qc_system *S, const std::vector<QcTask> &tasks, int itmax, std::vector<QcBundle> &bundles, std::vector<int> &ketlist);
+inline int qc_unit_of(int LAB, int LCD, bool bm) { return bm ? 2 * (QC_LPAIR + 1) + 2 * LCD + (LAB >= 3 ? 1 : 0) : 2 * LAB + (LCD >= 4 ? 1 : 0); }
 void qc_dots(hipStream_t st, int n, const double *x, const double *const *ys, int ny, double *out);  // device ptr list
 void qc_lincomb(hipStream_t st, int n, const double *const *Fs, const double *c, int m, double *out);   // out = sum c_i Fs_i
 void qc_scale_cols_invsqrt(hipStream_t st, int n, const double *U, const double *Lam, double *out);

@@ -186,7 +186,7 @@ void qc_build_model(qc_system *S) {
     // shell pairs A >= B, with per-primitive-pair blocks [p, Px, Py, Pz, E(nherm x nab)].
     // The pair part of the ERI prefactor 2 pi^{5/2} / (p q sqrt(p+q)) is folded in as sqrt(2) pi^{5/4} / p.
     const double half_pref = std::sqrt(2.0) * std::pow(M_PI, 1.25);
-    S->pairs.clear(); S->pairA.clear(); S->pairB.clear(); S->pairKfull.clear(); S->pairdata.clear();
+    S->pairs.clear(); S->pairA.clear(); S->pairB.clear(); S->pairKfull.clear(); S->pairdata.clear(); S->pairdataT.clear();
     // Primitive pairs whose whole expansion block is below QC_PRIM_CUTOFF are not stored: with the Gaussian-product
     // factor exp(-mu R^2) and the coefficients folded into E, an integral is bounded by max|E_ab| max|E_cd| (times
     // O(10)), so a dropped primitive pair changes no integral by more than ~1e-16 - five orders below the 1e-10 parity
@@ -215,32 +215,46 @@ void qc_build_model(qc_system *S) {
                     if (mx < QC_PRIM_CUTOFF) continue;
                     blkbuf[0] = p; blkbuf[1] = P[0]; blkbuf[2] = P[1]; blkbuf[3] = P[2];
                     S->pairdata.insert(S->pairdata.end(), blkbuf.begin(), blkbuf.end());
+                    const int nh = qc_nherm(d.L);
+                    const size_t t0 = S->pairdataT.size();
+                    S->pairdataT.insert(S->pairdataT.end(), blkbuf.begin(), blkbuf.end());
+                    for (int h = 0; h < nh; ++h)
+                        for (int ab = 0; ab < nab; ++ab) S->pairdataT[t0 + 4 + (size_t)ab * nh + h] = blkbuf[4 + (size_t)h * nab + ab];
                     ++d.K;
                 }
             if (d.K == 0) continue;                       // the whole shell pair is negligible
             S->pairs.push_back(d); S->pairA.push_back(a); S->pairB.push_back(b); S->pairKfull.push_back(A.nprim * B.nprim);
         }
-    // unique quartets (pair P >= pair Q), oriented so the wider pair is the ket (column side), bucketed by
-    // launch class (LAB, LCD, lane-group width)
+    // unique quartets (pair P >= pair Q), bucketed by launch class.
+    //  * bra-major classes (bm): the narrower pair is an ss or ps pair and LAB + LCD <= QC_LREG.  It becomes the ket,
+    //    one lane per quartet: the per-primitive-quartet contraction costs ncd * HAB * HCD FMAs, so the pair with the
+    //    fewest functions belongs on the side that is contracted inside the primitive loop, and the bra side (shared
+    //    by the whole wave) is contracted once per bra primitive pair.
+    //  * all others: column kernels, the wider pair is the ket (one lane per ket function pair, R table shared in LDS).
     const int np = (int)S->pairs.size();
     S->nquartets = npairs_all * (npairs_all + 1) / 2;      // enumerated (unscreened) count, as the reference would visit
-    const int NB = (QC_LPAIR + 1) * (QC_LPAIR + 1) * 7;
+    const int NB = (QC_LPAIR + 1) * (QC_LPAIR + 1) * 7 * 2;
     std::vector<std::vector<QcTask>> bucket(NB);
     for (int P = 0; P < np; ++P)
         for (int Q = 0; Q <= P; ++Q) {
             const QcPairDesc &dp = S->pairs[P], &dq = S->pairs[Q];
             const int np_ = dp.na * dp.nb, nq_ = dq.na * dq.nb;
-            const bool p_is_ket = (np_ > nq_) || (np_ == nq_ && dp.L >= dq.L);
-            QcTask t = p_is_ket ? QcTask{Q, P} : QcTask{P, Q};
-            const QcPairDesc &k = S->pairs[t.ket];
-            bucket[(S->pairs[t.bra].L * (QC_LPAIR + 1) + k.L) * 7 + qc_lgc_for(k.L, k.na * k.nb)].push_back(t);
+            const bool p_is_wide = (np_ > nq_) || (np_ == nq_ && dp.L >= dq.L);
+            const int wide = p_is_wide ? P : Q, narrow = p_is_wide ? Q : P;
+            const QcPairDesc &dn = S->pairs[narrow], &dw = S->pairs[wide];
+            if (dn.L <= 1 && dn.L + dw.L <= QC_LREG) {
+                bucket[(((dw.L * (QC_LPAIR + 1) + dn.L) * 7) + 0) * 2 + 1].push_back(QcTask{wide, narrow});
+            } else {
+                bucket[(((dn.L * (QC_LPAIR + 1) + dw.L) * 7) + qc_lgc_for(dw.L, dw.na * dw.nb)) * 2].push_back(QcTask{narrow, wide});
+            }
         }
     S->classes.clear();
     for (int b = 0; b < NB; ++b) {
         auto &v = bucket[b];
         if (v.empty()) continue;
         QcClass c;
-        c.LGC = b % 7; c.LCD = (b / 7) % (QC_LPAIR + 1); c.LAB = b / 7 / (QC_LPAIR + 1);
+        c.bm = b & 1;
+        c.LGC = (b / 2) % 7; c.LCD = (b / 14) % (QC_LPAIR + 1); c.LAB = b / 14 / (QC_LPAIR + 1);
         c.tasks = std::move(v);
         S->classes.push_back(std::move(c));
     }
@@ -271,6 +285,34 @@ void qc_make_slots(const qc_system *S, const std::vector<QcTask> &tasks, int itm
     std::stable_sort(out.begin(), out.end(), [](const QcSlot &x, const QcSlot &y) { return x.hi - x.lo > y.hi - y.lo; });
 }
 
+// Bra-major work units: the tasks of one bra pair, kets sorted by primitive count (so the lanes of a wave run nearly
+// equal trip counts), cut into bundles of at most 64 kets; with itmax > 0 a bundle is further cut along the bra primitive
+// pairs so that a lane evaluates about itmax primitive quartets.
+void qc_make_bundles(const qc_system *S, const std::vector<QcTask> &tasks, int itmax, std::vector<QcBundle> &bundles, std::vector<int> &ketlist) {
+    bundles.clear(); ketlist.clear();
+    std::vector<QcTask> t(tasks);
+    std::stable_sort(t.begin(), t.end(), [&](const QcTask &x, const QcTask &y) {
+        if (x.bra != y.bra) return x.bra < y.bra;
+        return S->pairs[x.ket].K > S->pairs[y.ket].K;
+    });
+    for (size_t i = 0; i < t.size();) {
+        size_t j = i;
+        while (j < t.size() && t[j].bra == t[i].bra && j - i < 64) ++j;
+        const int Kab = S->pairs[t[i].bra].K, maxK = S->pairs[t[i].ket].K;
+        const int first = (int)ketlist.size();
+        for (size_t k = i; k < j; ++k) ketlist.push_back(t[k].ket);
+        int nparts = 1;
+        if (itmax > 0) nparts = std::min<int64_t>(Kab, std::max<int64_t>(1, ((int64_t)Kab * maxK + itmax - 1) / itmax));
+        for (int s = 0; s < nparts; ++s)
+            bundles.push_back(QcBundle{t[i].bra, (int)((int64_t)Kab * s / nparts), (int)((int64_t)Kab * (s + 1) / nparts), first, (int)(j - i), maxK, 0, 0});
+        i = j;
+    }
+    // long bundles first: the tail of the launch is made of short ones
+    std::stable_sort(bundles.begin(), bundles.end(), [](const QcBundle &x, const QcBundle &y) {
+        return (int64_t)(x.ij_hi - x.ij_lo) * x.maxK > (int64_t)(y.ij_hi - y.ij_lo) * y.maxK;
+    });
+}
+
 // Static shard: inside every launch class the cost-sorted quartet list is dealt to the ranks in boustrophedon order
 // (0..N-1, N-1..0, ...; start rank rotated per class), so each rank holds the same mix of classes and nearly the same
 // modelled cost.  Data-only; no communication.
@@ -282,14 +324,25 @@ void qc_build_shards(qc_system *S) {
             return (int64_t)S->pairs[x.bra].K * S->pairs[x.ket].K > (int64_t)S->pairs[y.bra].K * S->pairs[y.ket].K;
         });
         c.shard.clear();
-        for (size_t i = 0; i < c.tasks.size(); ++i)
-            if (qc_shard_owner(i, S->nranks, ci) == S->rank) c.shard.push_back(c.tasks[i]);
+        std::vector<QcBundle> pb; std::vector<int> kl;
+        if (c.bm && S->nranks > 1) qc_make_bundles(S, c.tasks, 0, pb, kl);
+        if (pb.size() >= (size_t)8 * S->nranks) {
+            // enough of them: deal whole 64-ket bundles, not single quartets, so a rank's waves stay full
+            for (size_t i = 0; i < pb.size(); ++i)
+                if (qc_shard_owner(i, S->nranks, ci) == S->rank)
+                    for (int k = 0; k < pb[i].nket; ++k) c.shard.push_back(QcTask{pb[i].bra, kl[pb[i].first + k]});
+        } else {
+            for (size_t i = 0; i < c.tasks.size(); ++i)
+                if (qc_shard_owner(i, S->nranks, ci) == S->rank) c.shard.push_back(c.tasks[i]);
+        }
         // slot length: long enough to amortise the per-slot digestion, short enough that the class still fills the chip
         int64_t tot_pq = 0;
         for (const auto &t : c.shard) tot_pq += (int64_t)S->pairs[t.bra].K * S->pairs[t.ket].K;
         const int64_t want_waves = 256 * 8, G = 64 >> c.LGC;
         int itmax = (int)std::min<int64_t>(QC_SLOT_ITMAX, std::max<int64_t>((c.LAB + c.LCD <= 2) ? 8 : 2, tot_pq / (want_waves * G)));
-        qc_make_slots(S, c.shard, itmax, c.slots);
+        c.slots.clear(); c.bundles.clear(); c.ketlist.clear();
+        if (c.bm) qc_make_bundles(S, c.shard, itmax, c.bundles, c.ketlist);
+        else qc_make_slots(S, c.shard, itmax, c.slots);
         c.prim_quartets = 0; c.bytes_alg = 0; c.flops_alg = 0;
         int words = 0;
         for (const auto &t : c.shard) {
@@ -313,6 +366,12 @@ void qc_build_shards(qc_system *S) {
         }
         c.slot_words = words;
         c.lds_bytes = words * 8 * (64 >> c.LGC);
+        if (c.bm) {   // I[nab * ncd][65]: one column per lane
+            int mx = 0;
+            for (const auto &t : c.shard) mx = std::max(mx, S->pairs[t.bra].na * S->pairs[t.bra].nb * S->pairs[t.ket].na * S->pairs[t.ket].nb);
+            c.slot_words = mx;
+            c.lds_bytes = mx * 65 * 8;
+        }
     }
 }
 

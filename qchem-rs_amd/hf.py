@@ -233,8 +233,16 @@ class System:
         return dict(class_ms=ms, class_id=cid, quartets=nq, bytes=by, flops=fl, total_ms=tot.value)
 
 
+PROFILE_UNITS = 18   # QC_PROFILE_UNITS in include/qchem_hip.h
+
+
+def unit_name(u: int) -> str:
+    """Kernel instantiation behind launch unit `u` of qc_fock_profile_tiers."""
+    return "qc_fock_tier_kernel<%d, %d>" % (u // 2, u % 2) if u < 14 else "qc_fock_bm_kernel<%d, %d>" % ((u - 14) // 2, (u - 14) % 2)
+
+
 def _fock_profile_tiers(self, dD_ptr: int, dG_ptr: int, reps: int):
-    ms = np.zeros(14, np.float32); nq = np.zeros(14, np.int64); by = np.zeros(14); fl = np.zeros(14); tot = C.c_float()
+    ms = np.zeros(PROFILE_UNITS, np.float32); nq = np.zeros(PROFILE_UNITS, np.int64); by = np.zeros(PROFILE_UNITS); fl = np.zeros(PROFILE_UNITS); tot = C.c_float()
     p = lambda a: a.ctypes.data_as(C.c_void_p)
     _check(lib().qc_fock_profile_tiers(self._h, C.c_void_p(dD_ptr), C.c_void_p(dG_ptr), reps, p(ms), p(nq), p(by), p(fl),
                                        C.cast(C.byref(tot), C.c_void_p)), "qc_fock_profile_tiers")
