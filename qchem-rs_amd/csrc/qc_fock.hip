@@ -1,4 +1,5 @@
 // qc_fock.hip - device set-up and the per-class launch loop of the direct-SCF Fock build.
+#include <cmath>
 #include <cstring>
 #include <vector>
 
@@ -87,11 +88,15 @@ int qc_device_init(qc_system *S) {
     QC_HIP_CHECK(hipMemcpy(S->d_pairdataT, S->pairdataT.data(), S->pairdataT.size() * sizeof(double), hipMemcpyHostToDevice));
     QC_HIP_CHECK(hipMalloc(&S->d_pairs, S->pairs.size() * sizeof(QcPairDesc)));
     QC_HIP_CHECK(hipMemcpy(S->d_pairs, S->pairs.data(), S->pairs.size() * sizeof(QcPairDesc), hipMemcpyHostToDevice));
-    std::vector<double> tab((size_t)(QC_LTOT + 1) * QC_BOYS_NGRID * 8), row(QC_BOYS_NORD);
+    // rows: F_{L+j}(x_k) / j!, j = 0..7, per total order L; then exp(-x_k)
+    std::vector<double> tab((size_t)(QC_LTOT + 1) * QC_BOYS_NGRID * 8 + QC_BOYS_NGRID), row(QC_BOYS_NORD);
     for (int k = 0; k < QC_BOYS_NGRID; ++k) {
         qc_boys_host(QC_BOYS_NORD - 1, k * QC_BOYS_DX, row.data());
-        for (int L = 0; L <= QC_LTOT; ++L)
-            for (int j = 0; j < 8; ++j) tab[((size_t)L * QC_BOYS_NGRID + k) * 8 + j] = row[L + j];
+        for (int L = 0; L <= QC_LTOT; ++L) {
+            double fact = 1.0;
+            for (int j = 0; j < 8; ++j) { tab[((size_t)L * QC_BOYS_NGRID + k) * 8 + j] = row[L + j] / fact; fact *= (j + 1); }
+        }
+        tab[(size_t)(QC_LTOT + 1) * QC_BOYS_NGRID * 8 + k] = std::exp(-k * QC_BOYS_DX);
     }
     QC_HIP_CHECK(hipMalloc(&S->d_boys, tab.size() * sizeof(double)));
     QC_HIP_CHECK(hipMemcpy(S->d_boys, tab.data(), tab.size() * sizeof(double), hipMemcpyHostToDevice));
@@ -150,9 +155,11 @@ static int launch_segments(qc_system *S, int unit, const std::vector<Seg> &segs,
         t.base = base; t.pairdataT = S->d_pairdataT;
         int grid = 0, lds = 0, k = 0;
         for (const Seg &sg : segs) {
-            grid += sg.nslots;
+            // persistent workgroups of QC_BM_WAVES waves: at most ~3 per CU, each wave strides through the bundle list
+            grid += std::min((sg.nslots + QC_BM_WAVES - 1) / QC_BM_WAVES, 256 * 3);
             t.seg_end[k] = grid; t.seg_lab[k] = sg.c->LAB; t.seg_bundles[k] = sg.d_bundles; t.seg_ketlist[k] = sg.d_ketlist;
-            lds = std::max(lds, sg.lds);
+            t.seg_nbundles[k] = sg.nslots; t.seg_iwords[k] = sg.lds / 8;
+            lds = std::max(lds, QC_BM_LDS_TABLE + QC_BM_WAVES * sg.lds);
             ++k;
         }
         t.nseg = k;

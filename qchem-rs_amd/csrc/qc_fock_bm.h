@@ -4,12 +4,16 @@
 
 // One launch = the bra-major classes of one ket type (LCD = 0: ss kets, 1: ps kets) and bra range (HI = 0: LAB <= 2,
 // 1: LAB >= 3); the grid is the concatenation of the classes' bundle lists ("segments"), one wave per bundle.
+constexpr int QC_BM_WAVES = 4;         // waves per workgroup (they share the LDS Boys table, nothing else)
+constexpr int QC_BM_LDS_TABLE = ((QC_BOYS_NGRID * 9 + 1) & ~1) * 8;   // bytes of the table at the head of the workgroup's LDS
 struct QcBmArgs {
     QcKernelArgs base;
     const double *pairdataT;
     int nseg;
     int seg_end[QC_MAXSEG];            // exclusive prefix of workgroup counts
     int seg_lab[QC_MAXSEG];
+    int seg_nbundles[QC_MAXSEG];
+    int seg_iwords[QC_MAXSEG];         // doubles of one wave's I block (nab * ncd * 65)
     const QcBundle *seg_bundles[QC_MAXSEG];
     const int *seg_ketlist[QC_MAXSEG];
 };

@@ -23,14 +23,147 @@
 
 #include "qc_fock_bm.h"
 
-template <int LAB, int LCD>
-__device__ __forceinline__ void qc_bm_body(const QcKernelArgs &a, const double *__restrict__ pdT, const QcBundle *__restrict__ bundles,
-                                           const int *__restrict__ ketlist, const int blk) {
+// The Boys table of the launch's Hermite order lives in LDS (QC_BM_TROW doubles per grid point: the 8 Taylor
+// coefficients and exp(-x_k)): with one quartet per lane every table access is a 64-address gather, and the texture path
+// - not the VALU - was what these kernels waited for when the rows came from global memory (rocprofv3: 60 % of the
+// wave-cycles waiting to issue).  Same evaluation as qc_boys<L>.
+constexpr int QC_BM_TROW = 9;
+constexpr int QC_BM_TWORDS = QC_BOYS_NGRID * QC_BM_TROW;
+
+template <int L>
+__device__ __forceinline__ void qc_boys_lds(double x, const double *__restrict__ T, double (&F)[L + 1]) {
+    if (x < QC_BOYS_XMAX) {
+        const int k = (int)(x * (1.0 / QC_BOYS_DX) + 0.5);
+        const double d = k * QC_BOYS_DX - x;
+        const double *__restrict__ r = T + k * QC_BM_TROW;
+        double f = r[7];
+        f = fma(f, d, r[6]);
+        f = fma(f, d, r[5]);
+        f = fma(f, d, r[4]);
+        f = fma(f, d, r[3]);
+        f = fma(f, d, r[2]);
+        f = fma(f, d, r[1]);
+        f = fma(f, d, r[0]);
+        F[L] = f;
+        if constexpr (L > 0) {
+            double ed = 1.0 / 40320.0;
+            ed = fma(ed, d, 1.0 / 5040.0);
+            ed = fma(ed, d, 1.0 / 720.0);
+            ed = fma(ed, d, 1.0 / 120.0);
+            ed = fma(ed, d, 1.0 / 24.0);
+            ed = fma(ed, d, 1.0 / 6.0);
+            ed = fma(ed, d, 0.5);
+            ed = fma(ed, d, 1.0);
+            ed = fma(ed, d, 1.0);
+            const double ex = r[8] * ed, x2 = 2.0 * x;
+#pragma unroll
+            for (int n = L; n > 0; --n) F[n - 1] = fma(x2, F[n], ex) * (1.0 / (2 * n - 1));
+        }
+    } else {
+        const double t = rsqrt(x);
+        F[0] = (0.5 * 1.7724538509055160273) * t;
+        if constexpr (L > 0) {
+            const double hr = 0.5 * (t * t);
+#pragma unroll
+            for (int n = 0; n < L; ++n) F[n + 1] = ((double)(2 * n + 1) * hr) * F[n];
+        }
+    }
+}
+
+// One pass over the ket primitives for NIJ consecutive bra primitive pairs (NIJ = 2 shares every ket load between two
+// primitive quartets), followed by step 3 with the wave-uniform bra blocks.
+template <int LAB, int LCD, int NIJ>
+__device__ __forceinline__ void qc_bm_pass(const double *__restrict__ pd, const double *__restrict__ pdT, const double *__restrict__ Tb,
+                                           const int bdoff, const int strideB, const int ij, const int nab, const double *__restrict__ ketBase,
+                                           const int K_cd, const int Kc1, const int maxK, double *const I) {
     constexpr int L = LAB + LCD, HAB = qc_nherm(LAB), NC = (LCD == 0) ? 1 : 3;
     constexpr int strideK = qc_pair_stride(LCD, NC);
+    constexpr int LS = 65;
+    double p[NIJ], Px[NIJ], Py[NIJ], Pz[NIJ];
+#pragma unroll
+    for (int u = 0; u < NIJ; ++u) {
+        const double *__restrict__ bh = pd + bdoff + (size_t)(ij + u) * strideB;
+        p[u] = bh[0]; Px[u] = bh[1]; Py[u] = bh[2]; Pz[u] = bh[3];
+    }
+    double W[NIJ][NC][HAB];
+#pragma unroll
+    for (int u = 0; u < NIJ; ++u)
+#pragma unroll
+        for (int c = 0; c < NC; ++c)
+#pragma unroll
+            for (int h = 0; h < HAB; ++h) W[u][c][h] = 0.0;
+    // the next ket primitive's header (and, for ss kets, its single expansion value) is requested one iteration ahead
+    double4 hk = *reinterpret_cast<const double4 *>(ketBase);
+    double ekn = (LCD == 0) ? ketBase[4] : 0.0;
+    for (int kl = 0; kl < maxK; ++kl) {
+        const bool valid = kl < K_cd;
+        const double4 ck = hk;
+        const double ek = ekn;
+        const double *__restrict__ kb = ketBase + (size_t)min(kl, Kc1) * strideK;
+        {
+            const double *__restrict__ kbn = ketBase + (size_t)min(kl + 1, Kc1) * strideK;
+            hk = *reinterpret_cast<const double4 *>(kbn);
+            if constexpr (LCD == 0) ekn = kbn[4];
+        }
+        double ev[12];
+        if constexpr (LCD == 1) {   // ket block: E[h][col], 12 consecutive doubles behind the 32-byte header
+            const double4 e0 = *reinterpret_cast<const double4 *>(kb + 4), e1 = *reinterpret_cast<const double4 *>(kb + 8),
+                          e2 = *reinterpret_cast<const double4 *>(kb + 12);
+            ev[0] = e0.x; ev[1] = e0.y; ev[2] = e0.z; ev[3] = e0.w; ev[4] = e1.x; ev[5] = e1.y; ev[6] = e1.z; ev[7] = e1.w;
+            ev[8] = e2.x; ev[9] = e2.y; ev[10] = e2.z; ev[11] = e2.w;
+        }
+        const double q = ck.x;
+#pragma unroll
+        for (int u = 0; u < NIJ; ++u) {
+            const double X = Px[u] - ck.y, Y = Py[u] - ck.z, Z = Pz[u] - ck.w;
+            const double pref = rsqrt(p[u] + q);
+            const double alpha = p[u] * q * (pref * pref);
+            double F[L + 1], Rr[qc_nherm(L)];
+            qc_boys_lds<L>(alpha * (X * X + Y * Y + Z * Z), Tb, F);
+            qc_rtab<L>(alpha, X, Y, Z, F, Rr);
+            const double sc = valid ? pref : 0.0;
+            if constexpr (LCD == 0) {
+                double e[1] = {ek * sc};
+                qc_step2<LAB, 0>(W[u][0], e, Rr);
+            } else {
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    double e[4];
+#pragma unroll
+                    for (int h = 0; h < 4; ++h) e[h] = ev[h * 3 + c] * sc;
+                    qc_step2<LAB, 1>(W[u][c], e, Rr);
+                }
+            }
+        }
+    }
+    // step 3 with the wave-uniform bra blocks: I[ab][c] += sum_u sum_h E_ab,ij+u[ab][h] W[u][c][h]
+    const double *__restrict__ ET = pdT + bdoff + (size_t)ij * strideB + 4;
+    for (int ab = 0; ab < nab; ++ab) {
+        double acc[NC];
+#pragma unroll
+        for (int c = 0; c < NC; ++c) acc[c] = 0.0;
+#pragma unroll
+        for (int u = 0; u < NIJ; ++u) {
+            const double *__restrict__ row = ET + (size_t)u * strideB + ab * HAB;
+#pragma unroll
+            for (int h = 0; h < HAB; ++h) {
+                const double e = row[h];
+#pragma unroll
+                for (int c = 0; c < NC; ++c) acc[c] = fma(e, W[u][c][h], acc[c]);
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < NC; ++c) I[(ab * NC + c) * LS] += acc[c];
+    }
+}
+
+template <int LAB, int LCD>
+__device__ __forceinline__ void qc_bm_body(const QcKernelArgs &a, const double *__restrict__ pdT, const QcBundle *__restrict__ bundles,
+                                           const int *__restrict__ ketlist, const int blk, const double *__restrict__ Tb, double *const Iw) {
+    constexpr int HAB = qc_nherm(LAB), NC = (LCD == 0) ? 1 : 3;
     constexpr int LS = 65;                                    // LDS row stride (doubles)
-    extern __shared__ double lds[];
-    const int lane = threadIdx.x;
+    constexpr bool PAIRED = 2 * NC * HAB <= 24;               // two bra primitive pairs per pass when W[2][NC][HAB] fits
+    const int lane = threadIdx.x & 63;
     const double *__restrict__ pd = a.pairdata;
     const int n = a.n;
     const bool uhf = a.Dk1 != nullptr;
@@ -50,68 +183,16 @@ __device__ __forceinline__ void qc_bm_body(const QcKernelArgs &a, const double *
     const bool active = lane < nket;
     const int ket = ketlist[first + (active ? lane : 0)];
     const QcPairDesc pk = a.pairs[ket];
-    const int K_cd = active ? pk.K : 0;
+    const int K_cd = active ? pk.K : 0, Kc1 = max(K_cd - 1, 0);
     const double *__restrict__ ketBase = pd + pk.doff;
-    double *const I = lds + lane;                             // I[x * LS], x = ab * NC + col
+    double *const I = Iw + lane;                              // I[x * LS], x = ab * NC + col
 
     for (int x = 0; x < nab * NC; ++x) I[x * LS] = 0.0;
 
-    for (int ij = ij_lo; ij < ij_hi; ++ij) {
-        const double *__restrict__ bh = pd + bdoff + (size_t)ij * strideB;
-        const double p = bh[0], Px = bh[1], Py = bh[2], Pz = bh[3];
-        double W[NC][HAB];
-#pragma unroll
-        for (int c = 0; c < NC; ++c)
-#pragma unroll
-            for (int h = 0; h < HAB; ++h) W[c][h] = 0.0;
-        double4 hk = *reinterpret_cast<const double4 *>(ketBase);
-        for (int kl = 0; kl < maxK; ++kl) {
-            const bool valid = kl < K_cd;
-            const double4 ck = hk;
-            const double *__restrict__ kb = ketBase + (size_t)(valid ? kl : 0) * strideK;
-            if (kl + 1 < K_cd) hk = *reinterpret_cast<const double4 *>(ketBase + (size_t)(kl + 1) * strideK);
-            const double q = ck.x;
-            const double X = Px - ck.y, Y = Py - ck.z, Z = Pz - ck.w;
-            const double pref = rsqrt(p + q);
-            const double alpha = p * q * (pref * pref);
-            double F[L + 1], Rr[qc_nherm(L)];
-            qc_boys<L>(alpha * (X * X + Y * Y + Z * Z), a.boys, F);
-            qc_rtab<L>(alpha, X, Y, Z, F, Rr);
-            const double sc = valid ? pref : 0.0;
-            if constexpr (LCD == 0) {
-                double e[1] = {kb[4] * sc};
-                qc_step2<LAB, 0>(W[0], e, Rr);
-            } else {
-                // ket block: E[h][col], 12 consecutive doubles behind the 32-byte header
-                const double4 e0 = *reinterpret_cast<const double4 *>(kb + 4), e1 = *reinterpret_cast<const double4 *>(kb + 8),
-                              e2 = *reinterpret_cast<const double4 *>(kb + 12);
-                const double ev[12] = {e0.x, e0.y, e0.z, e0.w, e1.x, e1.y, e1.z, e1.w, e2.x, e2.y, e2.z, e2.w};
-#pragma unroll
-                for (int c = 0; c < 3; ++c) {
-                    double e[4];
-#pragma unroll
-                    for (int h = 0; h < 4; ++h) e[h] = ev[h * 3 + c] * sc;
-                    qc_step2<LAB, 1>(W[c], e, Rr);
-                }
-            }
-        }
-        // step 3 with the wave-uniform bra block: I[ab][c] += sum_h E_ab,ij[ab][h] W[c][h]
-        const double *__restrict__ ET = pdT + bdoff + (size_t)ij * strideB + 4;
-        for (int ab = 0; ab < nab; ++ab) {
-            const double *__restrict__ row = ET + ab * HAB;
-            double acc[NC];
-#pragma unroll
-            for (int c = 0; c < NC; ++c) acc[c] = 0.0;
-#pragma unroll
-            for (int h = 0; h < HAB; ++h) {
-                const double ev = row[h];
-#pragma unroll
-                for (int c = 0; c < NC; ++c) acc[c] = fma(ev, W[c][h], acc[c]);
-            }
-#pragma unroll
-            for (int c = 0; c < NC; ++c) I[(ab * NC + c) * LS] += acc[c];
-        }
-    }
+    int ij = ij_lo;
+    if constexpr (PAIRED)
+        for (; ij + 1 < ij_hi; ij += 2) qc_bm_pass<LAB, LCD, 2>(pd, pdT, Tb, bdoff, strideB, ij, nab, ketBase, K_cd, Kc1, maxK, I);
+    for (; ij < ij_hi; ++ij) qc_bm_pass<LAB, LCD, 1>(pd, pdT, Tb, bdoff, strideB, ij, nab, ketBase, K_cd, Kc1, maxK, I);
 
     const int nd = pk.nb;                                     // (nc, nd) = (1,1), (3,1) or (1,3)
     const int c0 = pk.offa, d0 = pk.offb;
@@ -233,7 +314,7 @@ __device__ __forceinline__ void qc_bm_body(const QcKernelArgs &a, const double *
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     for (int ab = lane; ab < nab; ab += 64) {
-        const double *row = lds + (size_t)(ab * NC) * LS;
+        const double *row = Iw + (size_t)(ab * NC) * LS;
         double s0 = 0.0, s1 = 0.0;
 #pragma unroll 8
         for (int j = 0; j < 64; j += 2) { s0 += row[j]; s1 += row[j + 1]; }
@@ -243,14 +324,35 @@ __device__ __forceinline__ void qc_bm_body(const QcKernelArgs &a, const double *
     }
 }
 
+// Workgroup = QC_BM_WAVES independent waves sharing the LDS Boys table of their segment's Hermite order; every wave
+// walks the segment's bundle list with the stride of the launch (bundles are sorted longest first).
+template <int LAB, int LCD>
+__device__ __forceinline__ void qc_bm_segment(const QcBmArgs &a, const int s, const int wg, const int nwg) {
+    extern __shared__ double lds[];
+    constexpr int L = LAB + LCD;
+    const int tid = threadIdx.x, wave = tid >> 6;
+    {
+        const double *__restrict__ rows = a.base.boys + (size_t)L * QC_BOYS_NGRID * 8;
+        const double *__restrict__ exk = a.base.boys + (size_t)(QC_LTOT + 1) * QC_BOYS_NGRID * 8;
+        for (int i = tid; i < QC_BM_TWORDS; i += QC_BM_WAVES * 64) {
+            const int k = i / QC_BM_TROW, j = i - k * QC_BM_TROW;
+            lds[i] = (j < 8) ? rows[k * 8 + j] : exk[k];
+        }
+    }
+    __syncthreads();
+    double *const Iw = lds + ((QC_BM_TWORDS + 1) & ~1) + (size_t)wave * a.seg_iwords[s];
+    const int nb = a.seg_nbundles[s];
+    for (int b = wg * QC_BM_WAVES + wave; b < nb; b += nwg * QC_BM_WAVES)
+        qc_bm_body<LAB, LCD>(a.base, a.pairdataT, a.seg_bundles[s], a.seg_ketlist[s], b, lds, Iw);
+}
+
 template <int LCD, int HI>
-__global__ __launch_bounds__(64) void qc_fock_bm_kernel(const QcBmArgs a) {
+__global__ __launch_bounds__(QC_BM_WAVES * 64) void qc_fock_bm_kernel(const QcBmArgs a) {
     int s = 0;
     while (s + 1 < a.nseg && (int)blockIdx.x >= a.seg_end[s]) ++s;
-    const int blk = blockIdx.x - (s ? a.seg_end[s - 1] : 0);
-    const QcBundle *bundles = a.seg_bundles[s];
-    const int *ketlist = a.seg_ketlist[s];
-#define QC_BM_CASE(LAB) case LAB: qc_bm_body<LAB, LCD>(a.base, a.pairdataT, bundles, ketlist, blk); break;
+    const int b0 = s ? a.seg_end[s - 1] : 0;
+    const int wg = blockIdx.x - b0, nwg = a.seg_end[s] - b0;
+#define QC_BM_CASE(LAB) case LAB: qc_bm_segment<LAB, LCD>(a, s, wg, nwg); break;
     if constexpr (LCD == 0 && HI == 0) { switch (a.seg_lab[s]) { QC_BM_CASE(0) QC_BM_CASE(1) QC_BM_CASE(2) default: break; } }
     if constexpr (LCD == 0 && HI == 1) { switch (a.seg_lab[s]) { QC_BM_CASE(3) QC_BM_CASE(4) default: break; } }
     if constexpr (LCD == 1 && HI == 0) { switch (a.seg_lab[s]) { QC_BM_CASE(1) QC_BM_CASE(2) default: break; } }
@@ -267,7 +369,7 @@ static int launch_bm(int grid, size_t lds, hipStream_t st, const QcBmArgs &a) {
         if (e != hipSuccess) return QC_ERR_HIP;
         lds_allowed = lds;
     }
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(64), lds, st, a);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(QC_BM_WAVES * 64), lds, st, a);
     return hipGetLastError() == hipSuccess ? QC_OK : QC_ERR_HIP;
 }
 

@@ -86,8 +86,10 @@ __device__ __forceinline__ void qc_step2_rolled(double (&W)[qc_nherm(LAB)], cons
 }
 
 
-// Boys function F_0..F_L at x: 8-term Taylor expansion about the nearest grid point of the pre-tabulated
-// F_n(x_k) for the top order, downward recursion below it; asymptotic form + upward recursion beyond the table.
+// Boys function F_0..F_L at x.  Inside the table: Horner evaluation of the 8-term Taylor expansion of the top order
+// about the nearest grid point x_k (rows hold F_{L+j}(x_k) / j!), exp(-x) = exp(-x_k) * exp(x_k - x) from the grid value
+// and a degree-8 polynomial (|x_k - x| <= DX/2: remainder 5e-18), downward recursion below.  Beyond the table:
+// asymptotic F_0 = sqrt(pi/x)/2 and upward recursion (the exp(-x) term, < 7e-19 there, is kept for the high orders only).
 template <int L>
 __device__ __forceinline__ void qc_boys(double x, const double *__restrict__ tab, double (&F)[L + 1]) {
     if (x < QC_BOYS_XMAX) {
@@ -95,27 +97,43 @@ __device__ __forceinline__ void qc_boys(double x, const double *__restrict__ tab
         const double d = k * QC_BOYS_DX - x;
         const double4 *row = reinterpret_cast<const double4 *>(tab + ((size_t)L * QC_BOYS_NGRID + k) * 8);   // 64-byte aligned row
         const double4 lo = row[0], hi = row[1];
-        double f = hi.w * (1.0 / 5040.0);
-        f = fma(f, d, hi.z * (1.0 / 720.0));
-        f = fma(f, d, hi.y * (1.0 / 120.0));
-        f = fma(f, d, hi.x * (1.0 / 24.0));
-        f = fma(f, d, lo.w * (1.0 / 6.0));
-        f = fma(f, d, lo.z * 0.5);
+        double f = hi.w;
+        f = fma(f, d, hi.z);
+        f = fma(f, d, hi.y);
+        f = fma(f, d, hi.x);
+        f = fma(f, d, lo.w);
+        f = fma(f, d, lo.z);
         f = fma(f, d, lo.y);
         f = fma(f, d, lo.x);
         F[L] = f;
         if constexpr (L > 0) {
-            const double ex = exp(-x), x2 = 2.0 * x;
+            const double exk = tab[(size_t)(QC_LTOT + 1) * QC_BOYS_NGRID * 8 + k];
+            double ed = 1.0 / 40320.0;
+            ed = fma(ed, d, 1.0 / 5040.0);
+            ed = fma(ed, d, 1.0 / 720.0);
+            ed = fma(ed, d, 1.0 / 120.0);
+            ed = fma(ed, d, 1.0 / 24.0);
+            ed = fma(ed, d, 1.0 / 6.0);
+            ed = fma(ed, d, 0.5);
+            ed = fma(ed, d, 1.0);
+            ed = fma(ed, d, 1.0);
+            const double ex = exk * ed, x2 = 2.0 * x;
 #pragma unroll
             for (int n = L; n > 0; --n) F[n - 1] = fma(x2, F[n], ex) * (1.0 / (2 * n - 1));
         }
     } else {
-        const double rx = 1.0 / x;
-        F[0] = 0.5 * sqrt(M_PI * rx);
+        const double t = rsqrt(x);
+        F[0] = (0.5 * 1.7724538509055160273) * t;
         if constexpr (L > 0) {
-            const double ex = exp(-x), hr = 0.5 * rx;
+            const double hr = 0.5 * (t * t);
+            if constexpr (L <= QC_LREG) {     // exp(-x) < 7e-19: below 1e-13 relative for orders <= 4
 #pragma unroll
-            for (int n = 0; n < L; ++n) F[n + 1] = fma((double)(2 * n + 1), F[n], -ex) * hr;
+                for (int n = 0; n < L; ++n) F[n + 1] = ((double)(2 * n + 1) * hr) * F[n];
+            } else {                          // high orders are small themselves (F_12(42) ~ 4e-13): keep the term
+                const double ex = exp(-x);
+#pragma unroll
+                for (int n = 0; n < L; ++n) F[n + 1] = fma((double)(2 * n + 1), F[n], -ex) * hr;
+            }
         }
     }
 }
@@ -447,7 +465,8 @@ struct QcTierArgs {
 };
 
 template <int LAB, int TIER>
-__global__ __launch_bounds__(64) void qc_fock_tier_kernel(const QcTierArgs a) {
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu((TIER == 0 && LAB <= 4) ? 2 : 1)))
+void qc_fock_tier_kernel(const QcTierArgs a) {
     // the high-L tiers are few, long, latency-bound waves: let them win issue arbitration against the many short
     // low-L waves they share a SIMD with
     if constexpr (TIER == 1) __builtin_amdgcn_s_setprio(3);

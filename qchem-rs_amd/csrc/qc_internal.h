@@ -124,7 +124,8 @@ void qc_build_shards(qc_system *S);
 void qc_host_one_electron(const qc_system *S, int which, double *out);
 void qc_boys_host(int nmax, double x, double *F);
 
-// Boys tables, one per total Hermite order L: row k = F_L .. F_{L+7} at x_k = k * QC_BOYS_DX (64-byte rows)
+// Boys tables, one per total Hermite order L: row k = F_{L+j}(x_k) / j!, j = 0..7, x_k = k * QC_BOYS_DX (64-byte rows);
+// behind them exp(-x_k)
 constexpr double QC_BOYS_DX = 0.1;
 constexpr int QC_BOYS_NGRID = 421;             // x up to 42
 constexpr double QC_BOYS_XMAX = 41.9;          // beyond: asymptotic + upward recursion
