@@ -334,10 +334,18 @@ __device__ __forceinline__ void qc_bm_segment(const QcBmArgs &a, const int s, co
     {
         const double *__restrict__ rows = a.base.boys + (size_t)L * QC_BOYS_NGRID * 8;
         const double *__restrict__ exk = a.base.boys + (size_t)(QC_LTOT + 1) * QC_BOYS_NGRID * 8;
-        for (int i = tid; i < QC_BM_TWORDS; i += QC_BM_WAVES * 64) {
+        // constant trip count, fully unrolled: all loads of a thread are in flight together (one L2 round trip, not 15)
+        constexpr int NT = QC_BM_WAVES * 64, NIT = (QC_BM_TWORDS + NT - 1) / NT;
+        double v[NIT];
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int i = min(tid + it * NT, QC_BM_TWORDS - 1);
             const int k = i / QC_BM_TROW, j = i - k * QC_BM_TROW;
-            lds[i] = (j < 8) ? rows[k * 8 + j] : exk[k];
+            v[it] = (j < 8) ? rows[k * 8 + j] : exk[k];
         }
+#pragma unroll
+        for (int it = 0; it < NIT; ++it)
+            if (tid + it * NT < QC_BM_TWORDS) lds[tid + it * NT] = v[it];
     }
     __syncthreads();
     double *const Iw = lds + ((QC_BM_TWORDS + 1) & ~1) + (size_t)wave * a.seg_iwords[s];

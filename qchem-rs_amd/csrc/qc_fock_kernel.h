@@ -61,7 +61,10 @@ template <int LAB, int LCD>
 __device__ __forceinline__ void qc_step2_rolled(double (&W)[qc_nherm(LAB)], const double *__restrict__ Ecd, int ncd, double sc,
                                                 const double *__restrict__ R) {
     constexpr QcTuvTable T = qc_make_tuv();
+    constexpr int HAB = qc_nherm(LAB);
+    constexpr int B = 14;                     // R values fetched from LDS per batch before the FMAs that consume them
     const double *e_ptr = Ecd;
+    double e_next = *e_ptr;
     for (int N2 = 0; N2 <= LCD; ++N2) {
         const double sgn = (N2 & 1) ? -sc : sc;
         int off3[LAB + 1];
@@ -70,15 +73,25 @@ __device__ __forceinline__ void qc_step2_rolled(double (&W)[qc_nherm(LAB)], cons
         for (int t2 = N2; t2 >= 0; --t2) {
             for (int u2 = N2 - t2; u2 >= 0; --u2) {
                 const int v2 = N2 - t2 - u2, s2 = N2 - t2;
-                const double e = *e_ptr * sgn;
+                const double e = e_next * sgn;
                 e_ptr += ncd;
+                if (!(N2 == LCD && t2 == 0 && u2 == 0)) e_next = *e_ptr;     // next ket Hermite coefficient, one iteration ahead
                 int off2[LAB + 1];
 #pragma unroll
                 for (int k = 0; k <= LAB; ++k) off2[k] = (k + s2) * (k + s2 + 1) / 2 + v2;
 #pragma unroll
-                for (int h1 = 0; h1 < qc_nherm(LAB); ++h1) {
-                    const int N1 = T.t[h1] + T.u[h1] + T.v[h1], s1 = T.u[h1] + T.v[h1], v1 = T.v[h1];
-                    W[h1] = fma(e, R[off3[N1] + off2[s1] + v1], W[h1]);
+                for (int h0 = 0; h0 < HAB; h0 += B) {
+                    double r[B];
+#pragma unroll
+                    for (int i = 0; i < B; ++i) {
+                        const int h1 = (h0 + i < HAB) ? h0 + i : HAB - 1;
+                        const int N1 = T.t[h1] + T.u[h1] + T.v[h1], s1 = T.u[h1] + T.v[h1], v1 = T.v[h1];
+                        r[i] = R[off3[N1] + off2[s1] + v1];
+                    }
+                    __builtin_amdgcn_sched_barrier(0);          // all loads of the batch are in flight before the first FMA waits
+#pragma unroll
+                    for (int i = 0; i < B; ++i)
+                        if (h0 + i < HAB) W[h0 + i] = fma(e, r[i], W[h0 + i]);
                 }
             }
         }

@@ -29,7 +29,7 @@ from .loader import MolecularSystem
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libqchem_hip.so")
+LIB_PATH = os.environ.get("QCHEM_HIP_LIB") or os.path.join(_HERE, "libqchem_hip.so")
 
 QC_OK, QC_NOT_CONVERGED, QC_DIIS_SINGULAR = 0, 1, 2
 QC_ERR_INVALID, QC_ERR_NO_DEVICE, QC_ERR_HIP, QC_ERR_RCCL, QC_ERR_UNSUPPORTED = -1, -2, -3, -4, -5

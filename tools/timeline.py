@@ -10,6 +10,7 @@ t0 = ks[i0][1]
 print("window (us): %.1f" % ((ks[i1][0] - t0) / 1e3))
 for s, e, n, q, g in ks[i0:i1 + 2]:
     m = re.search(r'qc_fock_tier_kernel<(\d+), (\d+)>', n)
-    nm = ("tier<%s,%s>" % m.groups()) if m else n.split('(')[0][:34]
-    if len(sys.argv) > 3 or m or 'jacobi' in n or 'reduce' in n:
+    m2 = re.search(r'qc_fock_bm_kernel<(\d+), (\d+)>', n)
+    nm = ("tier<%s,%s>" % m.groups()) if m else ("bm<%s,%s>" % m2.groups()) if m2 else n.split('(')[0][:34]
+    if len(sys.argv) > 3 or m or m2 or 'jacobi' in n or 'reduce' in n:
         print("%8.1f %8.1f %7.1f  q%s %s grid=%s" % ((s - t0) / 1e3, (e - t0) / 1e3, (e - s) / 1e3, q, nm, g))
