@@ -2,12 +2,13 @@
 //
 // qc_scf_rhf / qc_scf_uhf restate the control flow of restricted_hartree_fock (core/src/hf/rhf.rs:32-108) and
 // unrestricted_hartree_fock (uhf.rs:36-167) - guess, DIIS windows, update order, energy expression, diagonal-only
-// convergence test - with every matrix resident in HBM and every O(n^3)/O(n^4) step a HIP kernel.  Only the DIIS
-// (<= 9 x 9) QR solve and the convergence decision run on the host, as they do in the reference.
+// convergence test - with every matrix resident in HBM and every step a HIP kernel, the DIIS (<= 9 x 9) QR solve
+// included; the host takes the convergence decision from two scalars it reads back once per pass.
 #include <rccl/rccl.h>
 
 #include <chrono>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <deque>
 #include <memory>
@@ -28,96 +29,68 @@ struct DevBuf {
     ~DevBuf() { if (p) (void)hipFree(p); }
 };
 
-// Householder QR solve, the arithmetic of nalgebra's `matrix.qr().solve(&b)` (diis.rs:50-51); false = zero pivot
-bool qr_solve(int m, std::vector<double> A, std::vector<double> y, std::vector<double> &x) {
-    for (int k = 0; k < m; ++k) {
-        double norm = 0.0;
-        for (int i = k; i < m; ++i) norm += A[i * m + k] * A[i * m + k];
-        norm = std::sqrt(norm);
-        if (norm == 0.0) return false;
-        const double alpha = A[k * m + k] > 0 ? -norm : norm;
-        std::vector<double> v(m, 0.0);
-        double vn = 0.0;
-        for (int i = k; i < m; ++i) { v[i] = A[i * m + k] - (i == k ? alpha : 0.0); vn += v[i] * v[i]; }
-        if (vn > 0.0) {
-            for (int j = k; j < m; ++j) {
-                double d = 0.0; for (int i = k; i < m; ++i) d += v[i] * A[i * m + j];
-                d *= 2.0 / vn; for (int i = k; i < m; ++i) A[i * m + j] -= d * v[i];
-            }
-            double d = 0.0; for (int i = k; i < m; ++i) d += v[i] * y[i];
-            d *= 2.0 / vn; for (int i = k; i < m; ++i) y[i] -= d * v[i];
-        }
-    }
-    x.assign(m, 0.0);
-    for (int i = m - 1; i >= 0; --i) {
-        double s = y[i];
-        for (int j = i + 1; j < m; ++j) s -= A[i * m + j] * x[j];
-        if (A[i * m + i] == 0.0) return false;
-        x[i] = s / A[i * m + i];
-    }
-    return true;
-}
-
-// Diis (diis.rs:6-60) with the sample window in HBM.  Newest sample first; B entries of older pairs are cached.
+// Diis (diis.rs:6-60) with the sample window, the B matrix and the QR solve in HBM / on the device: nothing of it
+// synchronises with the host.  Samples live in ring slots; `slots` lists them newest first.  A singular system
+// ("DIIS failed", rhf.rs:73) raises *d_flag, which the SCF step reads back together with the energy.
 struct DeviceDiis {
     int minlen, maxlen, n;
-    std::deque<double *> err, fock;        // device matrices, newest at front
-    std::deque<std::vector<double>> dotrow; // dotrow[i][j] = <e_i, e_j> for j >= i (aligned with deque order)
-    std::vector<double *> pool;
-    double *d_dots = nullptr;
+    std::deque<int> slots;
+    std::vector<double *> pool;            // err of slot s = pool[2s], fock = pool[2s + 1]
+    double *d_dots = nullptr, *d_B = nullptr, *d_c = nullptr;
     DeviceDiis(int mn, int mx, int n_) : minlen(mn), maxlen(mx), n(n_) {}
-    ~DeviceDiis() { for (auto p : pool) (void)hipFree(p); if (d_dots) (void)hipFree(d_dots); }
-    int init() {
-        for (int i = 0; i < 2 * (maxlen + 1); ++i) { double *p; if (hipMalloc(&p, sizeof(double) * n * n) != hipSuccess) return QC_ERR_HIP; pool.push_back(p); }
-        return hipMalloc(&d_dots, 16 * sizeof(double)) == hipSuccess ? QC_OK : QC_ERR_HIP;
+    ~DeviceDiis() {
+        for (auto p : pool) (void)hipFree(p);
+        if (d_dots) (void)hipFree(d_dots);
+        if (d_B) (void)hipFree(d_B);
+        if (d_c) (void)hipFree(d_c);
     }
-    // returns QC_OK and writes the extrapolated Fock into d_out, or QC_DIIS_SINGULAR
-    int fock_step(hipStream_t st, const double *d_err, const double *d_fock, double *d_out) {
-        const size_t bytes = sizeof(double) * n * n;
-        // push_front + truncate (diis.rs:29-30): recycle the oldest buffers
-        double *e, *f;
-        if ((int)err.size() == maxlen) { e = err.back(); f = fock.back(); err.pop_back(); fock.pop_back(); }
-        else { e = pool[2 * err.size()]; f = pool[2 * err.size() + 1]; }
-        if (hipMemcpyAsync(e, d_err, bytes, hipMemcpyDeviceToDevice, st) != hipSuccess) return QC_ERR_HIP;
-        if (hipMemcpyAsync(f, d_fock, bytes, hipMemcpyDeviceToDevice, st) != hipSuccess) return QC_ERR_HIP;
-        err.push_front(e); fock.push_front(f);
-        const int m = (int)err.size();
-        if (m < minlen) {       // diis.rs:33-38: not enough samples, hand back the newest Fock
-            if (hipMemcpyAsync(d_out, f, bytes, hipMemcpyDeviceToDevice, st) != hipSuccess) return QC_ERR_HIP;
-            // keep the dot cache aligned even while DIIS is idle
-        }
-        // new row of B: <e_0, e_j> for all j in the window
-        std::vector<const double *> ys(err.begin(), err.end());
-        qc_dots(st, n, e, ys.data(), m, d_dots);
-        std::vector<double> row(m);
-        if (hipMemcpyAsync(row.data(), d_dots, m * sizeof(double), hipMemcpyDeviceToHost, st) != hipSuccess) return QC_ERR_HIP;
-        if (hipStreamSynchronize(st) != hipSuccess) return QC_ERR_HIP;
-        dotrow.push_front(row);
-        if ((int)dotrow.size() > maxlen) dotrow.pop_back();
-        for (size_t i = 1; i < dotrow.size(); ++i) if ((int)dotrow[i].size() > m - (int)i) dotrow[i].resize(m - i);
-        if (m < minlen) return QC_OK;
-        std::vector<double> B((size_t)(m + 1) * (m + 1), 0.0), rhs(m + 1, 0.0), c;
-        for (int i = 0; i < m; ++i)
-            for (int j = i; j < m; ++j) B[i * (m + 1) + j] = B[j * (m + 1) + i] = dotrow[i][j - i];
-        for (int i = 0; i < m; ++i) B[i * (m + 1) + m] = B[m * (m + 1) + i] = 1.0;   // border +1, corner 0 (diis.rs:40-46)
-        rhs[m] = 1.0;
-        if (!qr_solve(m + 1, B, rhs, c)) return QC_DIIS_SINGULAR;
-        std::vector<const double *> fs(fock.begin(), fock.end());
-        qc_lincomb(st, n, fs.data(), c.data(), m, d_out);
-        return QC_OK;
+    int init() {
+        if (maxlen > 11) return QC_ERR_INVALID;
+        for (int i = 0; i < 2 * maxlen; ++i) { double *p; if (hipMalloc(&p, sizeof(double) * n * n) != hipSuccess) return QC_ERR_HIP; pool.push_back(p); }
+        if (hipMalloc(&d_dots, 16 * sizeof(double)) != hipSuccess || hipMalloc(&d_c, 16 * sizeof(double)) != hipSuccess ||
+            hipMalloc(&d_B, sizeof(double) * maxlen * maxlen) != hipSuccess) return QC_ERR_HIP;
+        return hipMemset(d_B, 0, sizeof(double) * maxlen * maxlen) == hipSuccess ? QC_OK : QC_ERR_HIP;
+    }
+    // claim the slot of the next sample (push_front + truncate, diis.rs:29-30: the oldest slot is recycled); the caller
+    // writes the error and Fock matrices straight into the returned buffers
+    void next_sample(double **d_err, double **d_fock) {
+        int s;
+        if ((int)slots.size() == maxlen) { s = slots.back(); slots.pop_back(); } else s = (int)slots.size();
+        slots.push_front(s);
+        *d_err = pool[2 * s]; *d_fock = pool[2 * s + 1];
+    }
+    // enqueues: new row of B, coefficient solve, extrapolated Fock matrix into d_out
+    int extrapolate(hipStream_t st, double *d_out, int *d_flag) {
+        const int m = (int)slots.size();
+        const double *ys[12], *fs[12];
+        int sl[12];
+        for (int j = 0; j < m; ++j) { sl[j] = slots[j]; ys[j] = pool[2 * slots[j]]; fs[j] = pool[2 * slots[j] + 1]; }
+        qc_dots(st, n, ys[0], ys, m, d_dots);                                         // <e_0, e_j>, diis.rs:43-45
+        qc_diis_solve(st, m, minlen, maxlen, sl, d_dots, d_B, d_c, d_flag);           // (1, 0, ...) while m < minlen
+        qc_lincomb_dev(st, n, fs, d_c, m, d_out);                                     // diis.rs:52-58
+        return hipGetLastError() == hipSuccess ? QC_OK : QC_ERR_HIP;
     }
 };
 
 struct ScfWork {
     int n;
-    DevBuf H, S, X, t1, t2, t3, t4, Fp, Cp, C, w, ework, Fd, scal, small, CpPrev[2];
+    DevBuf H, S, X, t1, t2, t3, t4, Fp, Cp, C, w, ework, Fd, scal, small, CpPrev[2], CpNew[2], Fps[2];
     bool have_prev[2] = {false, false};
+    int npass[2] = {3, 3};                 // refinement passes enqueued per eigensolve (follows what the last one needed)
+    int *ctl = nullptr;                    // device control words: [4 s + 0..3] eigen-refinement of spin s, [8] DIIS failure
+    double *h_scal = nullptr;              // pinned read-back: 4 doubles (energy, rms^2 per spin) + 16 ints
+    ~ScfWork() {
+        if (ctl) (void)hipFree(ctl);
+        if (h_scal) (void)hipHostFree(h_scal);
+    }
     int init(int n_) {
         n = n_;
         const size_t nn = (size_t)n * n;
-        DevBuf *all[] = {&H, &S, &X, &t1, &t2, &t3, &t4, &Fp, &Cp, &C, &ework, &Fd, &CpPrev[0], &CpPrev[1]};
+        DevBuf *all[] = {&H, &S, &X, &t1, &t2, &t3, &t4, &Fp, &Cp, &C, &ework, &Fd, &CpPrev[0], &CpPrev[1], &CpNew[0], &CpNew[1], &Fps[0], &Fps[1]};
         for (auto b : all) if (b->alloc(nn) != QC_OK) return QC_ERR_HIP;
         if (w.alloc(n) != QC_OK || scal.alloc(16) != QC_OK || small.alloc(2 * n + 16) != QC_OK) return QC_ERR_HIP;
+        if (hipMalloc(&ctl, 16 * sizeof(int)) != hipSuccess || hipMemset(ctl, 0, 16 * sizeof(int)) != hipSuccess) return QC_ERR_HIP;
+        if (hipHostMalloc(&h_scal, 4 * sizeof(double) + 16 * sizeof(int)) != hipSuccess) return QC_ERR_HIP;
         return QC_OK;
     }
 };
@@ -169,25 +142,38 @@ int huckel_density(qc_system *S, ScfWork &W, const std::vector<double> &h_eht, i
     return QC_OK;
 }
 
-// One spin's Roothaan step: F = H + G; e = FDS - SDF; DIIS; F' = X^T F X; eig; C = X C'   (rhf.rs:70-76)
-int roothaan_step(qc_system *S, ScfWork &W, DeviceDiis &diis, const double *dG, const double *dD, double *dw_out, int spin) {
+// One spin's Roothaan step, enqueued without any host synchronisation: F = H + G; e = FDS - SDF; DIIS; F' = X^T F X;
+// eigenvectors; C = X C'   (rhf.rs:70-76).  The eigensolve is warm-started from this spin's previous vectors once they
+// exist (qc_eig_refine_async: outcome in ctl[4 spin]); new vectors go to CpNew[spin], C to dC.
+int roothaan_enqueue(qc_system *S, ScfWork &W, DeviceDiis &diis, const double *dG, const double *dD, double *dw_out, double *dC, int spin) {
     const int n = S->nbasis;
     hipStream_t st = S->stream;
-    qc_axpby(st, n, 1.0, W.H.p, 1.0, dG, W.t1.p);                                        // F
-    qc_gemm(st, n, n, n, 1.0, W.t1.p, n, false, dD, n, false, 0.0, W.t2.p, n);           // F D
+    double *dE, *dF;
+    diis.next_sample(&dE, &dF);
+    qc_axpby(st, n, 1.0, W.H.p, 1.0, dG, dF);                                            // F
+    qc_gemm(st, n, n, n, 1.0, dF, n, false, dD, n, false, 0.0, W.t2.p, n);               // F D
     qc_gemm(st, n, n, n, 1.0, W.t2.p, n, false, W.S.p, n, false, 0.0, W.Fp.p, n);        // F D S
-    qc_sub_transpose(st, n, W.Fp.p, W.t2.p);                                             // e = FDS - (FDS)^T = FDS - SDF
-    int rc = diis.fock_step(st, W.t2.p, W.t1.p, W.Fd.p);
+    qc_sub_transpose(st, n, W.Fp.p, dE);                                                 // e = FDS - (FDS)^T = FDS - SDF
+    int rc = diis.extrapolate(st, W.Fd.p, W.ctl + 8);
     if (rc != QC_OK) return rc;
     qc_gemm(st, n, n, n, 1.0, W.Fd.p, n, false, W.X.p, n, false, 0.0, W.t1.p, n);        // F X
-    qc_gemm(st, n, n, n, 1.0, W.X.p, n, true, W.t1.p, n, false, 0.0, W.Fp.p, n);         // X^T (F X)
-    // sorted_eigs (rhf.rs:75), warm-started from this spin's previous eigenvectors once they exist
-    if (W.have_prev[spin]) rc = qc_eig_device_refine(st, n, W.Fp.p, W.CpPrev[spin].p, W.Cp.p, dw_out, W.ework.p, W.t1.p, W.t2.p, W.t3.p, W.t4.p, W.small.p);
-    else rc = device_sorted_eigs(S, W, W.Fp.p, W.Cp.p, dw_out);
+    qc_gemm(st, n, n, n, 1.0, W.X.p, n, true, W.t1.p, n, false, 0.0, W.Fps[spin].p, n);  // X^T (F X)
+    if (W.have_prev[spin])
+        rc = qc_eig_refine_async(st, n, W.Fps[spin].p, W.CpPrev[spin].p, W.CpNew[spin].p, dw_out, W.ework.p, W.t1.p, W.t2.p, W.t3.p, W.t4.p,
+                                 W.small.p, W.ctl + 4 * spin, W.npass[spin]);
+    else rc = device_sorted_eigs(S, W, W.Fps[spin].p, W.CpNew[spin].p, dw_out);          // sorted_eigs (rhf.rs:75), cold
     if (rc != QC_OK) return rc;
-    QC_HIP_CHECK(hipMemcpyAsync(W.CpPrev[spin].p, W.Cp.p, sizeof(double) * n * n, hipMemcpyDeviceToDevice, st));
-    W.have_prev[spin] = true;
-    qc_gemm(st, n, n, n, 1.0, W.X.p, n, false, W.Cp.p, n, false, 0.0, W.C.p, n);         // C = X C'
+    qc_gemm(st, n, n, n, 1.0, W.X.p, n, false, W.CpNew[spin].p, n, false, 0.0, dC, n);   // C = X C'
+    return QC_OK;
+}
+
+// the rare repeat of a spin's eigensolve when the sync-free refinement asked for rotations (ctl = 2)
+int roothaan_redo_eig(qc_system *S, ScfWork &W, double *dw_out, double *dC, int spin) {
+    const int n = S->nbasis;
+    hipStream_t st = S->stream;
+    int rc = qc_eig_device_refine(st, n, W.Fps[spin].p, W.CpPrev[spin].p, W.CpNew[spin].p, dw_out, W.ework.p, W.t1.p, W.t2.p, W.t3.p, W.t4.p, W.small.p);
+    if (rc != QC_OK) return rc;
+    qc_gemm(st, n, n, n, 1.0, W.X.p, n, false, W.CpNew[spin].p, n, false, 0.0, dC, n);
     return QC_OK;
 }
 
@@ -275,21 +261,25 @@ int qc_eri_full(qc_system *S, double *out) {
 
 }  // extern "C"
 
-int qc_fock_build_device(qc_system *S, const double *dDa, const double *dDb, double *dGa, double *dGb, bool uhf) {
+int qc_fock_build_device(qc_system *S, const double *dDa, const double *dDb, double *dGa, double *dGb, bool uhf, int *twin_cache) {
     const int n = S->nbasis;
     const size_t nn = (size_t)n * n;
     hipStream_t st = S->stream;
     // Spin symmetry: the reference evaluates both spins with identical arithmetic (uhf.rs:210-227), so bitwise-equal
     // densities give bitwise-equal G (its closed-shell UHF never breaks symmetry).  Atomic accumulation
     // order would not preserve that, so equal spins are detected and digested once.
+    // Inside an SCF run the answer cannot change (equal spins stay equal under identical arithmetic, different ones stay
+    // different), so the drivers pass a cache and only their first build pays the host round trip.
     bool twin = false;
-    if (uhf) {
+    if (uhf && twin_cache && *twin_cache >= 0) twin = *twin_cache != 0;
+    else if (uhf) {
         int diff = 1;
         QC_HIP_CHECK(hipMemsetAsync(S->d_flag, 0, sizeof(int), st));
         qc_count_diff(st, nn, dDa, dDb, S->d_flag);
         QC_HIP_CHECK(hipMemcpyAsync(&diff, S->d_flag, sizeof(int), hipMemcpyDeviceToHost, st));
         QC_HIP_CHECK(hipStreamSynchronize(st));
         twin = (diff == 0);
+        if (twin_cache) *twin_cache = twin ? 1 : 0;
     }
     const bool two = uhf && !twin;
     const int nspin = two ? 2 : 1;
@@ -415,15 +405,17 @@ struct qc_scf_state {
     bool uhf = false;
     int nocc[2] = {0, 0};
     ScfWork W;
-    DevBuf D, Dn, G, Cs, ws;
+    DevBuf D[2], Dn[2], G, Cs, ws;             // densities are double-buffered per spin: D <-> Dn swap when a pass is accepted
     DevBuf T4, TK, Dtot;                       // stored mode: RHF T = I - I^x / 2; UHF I and its exchange-permuted copy
     bool stored = false;
+    int twin = -1;                             // UHF spin-twin decision, taken at the first build
     double ms_tensor = 0;
     DeviceDiis *diis[2] = {nullptr, nullptr};
     hipEvent_t ev0 = nullptr, ev1 = nullptr, ev2 = nullptr;
     double ms_fock = 0, ms_linalg = 0, ms_setup = 0;
     ~qc_scf_state() {
         delete diis[0]; delete diis[1];
+        if (S && S->stream) (void)hipStreamSynchronize(S->stream);
         if (ev0) (void)hipEventDestroy(ev0);
         if (ev1) (void)hipEventDestroy(ev1);
         if (ev2) (void)hipEventDestroy(ev2);
@@ -446,12 +438,12 @@ static int scf_begin(qc_system *S, bool uhf, int n_alpha, int n_beta, qc_scf_sta
     if (st->nocc[0] < 0 || st->nocc[1] < 0 || st->nocc[0] > n || st->nocc[1] > n) return QC_ERR_INVALID;
     const int nspin = uhf ? 2 : 1;
     if ((rc = st->W.init(n)) != QC_OK) return rc;
-    if (st->D.alloc(nspin * nn) != QC_OK || st->Dn.alloc(nn) != QC_OK || st->G.alloc(nspin * nn) != QC_OK ||
-        st->Cs.alloc(nspin * nn) != QC_OK || st->ws.alloc(nspin * n) != QC_OK) return QC_ERR_HIP;
+    for (int s = 0; s < nspin; ++s) if (st->D[s].alloc(nn) != QC_OK || st->Dn[s].alloc(nn) != QC_OK) return QC_ERR_HIP;
+    if (st->G.alloc(nspin * nn) != QC_OK || st->Cs.alloc(nspin * nn) != QC_OK || st->ws.alloc(nspin * n) != QC_OK) return QC_ERR_HIP;
     std::vector<double> h_eht;
     if ((rc = scf_setup(S, st->W, h_eht)) != QC_OK) return rc;           // rhf.rs:41-49
     for (int s = 0; s < nspin; ++s)                                       // rhf.rs:50 / uhf.rs:60-63
-        if ((rc = huckel_density(S, st->W, h_eht, st->nocc[s], uhf ? 1.0 : 2.0, st->D.p + s * nn)) != QC_OK) return rc;
+        if ((rc = huckel_density(S, st->W, h_eht, st->nocc[s], uhf ? 1.0 : 2.0, st->D[s].p)) != QC_OK) return rc;
     if (S->fock_mode == 1) {
         // the reference's conventional SCF: ERI tensor once (rhf.rs:45), antisymmetrised copy (rhf.rs:58-62), dense
         // contraction per pass.  8 n^4 bytes per tensor; two of them live during the build.
@@ -487,10 +479,22 @@ static int scf_begin(qc_system *S, bool uhf, int n_alpha, int n_beta, qc_scf_sta
     return QC_OK;
 }
 
+// Wait for an event by polling (what hipStreamSynchronize does too): a parked thread's wake-up latency is longer
+// than a whole SCF pass of a small molecule.
+static hipError_t wait_event(hipEvent_t ev) {
+    hipError_t e;
+    while ((e = hipEventQuery(ev)) == hipErrorNotReady) {}
+    return e;
+}
+
 // one pass of the loop body.  RHF: rhf.rs:67-88.  UHF: uhf.rs:81-137 (returns the reference's `density_rms`,
 // i.e. (rms_a + rms_b) / 2, and the energy expression of uhf.rs:145-153 evaluated every pass).
+// The whole pass is enqueued without looking at the device; one synchronisation at its end returns the energy, the rms
+// and the control words (DIIS failure, eigen-refinement outcome).  Launch latency of ~50 small kernels then overlaps with
+// their execution instead of adding to it.
 static int scf_iterate(qc_scf_state *st, double *energy, double *rms_out) {
     qc_system *S = st->S;
+    ScfWork &W = st->W;
     const int n = S->nbasis;
     const size_t nn = (size_t)n * n;
     hipStream_t sm = S->stream;
@@ -500,35 +504,69 @@ static int scf_iterate(qc_scf_state *st, double *energy, double *rms_out) {
     // G of every spin from the *old* densities
     if (st->stored) {
         if (st->uhf) {   // uhf.rs:216-226: G_s = <I, D_s + D_s'> - <I^x, D_s>
-            qc_axpby(sm, n, 1.0, st->D.p, 1.0, st->D.p + nn, st->Dtot.p);
-            qc_axpby(sm, n, -1.0, st->D.p, 0.0, nullptr, st->W.t1.p);
-            qc_tensor_gemv(sm, n, st->T4.p, st->Dtot.p, st->TK.p, st->W.t1.p, st->G.p);
-            qc_axpby(sm, n, -1.0, st->D.p + nn, 0.0, nullptr, st->W.t1.p);
-            qc_tensor_gemv(sm, n, st->T4.p, st->Dtot.p, st->TK.p, st->W.t1.p, st->G.p + nn);
+            qc_axpby(sm, n, 1.0, st->D[0].p, 1.0, st->D[1].p, st->Dtot.p);
+            qc_axpby(sm, n, -1.0, st->D[0].p, 0.0, nullptr, W.t1.p);
+            qc_tensor_gemv(sm, n, st->T4.p, st->Dtot.p, st->TK.p, W.t1.p, st->G.p);
+            qc_axpby(sm, n, -1.0, st->D[1].p, 0.0, nullptr, W.t1.p);
+            qc_tensor_gemv(sm, n, st->T4.p, st->Dtot.p, st->TK.p, W.t1.p, st->G.p + nn);
         } else {
-            qc_tensor_gemv(sm, n, st->T4.p, st->D.p, nullptr, nullptr, st->G.p);   // rhf.rs:152-167
+            qc_tensor_gemv(sm, n, st->T4.p, st->D[0].p, nullptr, nullptr, st->G.p);   // rhf.rs:152-167
         }
-    } else if ((rc = qc_fock_build_device(S, st->D.p, st->uhf ? st->D.p + nn : nullptr, st->G.p, st->uhf ? st->G.p + nn : nullptr, st->uhf)) != QC_OK) return rc;
+    } else if ((rc = qc_fock_build_device(S, st->D[0].p, st->uhf ? st->D[1].p : nullptr, st->G.p, st->uhf ? st->G.p + nn : nullptr, st->uhf,
+                                          &st->twin)) != QC_OK) return rc;
+    // (Enqueueing the *next* pass's build here, ahead of the wait below, was tried: its side-stream launches then sit
+    // behind unsignalled barriers while the main queue still works, and with 8 hardware queues on 4 pipes the blocked
+    // queues stall their pipe neighbours - 1.6 ms per pass instead of 0.6.)
     QC_HIP_CHECK(hipEventRecord(st->ev1, sm));
+    QC_HIP_CHECK(hipMemsetAsync(W.ctl, 0, 16 * sizeof(int), sm));
+    for (int s = 0; s < nspin; ++s)
+        if ((rc = roothaan_enqueue(S, W, *st->diis[s], st->G.p + s * nn, st->D[s].p, st->ws.p + s * n, st->Cs.p + s * nn, s)) != QC_OK) return rc;
+    auto density_and_scalars = [&](int s) -> int {
+        if (st->nocc[s] > 0) qc_gemm(sm, n, n, st->nocc[s], st->uhf ? 1.0 : 2.0, st->Cs.p + s * nn, n, false, st->Cs.p + s * nn, n, true, 0.0, st->Dn[s].p, n);
+        else QC_HIP_CHECK(hipMemsetAsync(st->Dn[s].p, 0, nn * sizeof(double), sm));
+        qc_energy_rms(sm, n, st->Dn[s].p, st->D[s].p, W.H.p, st->G.p + s * nn, W.scal.p + 2 * s);
+        return QC_OK;
+    };
+    for (int s = 0; s < nspin; ++s) if ((rc = density_and_scalars(s)) != QC_OK) return rc;
+    int *h_ctl = reinterpret_cast<int *>(W.h_scal + 4);
+    QC_HIP_CHECK(hipMemcpyAsync(W.h_scal, W.scal.p, 4 * sizeof(double), hipMemcpyDeviceToHost, sm));
+    QC_HIP_CHECK(hipMemcpyAsync(h_ctl, W.ctl, 16 * sizeof(int), hipMemcpyDeviceToHost, sm));
+    QC_HIP_CHECK(hipEventRecord(st->ev2, sm));
+    QC_HIP_CHECK(wait_event(st->ev2));
+    if (h_ctl[8] != 0) return QC_DIIS_SINGULAR;                          // "DIIS failed", rhf.rs:73
+    static const bool dbg = getenv("QC_SCF_DEBUG") != nullptr;
+    if (dbg) fprintf(stderr, "[scf] ctl a: %d %d %d %d  b: %d %d %d %d  npass %d %d have_prev %d\n", h_ctl[0], h_ctl[1], h_ctl[2], h_ctl[3], h_ctl[4], h_ctl[5], h_ctl[6], h_ctl[7], W.npass[0], W.npass[1], (int)W.have_prev[0]);
+    float ms_f = 0, ms_l = 0;
+    (void)hipEventElapsedTime(&ms_f, st->ev0, st->ev1);
+    (void)hipEventElapsedTime(&ms_l, st->ev1, st->ev2);
+    bool redo = false;
     for (int s = 0; s < nspin; ++s) {
-        if ((rc = roothaan_step(S, st->W, *st->diis[s], st->G.p + s * nn, st->D.p + s * nn, st->ws.p + s * n, s)) != QC_OK) return rc;
-        QC_HIP_CHECK(hipMemcpyAsync(st->Cs.p + s * nn, st->W.C.p, nn * sizeof(double), hipMemcpyDeviceToDevice, sm));
+        if (!W.have_prev[s]) continue;
+        if (h_ctl[4 * s] == 1) { W.npass[s] = std::max(1, std::min(3, h_ctl[4 * s + 3])); continue; }
+        W.npass[s] = 3;
+        // the refinement wanted rotations (large step, or a degenerate cluster): repeat this spin's eigensolve the careful way
+        if (!redo) QC_HIP_CHECK(hipEventRecord(st->ev1, sm));
+        if ((rc = roothaan_redo_eig(S, W, st->ws.p + s * n, st->Cs.p + s * nn, s)) != QC_OK) return rc;
+        if ((rc = density_and_scalars(s)) != QC_OK) return rc;
+        redo = true;
+    }
+    if (redo) {
+        QC_HIP_CHECK(hipMemcpyAsync(W.h_scal, W.scal.p, 4 * sizeof(double), hipMemcpyDeviceToHost, sm));
+        QC_HIP_CHECK(hipEventRecord(st->ev2, sm));
+        QC_HIP_CHECK(wait_event(st->ev2));
+        float ms_r = 0;
+        (void)hipEventElapsedTime(&ms_r, st->ev1, st->ev2);
+        ms_l += ms_r;
     }
     double rms_sum = 0.0, e_sum = 0.0;
     for (int s = 0; s < nspin; ++s) {
-        if (st->nocc[s] > 0) qc_gemm(sm, n, n, st->nocc[s], st->uhf ? 1.0 : 2.0, st->Cs.p + s * nn, n, false, st->Cs.p + s * nn, n, true, 0.0, st->Dn.p, n);
-        else QC_HIP_CHECK(hipMemsetAsync(st->Dn.p, 0, nn * sizeof(double), sm));
-        qc_energy_rms(sm, n, st->Dn.p, st->D.p + s * nn, st->W.H.p, st->G.p + s * nn, st->W.scal.p + 2 * s);
-        QC_HIP_CHECK(hipMemcpyAsync(st->D.p + s * nn, st->Dn.p, nn * sizeof(double), hipMemcpyDeviceToDevice, sm));   // D += 1.0 * dD
+        e_sum += W.h_scal[2 * s]; rms_sum += std::sqrt(W.h_scal[2 * s + 1] / n);
+        std::swap(st->D[s].p, st->Dn[s].p);                              // D += 1.0 * dD
+        std::swap(W.CpPrev[s].p, W.CpNew[s].p);
+        W.have_prev[s] = true;
     }
-    double er[4];
-    QC_HIP_CHECK(hipMemcpyAsync(er, st->W.scal.p, 2 * nspin * sizeof(double), hipMemcpyDeviceToHost, sm));
-    QC_HIP_CHECK(hipEventRecord(st->ev2, sm));
-    QC_HIP_CHECK(hipStreamSynchronize(sm));
-    for (int s = 0; s < nspin; ++s) { e_sum += er[2 * s]; rms_sum += std::sqrt(er[2 * s + 1] / n); }
-    float ms_f = 0, ms_l = 0;
-    (void)hipEventElapsedTime(&ms_f, st->ev0, st->ev1); (void)hipEventElapsedTime(&ms_l, st->ev1, st->ev2);
-    st->ms_fock += ms_f; st->ms_linalg += ms_l;
+    st->ms_fock += ms_f;
+    st->ms_linalg += ms_l;
     if (energy) *energy = e_sum;
     if (rms_out) *rms_out = st->uhf ? rms_sum / 2.0 : rms_sum;
     return QC_OK;
@@ -579,7 +617,7 @@ int qc_scf_orbital_energies(qc_scf_state *st, int spin, double *out) {
 int qc_scf_density(qc_scf_state *st, int spin, double *out) {
     if (!st || !out || spin < 0 || spin > (st->uhf ? 1 : 0)) return QC_ERR_INVALID;
     const size_t nn = (size_t)st->S->nbasis * st->S->nbasis;
-    QC_HIP_CHECK(hipMemcpy(out, st->D.p + spin * nn, nn * sizeof(double), hipMemcpyDeviceToHost));
+    QC_HIP_CHECK(hipMemcpy(out, st->D[spin].p, nn * sizeof(double), hipMemcpyDeviceToHost));
     return QC_OK;
 }
 int qc_set_fock_mode(qc_system *S, int mode) {

@@ -148,11 +148,15 @@ struct QcFockArgs {
 int qc_launch_eri_full(qc_system *S, double *d_out);
 void qc_drop_graphs(qc_system *S);
 int qc_launch_fock_classes(qc_system *S, const QcFockArgs &a, float *class_ms /*nullable*/, float *unit_ms = nullptr /*nullable, 14*/);
-int qc_fock_build_device(qc_system *S, const double *dDa, const double *dDb, double *dGa, double *dGb, bool uhf);
+int qc_fock_build_device(qc_system *S, const double *dDa, const double *dDb, double *dGa, double *dGb, bool uhf, int *twin_cache = nullptr);
 
 // dense linear algebra on the handle's stream (all row-major n x n, device pointers)
 void qc_gemm(hipStream_t st, int m, int n, int k, double alpha, const double *A, int lda, bool ta, const double *B,
-             int ldb, bool tb, double beta, double *C, int ldc);
+             int ldb, bool tb, double beta, double *C, int ldc, const int *skip = nullptr /* device flag: non-zero = no-op */);
+int qc_eig_refine_async(hipStream_t st, int n, double *dA, const double *dV0, double *dV, double *dw, double *d_work, double *t1, double *t2,
+                        double *t3, double *t4, double *small, int *ctl, int npass);
+void qc_diis_solve(hipStream_t st, int m, int minlen, int maxlen, const int *slots, const double *dots, double *B, double *c, int *flag);
+void qc_lincomb_dev(hipStream_t st, int n, const double *const *Fs, const double *c_dev, int m, double *out);
 int qc_eig_device(hipStream_t st, int n, double *dA /*destroyed*/, double *dV, double *dw, double *d_work);
 int qc_eig_device_warm(hipStream_t st, int n, double *dA, const double *dV0, double *dV, double *dw, double *d_work, double *t1, double *t2);
 int qc_eig_device_refine(hipStream_t st, int n, double *dA, const double *dV0, double *dV, double *dw, double *d_work, double *t1, double *t2,

@@ -18,7 +18,8 @@ typedef double double4_t __attribute__((ext_vector_type(4)));
 // B[k = l >> 4][j = l & 15]; result register r holds C[row = (l >> 4) + 4 r][col = l & 15].
 __global__ __launch_bounds__(64) void qc_gemm_kernel(int m, int n, int k, double alpha, const double *__restrict__ A, int lda, int ta,
                                                      const double *__restrict__ B, int ldb, int tb, double beta, double *__restrict__ C,
-                                                     int ldc) {
+                                                     int ldc, const int *__restrict__ skip) {
+    if (skip && *skip != 0) return;                        // device-side control flow of the sync-free SCF step
     const int lane = threadIdx.x, li = lane & 15, lk = lane >> 4;
     const int row0 = blockIdx.y * 16, col0 = blockIdx.x * 16;
     const int ai = row0 + li, bj = col0 + li;
@@ -50,9 +51,9 @@ __global__ __launch_bounds__(64) void qc_gemm_kernel(int m, int n, int k, double
 }
 
 void qc_gemm(hipStream_t st, int m, int n, int k, double alpha, const double *A, int lda, bool ta, const double *B, int ldb, bool tb,
-             double beta, double *C, int ldc) {
+             double beta, double *C, int ldc, const int *skip) {
     dim3 grid((n + 15) / 16, (m + 15) / 16);
-    hipLaunchKernelGGL(qc_gemm_kernel, grid, dim3(64), 0, st, m, n, k, alpha, A, lda, ta ? 1 : 0, B, ldb, tb ? 1 : 0, beta, C, ldc);
+    hipLaunchKernelGGL(qc_gemm_kernel, grid, dim3(64), 0, st, m, n, k, alpha, A, lda, ta ? 1 : 0, B, ldb, tb ? 1 : 0, beta, C, ldc, skip);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -419,7 +420,9 @@ int qc_eig_device_warm(hipStream_t st, int n, double *dA, const double *dV0, dou
 constexpr double QC_REF_TAU = 1e-3, QC_REF_TINY = 1e-13, QC_REF_GFLOOR = 1e-8;
 
 __global__ __launch_bounds__(1024) void qc_refine_stats_kernel(int n, const double *__restrict__ S, const double *__restrict__ XtX,
-                                                                double *__restrict__ lam, double *__restrict__ stats, int *__restrict__ partner) {
+                                                                double *__restrict__ lam, double *__restrict__ stats, int *__restrict__ partner,
+                                                                int *__restrict__ ctl) {
+    if (ctl && ctl[0] != 0) return;
     __shared__ double red[4 * 16];
     __shared__ double sh_scale;
     __shared__ int sh_multi, sh_nstrong;
@@ -445,9 +448,9 @@ __global__ __launch_bounds__(1024) void qc_refine_stats_kernel(int n, const doub
     __syncthreads();                                         // lam[] (global, written by this workgroup) is visible
     const double scale = sh_scale, tiny = QC_REF_TINY * scale, gfloor = QC_REF_GFLOOR * scale;
     double cmax = 0.0, emax = 0.0;
-    for (int i = tid; i < n; i += 1024) {                    // one row per thread
+    for (int i = tid >> 4; i < n; i += 64) {                 // one row per team of 16 lanes
         int cnt = 0, who = -1;
-        for (int j = 0; j < n; ++j) {
+        for (int j = tid & 15; j < n; j += 16) {
             if (j == i) continue;
             const double r = -XtX[(size_t)i * n + j];
             const double sij = 0.5 * (S[(size_t)i * n + j] + S[(size_t)j * n + i]);   // A is symmetric only to rounding
@@ -457,9 +460,13 @@ __global__ __launch_bounds__(1024) void qc_refine_stats_kernel(int n, const doub
             else if (g <= gfloor) cmax = fmax(cmax, a);
             else emax = fmax(emax, a / g);
         }
-        partner[i] = cnt == 0 ? -1 : (cnt == 1 ? who : -2);
-        if (cnt > 1) sh_multi = 1;
-        if (cnt == 1) atomicAdd(&sh_nstrong, 1);
+#pragma unroll
+        for (int o = 8; o > 0; o >>= 1) { cnt += __shfl_xor(cnt, o, 16); who = max(who, __shfl_xor(who, o, 16)); }
+        if ((tid & 15) == 0) {
+            partner[i] = cnt == 0 ? -1 : (cnt == 1 ? who : -2);
+            if (cnt > 1) sh_multi = 1;
+            if (cnt == 1) atomicAdd(&sh_nstrong, 1);
+        }
     }
     for (int o = 32; o > 0; o >>= 1) { cmax = fmax(cmax, __shfl_down(cmax, o, 64)); emax = fmax(emax, __shfl_down(emax, o, 64)); }
     __syncthreads();
@@ -472,12 +479,22 @@ __global__ __launch_bounds__(1024) void qc_refine_stats_kernel(int n, const doub
         int multi = sh_multi;
         for (int i = 0; i < n && !multi; ++i) if (partner[i] >= 0 && partner[partner[i]] != i) multi = 1;
         stats[3] = 0.5 * sh_nstrong; stats[4] = a; stats[5] = b; stats[6] = multi;
+        if (ctl) {   // the decisions qc_eig_device_refine takes on the host, for the sync-free variant
+            const double orth = stats[1], scl = fmax(stats[2], 1e-300);
+            if (!(b <= 0.1) || !(orth <= 1e-3) || multi) ctl[0] = 2;             // not perturbative: rotations needed
+            else {
+                ctl[1] = (b <= 1e-7 && orth <= 1e-7 && sh_nstrong == 0) ? 1 : 0;   // one more update finishes
+                ctl[2] = (a <= 1e-12 * scl) ? 1 : 0;                               // no coupling left inside degenerate pairs
+            }
+        }
     }
 }
 
 // M = I + E with exact rotations on the strong pairs
 __global__ void qc_refine_update_kernel(int n, const double *__restrict__ S, const double *__restrict__ XtX, const double *__restrict__ lam,
-                                        const double *__restrict__ stats, const int *__restrict__ partner, double *__restrict__ M) {
+                                        const double *__restrict__ stats, const int *__restrict__ partner, double *__restrict__ M,
+                                        const int *__restrict__ ctl) {
+    if (ctl && ctl[0] != 0) return;
     const double scale = stats[2], tiny = QC_REF_TINY * scale, gfloor = QC_REF_GFLOOR * scale;
     for (int x = blockIdx.x * blockDim.x + threadIdx.x; x < n * n; x += gridDim.x * blockDim.x) {
         const int i = x / n, j = x - i * n;
@@ -554,7 +571,7 @@ int qc_eig_device_refine(hipStream_t st, int n, double *dA, const double *dV0, d
         qc_gemm(st, n, n, n, 1.0, dA, n, false, X, n, false, 0.0, t1, n);          // A X
         qc_gemm(st, n, n, n, 1.0, X, n, true, t1, n, false, 0.0, t2, n);           // S = X^T A X
         qc_gemm(st, n, n, n, 1.0, X, n, true, X, n, false, 0.0, t3, n);            // X^T X
-        hipLaunchKernelGGL(qc_refine_stats_kernel, dim3(1), dim3(1024), 0, st, n, t2, t3, lam, stats, partner);
+        hipLaunchKernelGGL(qc_refine_stats_kernel, dim3(1), dim3(1024), 0, st, n, t2, t3, lam, stats, partner, (int *)nullptr);
         if (hipMemcpyAsync(hs, stats, 7 * sizeof(double), hipMemcpyDeviceToHost, st) != hipSuccess) return QC_ERR_HIP;
         if (hipStreamSynchronize(st) != hipSuccess) return QC_ERR_HIP;
         const double scale = fmax(hs[2], 1e-300), orth = hs[1], nstrong = hs[3], cmax = hs[4], emax = hs[5], multi = hs[6];
@@ -571,7 +588,7 @@ int qc_eig_device_refine(hipStream_t st, int n, double *dA, const double *dV0, d
             return QC_OK;
         }
         const bool last = emax <= 1e-7 && orth <= 1e-7 && nstrong == 0.0;
-        hipLaunchKernelGGL(qc_refine_update_kernel, dim3((unsigned)((nn + 255) / 256)), dim3(256), 0, st, n, t2, t3, lam, stats, partner, t1);
+        hipLaunchKernelGGL(qc_refine_update_kernel, dim3((unsigned)((nn + 255) / 256)), dim3(256), 0, st, n, t2, t3, lam, stats, partner, t1, (const int *)nullptr);
         qc_gemm(st, n, n, n, 1.0, X, n, false, t1, n, false, 0.0, d_work, n);      // X (I + E): error now ~ emax^2
         if (last && cmax <= 1e-12 * scale) {   // lam is second-order accurate already; d_work holds the final vectors
             hipLaunchKernelGGL(qc_sort_columns_kernel, dim3(1), dim3(1024), n * sizeof(int), st, n, lam, d_work, dw, dV);
@@ -590,6 +607,141 @@ int qc_eig_device_refine(hipStream_t st, int n, double *dA, const double *dV0, d
         }
     }
     return QC_ERR_HIP;   // not reached
+}
+
+// Sync-free variant for the SCF loop: a fixed number of passes is enqueued, every kernel looks at the device-side control
+// word ctl[0] (0 running, 1 done, 2 rotations needed) and returns at once when the refinement has ended.  The caller
+// reads ctl[0] together with the iteration's energy; on 2 it repeats the eigensolve with qc_eig_device_refine.
+__global__ __launch_bounds__(1024) void qc_refine_finish_kernel(int n, const double *__restrict__ lam, const double *__restrict__ Xn,
+                                                                 double *__restrict__ X, double *__restrict__ w, double *__restrict__ Xs,
+                                                                 int *__restrict__ ctl, int final_pass) {
+    if (ctl[0] != 0) return;
+    extern __shared__ int rank_s[];
+    const int tid = threadIdx.x;
+    const int last = ctl[1], clean = ctl[2];
+    __syncthreads();
+    if (tid == 0) ctl[3] += 1;                              // passes used (the host sizes the next step's pipeline with it)
+    if (last && clean) {                                    // Xn holds the final vectors: ascending eigenvalues, columns alongside
+        for (int i = tid; i < n; i += 1024) {
+            const double wi = lam[i];
+            int r = 0;
+            for (int j = 0; j < n; ++j) r += (lam[j] < wi || (lam[j] == wi && j < i)) ? 1 : 0;
+            rank_s[i] = r;
+            w[r] = wi;
+        }
+        __syncthreads();
+        for (int x = tid; x < n * n; x += 1024) {
+            const int i = x / n, j = x - i * n;
+            Xs[(size_t)i * n + rank_s[j]] = Xn[x];
+        }
+        __syncthreads();
+        if (tid == 0) ctl[0] = 1;
+    } else if (last || final_pass) {
+        __syncthreads();
+        if (tid == 0) ctl[0] = 2;                           // coupling inside a degenerate cluster, or passes exhausted
+    } else {
+        for (int x = tid; x < n * n; x += 1024) X[x] = Xn[x];
+    }
+}
+
+int qc_eig_refine_async(hipStream_t st, int n, double *dA, const double *dV0, double *dV, double *dw, double *d_work, double *t1, double *t2,
+                        double *t3, double *t4, double *small, int *ctl, int npass) {
+    const size_t nn = (size_t)n * n;
+    double *lam = small, *stats = small + n;
+    int *partner = reinterpret_cast<int *>(small + n + 8);
+    // ctl[0..3] must be zero on entry (the SCF step clears all control words with one memset)
+    const double *X = dV0;                                    // pass 0 reads the start vectors in place, later passes t4
+    for (int pass = 0; pass < npass; ++pass) {
+        qc_gemm(st, n, n, n, 1.0, dA, n, false, X, n, false, 0.0, t1, n, ctl);          // A X
+        qc_gemm(st, n, n, n, 1.0, X, n, true, t1, n, false, 0.0, t2, n, ctl);           // S = X^T A X
+        qc_gemm(st, n, n, n, 1.0, X, n, true, X, n, false, 0.0, t3, n, ctl);            // X^T X
+        hipLaunchKernelGGL(qc_refine_stats_kernel, dim3(1), dim3(1024), 0, st, n, t2, t3, lam, stats, partner, ctl);
+        hipLaunchKernelGGL(qc_refine_update_kernel, dim3((unsigned)((nn + 255) / 256)), dim3(256), 0, st, n, t2, t3, lam, stats, partner, t1, (const int *)ctl);
+        qc_gemm(st, n, n, n, 1.0, X, n, false, t1, n, false, 0.0, d_work, n, ctl);      // X (I + E)
+        hipLaunchKernelGGL(qc_refine_finish_kernel, dim3(1), dim3(1024), n * sizeof(int), st, n, lam, d_work, t4, dw, dV, ctl, pass == npass - 1 ? 1 : 0);
+        X = t4;
+    }
+    return hipGetLastError() == hipSuccess ? QC_OK : QC_ERR_HIP;
+}
+
+// DIIS coefficients on the device (diis.rs:40-51): B is kept slot-indexed in HBM, the new row <e_0, e_j> arrives in
+// `dots` (window order, newest first); Householder QR with the arithmetic of nalgebra's qr().solve(); one thread.
+struct QcDiisArgs { int m, minlen, maxlen; int slot[12]; };
+// the (m+1) x (m+1) system entirely in registers: every loop bound is a compile-time constant
+template <int M>
+__device__ __forceinline__ bool qc_qr_solve_reg(double (&A)[M * M], double (&y)[M], double (&x)[M]) {
+#pragma unroll
+    for (int k = 0; k < M; ++k) {
+        double norm = 0.0;
+#pragma unroll
+        for (int i = k; i < M; ++i) norm += A[i * M + k] * A[i * M + k];
+        norm = sqrt(norm);
+        if (norm == 0.0) return false;
+        const double alpha = A[k * M + k] > 0 ? -norm : norm;
+        double v[M];
+        double vn = 0.0;
+#pragma unroll
+        for (int i = k; i < M; ++i) { v[i] = A[i * M + k] - (i == k ? alpha : 0.0); vn += v[i] * v[i]; }
+        if (vn > 0.0) {
+#pragma unroll
+            for (int j = k; j < M; ++j) {
+                double d = 0.0;
+#pragma unroll
+                for (int i = k; i < M; ++i) d += v[i] * A[i * M + j];
+                d *= 2.0 / vn;
+#pragma unroll
+                for (int i = k; i < M; ++i) A[i * M + j] -= d * v[i];
+            }
+            double d = 0.0;
+#pragma unroll
+            for (int i = k; i < M; ++i) d += v[i] * y[i];
+            d *= 2.0 / vn;
+#pragma unroll
+            for (int i = k; i < M; ++i) y[i] -= d * v[i];
+        }
+    }
+#pragma unroll
+    for (int i = M - 1; i >= 0; --i) {
+        double s = y[i];
+#pragma unroll
+        for (int j = i + 1; j < M; ++j) s -= A[i * M + j] * x[j];
+        if (A[i * M + i] == 0.0) return false;
+        x[i] = s / A[i * M + i];
+    }
+    return true;
+}
+
+template <int M>
+__global__ void qc_diis_solve_kernel(QcDiisArgs a, const double *__restrict__ dots, double *B, double *__restrict__ c, int *__restrict__ flag) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    constexpr int m = M - 1;
+    const int ML = a.maxlen;
+#pragma unroll
+    for (int j = 0; j < m; ++j) { const double d = dots[j]; B[a.slot[0] * ML + a.slot[j]] = d; B[a.slot[j] * ML + a.slot[0]] = d; }
+    c[0] = 1.0;
+#pragma unroll
+    for (int j = 1; j < 12; ++j) c[j] = 0.0;
+    if (m < a.minlen) return;                               // diis.rs:33-38: hand back the newest Fock matrix
+    double A[M * M], y[M], x[M];
+#pragma unroll
+    for (int i = 0; i < m; ++i) {
+#pragma unroll
+        for (int j = 0; j < m; ++j) A[i * M + j] = B[a.slot[i] * ML + a.slot[j]];
+        A[i * M + m] = 1.0; A[m * M + i] = 1.0; y[i] = 0.0;  // border +1, corner 0 (diis.rs:40-46)
+    }
+    A[m * M + m] = 0.0; y[m] = 1.0;
+    if (!qc_qr_solve_reg<M>(A, y, x)) { *flag = 1; return; }   // "DIIS failed" (rhf.rs:73); c stays (1, 0, ...)
+#pragma unroll
+    for (int j = 0; j < m; ++j) c[j] = x[j];
+}
+void qc_diis_solve(hipStream_t st, int m, int minlen, int maxlen, const int *slots, const double *dots, double *B, double *c, int *flag) {
+    QcDiisArgs a{};
+    a.m = m; a.minlen = minlen; a.maxlen = maxlen;
+    for (int j = 0; j < m; ++j) a.slot[j] = slots[j];
+#define QC_DIIS_CASE(M) case M - 1: hipLaunchKernelGGL(qc_diis_solve_kernel<M>, dim3(1), dim3(64), 0, st, a, dots, B, c, flag); break;
+    switch (m) { QC_DIIS_CASE(2) QC_DIIS_CASE(3) QC_DIIS_CASE(4) QC_DIIS_CASE(5) QC_DIIS_CASE(6) QC_DIIS_CASE(7) QC_DIIS_CASE(8) QC_DIIS_CASE(9)
+                 QC_DIIS_CASE(10) QC_DIIS_CASE(11) QC_DIIS_CASE(12) default: break; }
+#undef QC_DIIS_CASE
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -793,6 +945,18 @@ __global__ void qc_lincomb_kernel(int nn, QcPtrList Fs, QcCoefList c, int m, dou
         for (int i = 0; i < m; ++i) s = fma(c.c[i], Fs.p[i][x], s);
         out[x] = s;
     }
+}
+__global__ void qc_lincomb_dev_kernel(int nn, QcPtrList Fs, const double *__restrict__ c, int m, double *out) {
+    for (int x = blockIdx.x * blockDim.x + threadIdx.x; x < nn; x += gridDim.x * blockDim.x) {
+        double s = 0.0;
+        for (int i = 0; i < m; ++i) s = fma(c[i], Fs.p[i][x], s);
+        out[x] = s;
+    }
+}
+void qc_lincomb_dev(hipStream_t st, int n, const double *const *Fs, const double *c_dev, int m, double *out) {
+    QcPtrList l;
+    for (int i = 0; i < m; ++i) l.p[i] = Fs[i];
+    hipLaunchKernelGGL(qc_lincomb_dev_kernel, dim3((n * n + 255) / 256), dim3(256), 0, st, n * n, l, c_dev, m, out);
 }
 void qc_lincomb(hipStream_t st, int n, const double *const *Fs, const double *c, int m, double *out) {
     QcPtrList l; QcCoefList cl;
