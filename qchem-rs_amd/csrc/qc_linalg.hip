@@ -177,10 +177,28 @@ __global__ __launch_bounds__(QC_EIG_THREADS) void qc_jacobi_kernel(int n, const 
 // B = A + sigma I is made positive definite with a Gershgorin shift; the columns of G (initially B) are rotated
 // pairwise to mutual orthogonality, G <- G J.  At convergence G = U Sigma: the normalised columns are the
 // eigenvectors and ||g_i|| - sigma the eigenvalues, so only ONE n x n matrix has to live in LDS (column-major,
-// 16 lanes per column pair, conflict-free reads).  One barrier per step.
-constexpr int QC_EIG1_TEAM = 16;
+// 8 lanes per column pair, conflict-free reads).  One barrier per step.  The rotation parameters are computed by every
+// lane of a team, so the kernel is bound by that scalar chain times the number of resident waves: narrow teams (fewer
+// waves) and reciprocal-square-root forms (no IEEE divide / sqrt sequences) make the step 2.4x shorter than the
+// 16-lane / divide version.
+constexpr int QC_EIG1_TEAM = 8;
+constexpr int QC_EIG1_ROWS = 128 / QC_EIG1_TEAM;       // rows per lane of the LDS variant (n <= 128)
+constexpr int QC_EIG1_THREADS = 64 * QC_EIG1_TEAM;     // 64 teams: one per column pair
 
-__global__ __launch_bounds__(QC_EIG_THREADS) void qc_jacobi1_kernel(int n, const double *__restrict__ Ain, double *__restrict__ Vout,
+// Jacobi rotation (c, s) that orthogonalises two columns with squared norms a, b and inner product g; returns the
+// relative coupling |g| / sqrt(a b).
+__device__ __forceinline__ double qc_hestenes_rotation(double a, double b, double g, double &cs, double &sn) {
+    const double rel = fabs(g) * rsqrt(a * b);
+    const double zeta = (b - a) * (0.5 / g);
+    const double z2 = fma(zeta, zeta, 1.0);
+    const double den = fabs(zeta) + z2 * rsqrt(z2);            // |zeta| + sqrt(zeta^2 + 1)
+    const double t = (zeta >= 0.0 ? 1.0 : -1.0) / den;
+    cs = rsqrt(fma(t, t, 1.0));
+    sn = cs * t;
+    return rel;
+}
+
+__global__ __launch_bounds__(QC_EIG1_THREADS) void qc_jacobi1_kernel(int n, const double *__restrict__ Ain, double *__restrict__ Vout,
                                                                     double *__restrict__ w, int max_sweeps) {
     extern __shared__ double sm[];
     const int m = (n + 1) & ~1, half = m / 2, ld = n | 1;        // column stride (doubles)
@@ -220,9 +238,9 @@ __global__ __launch_bounds__(QC_EIG_THREADS) void qc_jacobi1_kernel(int n, const
                 int p, q;
                 qc_rr_pair(step, team, m, p, q);
                 double *gp = G + (size_t)p * ld, *gq = G + (size_t)q * ld;
-                double a = 0.0, b = 0.0, c = 0.0, xp[8], xq[8];
+                double a = 0.0, b = 0.0, c = 0.0, xp[QC_EIG1_ROWS], xq[QC_EIG1_ROWS];
 #pragma unroll
-                for (int k = 0; k < 8; ++k) {
+                for (int k = 0; k < QC_EIG1_ROWS; ++k) {
                     const int r = tl + k * QC_EIG1_TEAM;
                     xp[k] = (r < n) ? gp[r] : 0.0; xq[k] = (r < n) ? gq[r] : 0.0;
                     a = fma(xp[k], xp[k], a); b = fma(xq[k], xq[k], b); c = fma(xp[k], xq[k], c);
@@ -231,13 +249,11 @@ __global__ __launch_bounds__(QC_EIG_THREADS) void qc_jacobi1_kernel(int n, const
                 for (int o = QC_EIG1_TEAM / 2; o > 0; o >>= 1) {
                     a += __shfl_xor(a, o, QC_EIG1_TEAM); b += __shfl_xor(b, o, QC_EIG1_TEAM); c += __shfl_xor(c, o, QC_EIG1_TEAM);
                 }
-                const double rel = fabs(c) / sqrt(a * b);
-                if (rel > 1e-16) {                                 // team-uniform
-                    const double zeta = (b - a) / (2.0 * c);
-                    const double t = (zeta >= 0.0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(fma(zeta, zeta, 1.0)));
-                    const double cs = 1.0 / sqrt(fma(t, t, 1.0)), sn = cs * t;
+                if (c * c > 1e-32 * (a * b)) {                     // team-uniform: |c| / sqrt(a b) > 1e-16
+                    double cs, sn;
+                    const double rel = qc_hestenes_rotation(a, b, c, cs, sn);
 #pragma unroll
-                    for (int k = 0; k < 8; ++k) {
+                    for (int k = 0; k < QC_EIG1_ROWS; ++k) {
                         const int r = tl + k * QC_EIG1_TEAM;
                         if (r < n) { gp[r] = cs * xp[k] - sn * xq[k]; gq[r] = sn * xp[k] + cs * xq[k]; }
                     }
@@ -365,12 +381,12 @@ int qc_eig_device(hipStream_t st, int n, double *dA, double *dV, double *dw, dou
     const size_t lds2 = 2 * (size_t)m * ld * sizeof(double) + tail, lds1 = (size_t)m * ld * sizeof(double) + tail;
     const bool v_in_lds = lds2 <= 160 * 1024;
     static const bool force1 = getenv("QC_EIG_ONESIDED") != nullptr;
-    if ((!v_in_lds || force1) && n <= 8 * QC_EIG1_TEAM) {           // 98 < n <= 128: one-sided variant, a single matrix in LDS
+    if ((!v_in_lds || force1) && n <= QC_EIG1_ROWS * QC_EIG1_TEAM) {   // 98 < n <= 128: one-sided variant, a single matrix in LDS
         const size_t l1 = ((size_t)m * (n | 1) + 32 + m) * sizeof(double) + (size_t)(m + 4) * sizeof(int) + 16;
         if (l1 <= 160 * 1024) {
             hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(qc_jacobi1_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)l1);
             if (e != hipSuccess) return QC_ERR_HIP;
-            hipLaunchKernelGGL(qc_jacobi1_kernel, dim3(1), dim3(QC_EIG_THREADS), l1, st, n, dA, dV, dw, 40);
+            hipLaunchKernelGGL(qc_jacobi1_kernel, dim3(1), dim3(QC_EIG1_THREADS), l1, st, n, dA, dV, dw, 40);
             return hipGetLastError() == hipSuccess ? QC_OK : QC_ERR_HIP;
         }
     }
