@@ -187,7 +187,7 @@ def main():
         pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         if os.path.exists(pmc) and key == "h2o_ccpvtz":   # HBM bytes per build from committed rocprofv3 --pmc passes (same workload)
             try:
-                recs = [v for k2, v in json.load(open(pmc)).items() if k2.startswith("qc_fock_tier_kernel")]
+                recs = [v for k2, v in json.load(open(pmc)).items() if k2.startswith("qc_fock_")]
                 line["roofline"]["traffic"] = {
                     "hbm_bytes": sum(r["hbm_bytes"] for r in recs), "fetch_bytes_x2": sum(r["fetch_bytes_x2"] for r in recs),
                     "write_bytes": sum(r["write_bytes"] or 0 for r in recs), "atomic_requests": sum(r["atomic_requests"] or 0 for r in recs),

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Build profiles/pmc_traffic.json from rocprofv3 --pmc passes (tools/run_pmc.sh <workload> <tag>).
 
-Per Fock tier kernel: HBM traffic per launch from FETCH_SIZE / WRITE_SIZE (separate passes, KB units).  The same kernel
+Per Fock kernel (qc_fock_tier_kernel<LAB, TIER>, qc_fock_bm_kernel<LCD, HI>): HBM traffic per launch from FETCH_SIZE / WRITE_SIZE (separate passes, KB units).  The same kernel
 name is also launched with a single class bucket by bench.py's per-class profile, so dispatches are grouped by grid size
 and the largest grid (= the full tier launch of a real build) is kept.  MI355X_MICROARCH.md: FETCH_SIZE counts 64 B per
 128-B request for wide coalesced reads (x2 correction); this kernel's reads are 8-32 B per lane gathers, which the guide
@@ -13,10 +13,10 @@ def groups(tag, sub):
     out = collections.defaultdict(lambda: collections.defaultdict(list))
     for f in glob.glob("gpurun_out/%s_%s/*/*counter_collection.csv" % (tag, sub)):
         for r in csv.DictReader(open(f)):
-            m = re.search(r"qc_fock_tier_kernel<(\d+), (\d+)>", r["Kernel_Name"])
+            m = re.search(r"(qc_fock_tier_kernel|qc_fock_bm_kernel)<(\d+), (\d+)>", r["Kernel_Name"])
             if not m:
                 continue
-            out["qc_fock_tier_kernel<%s, %s>" % m.groups()][(int(r["Grid_Size"]), r["Counter_Name"])].append(float(r["Counter_Value"]))
+            out["%s<%s, %s>" % m.groups()][(int(r["Grid_Size"]), r["Counter_Name"])].append(float(r["Counter_Value"]))
     return out
 
 def main(tag, workload):

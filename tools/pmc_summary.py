@@ -6,8 +6,8 @@ def load(pattern):
     for f in glob.glob(pattern):
         for r in csv.DictReader(open(f)):
             name = r["Kernel_Name"]
-            m = re.search(r"qc_fock_tier_kernel<(\d+), (\d+)>", name)
-            key = ("tier<%s,%s>" % m.groups() + " g=" + r.get("Grid_Size", "")) if m else name.split("(")[0][:40]
+            m = re.search(r"qc_fock_(tier|bm)_kernel<(\d+), (\d+)>", name)
+            key = ("%s<%s,%s>" % m.groups() + " g=" + r.get("Grid_Size", "")) if m else name.split("(")[0][:40]
             out[key][r["Counter_Name"]].append(float(r["Counter_Value"]))
     return out
 if __name__ == "__main__":
