@@ -1,5 +1,6 @@
 // qc_fock.hip - device set-up and the per-class launch loop of the direct-SCF Fock build.
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 
@@ -129,6 +130,7 @@ void qc_device_free(qc_system *S) {
     }
     if (S->ev_fork) (void)hipEventDestroy(S->ev_fork);
     S->ev_fork = nullptr;
+
     if (S->own_stream && S->stream) (void)hipStreamDestroy(S->stream);
     S->stream = nullptr; S->own_stream = false; S->device_ready = false;
 }
@@ -242,40 +244,89 @@ int qc_launch_fock_classes(qc_system *S, const QcFockArgs &fa, float *class_ms, 
     // stream's, GPU_MAX_HW_QUEUES=8).  Kernels on one stream run in order, so the assignment matters: the first build
     // of a handle times every unit alone (density-independent), then units are placed longest-first on the least
     // loaded stream.
-    if (S->unit_ms.size() != units.size()) {
-        S->unit_ms.assign(units.size(), 0.f);
-        int rc = qc_launch_fock_classes(S, fa, nullptr, S->unit_ms.data());     // serial, timed (results discarded by caller's memset)
-        if (rc != QC_OK) return rc;
-        if (fa.G0) QC_HIP_CHECK(hipMemsetAsync(fa.G0, 0, (size_t)a.nrep * a.rep_stride * sizeof(double), S->stream));
-        std::vector<int> order;
-        for (size_t u = 0; u < units.size(); ++u) if (!units[u].empty()) order.push_back((int)u);
-        std::stable_sort(order.begin(), order.end(), [&](int x, int y) { return S->unit_ms[x] > S->unit_ms[y]; });
-        std::vector<float> load(QC_NSTREAMS, 0.f);
+    auto lpt = [&](const std::vector<float> &w, int nstreams) {
+        std::vector<int> ord;
+        for (size_t u = 0; u < units.size(); ++u) if (!units[u].empty()) ord.push_back((int)u);
+        std::stable_sort(ord.begin(), ord.end(), [&](int x, int y) { return w[x] > w[y]; });
+        std::vector<float> load(nstreams, 0.f);
         S->unit_stream.assign(units.size(), 0);
-        for (int u : order) {
+        for (int u : ord) {
             const int k = (int)(std::min_element(load.begin(), load.end()) - load.begin());
             S->unit_stream[u] = k;
-            load[k] += S->unit_ms[u];
+            load[k] += w[u];
         }
-    }
-    QC_HIP_CHECK(hipEventRecord(S->ev_fork, S->stream));
-    std::vector<int> order;
-    for (size_t u = 0; u < units.size(); ++u) if (!units[u].empty()) order.push_back((int)u);
-    std::stable_sort(order.begin(), order.end(), [&](int x, int y) { return S->unit_ms[x] > S->unit_ms[y]; });
-    bool used[QC_NSTREAMS] = {};
-    for (int u : order) {
-        const int k = S->unit_stream[u];
-        hipStream_t st = S->side[k];
-        if (!used[k]) { QC_HIP_CHECK(hipStreamWaitEvent(st, S->ev_fork, 0)); used[k] = true; }
-        int rc = launch_segments(S, u, segs_of(units[u]), st, a);
+        S->unit_weight = w;
+    };
+    // one concurrent build: fork the side streams off the handle's stream, launch every unit on its stream (heaviest
+    // first), join.  `ev` (tuning only): [0] fork, [1] join, [2 + 2u], [3 + 2u] around unit u.
+    auto launch_concurrent = [&](hipEvent_t *ev) -> int {
+        if (ev) QC_HIP_CHECK(hipEventRecord(ev[0], S->stream));
+        QC_HIP_CHECK(hipEventRecord(S->ev_fork, S->stream));
+        std::vector<int> order;
+        for (size_t u = 0; u < units.size(); ++u) if (!units[u].empty()) order.push_back((int)u);
+        std::stable_sort(order.begin(), order.end(), [&](int x, int y) { return S->unit_weight[x] > S->unit_weight[y]; });
+        bool used[QC_NSTREAMS] = {};
+        for (int u : order) {
+            const int k = S->unit_stream[u];
+            hipStream_t st = S->side[k];
+            if (!used[k]) { QC_HIP_CHECK(hipStreamWaitEvent(st, S->ev_fork, 0)); used[k] = true; }
+            if (ev) QC_HIP_CHECK(hipEventRecord(ev[2 + 2 * u], st));
+            int rc = launch_segments(S, u, segs_of(units[u]), st, a);
+            if (rc != QC_OK) return rc;
+            if (ev) QC_HIP_CHECK(hipEventRecord(ev[3 + 2 * u], st));
+        }
+        for (int k = 0; k < QC_NSTREAMS; ++k) {
+            if (!used[k]) continue;
+            QC_HIP_CHECK(hipEventRecord(S->ev_join[k], S->side[k]));
+            QC_HIP_CHECK(hipStreamWaitEvent(S->stream, S->ev_join[k], 0));
+        }
+        if (ev) QC_HIP_CHECK(hipEventRecord(ev[1], S->stream));
+        return QC_OK;
+    };
+    if (S->unit_ms.size() != units.size()) {
+        // First build of a shard: tune the stream assignment (all of this is density-independent and its results are
+        // discarded).  Kernels that overlap slow each other down by class-dependent factors, so after an initial guess
+        // from the launches timed alone, QC_TUNE_ROUNDS concurrent builds are measured with events around every launch;
+        // each proposes the next assignment (longest-first on the durations seen *inside* the build, over 4 to 7 streams - fewer
+        // concurrent kernels disturb each other less), the fastest is kept.
+        S->unit_ms.assign(units.size(), 0.f);
+        const size_t gbytes = (size_t)a.nrep * a.rep_stride * sizeof(double);
+        int rc = qc_launch_fock_classes(S, fa, nullptr, S->unit_ms.data());     // warm-up: first launches pay code upload
+        if (rc == QC_OK) rc = qc_launch_fock_classes(S, fa, nullptr, S->unit_ms.data());   // serial, timed
         if (rc != QC_OK) return rc;
+        lpt(S->unit_ms, QC_NSTREAMS);
+        std::vector<hipEvent_t> ev(2 + 2 * units.size());
+        for (auto &e : ev) QC_HIP_CHECK(hipEventCreate(&e));
+        std::vector<std::vector<int>> cand;
+        std::vector<std::vector<float>> weight;
+        std::vector<float> total;
+        static const bool dbg = getenv("QC_TUNE_DEBUG") != nullptr;
+        for (int round = 0; round < QC_TUNE_ROUNDS; ++round) {
+            for (int rep = 0; rep < 2; ++rep) {             // the second run of a candidate is the one that counts
+                if (fa.G0) QC_HIP_CHECK(hipMemsetAsync(fa.G0, 0, gbytes, S->stream));
+                if ((rc = launch_concurrent(ev.data())) != QC_OK) return rc;
+                QC_HIP_CHECK(hipEventSynchronize(ev[1]));
+            }
+            float tot = 0.f;
+            QC_HIP_CHECK(hipEventElapsedTime(&tot, ev[0], ev[1]));
+            std::vector<float> dur(units.size(), 0.f);
+            for (size_t u = 0; u < units.size(); ++u)
+                if (!units[u].empty()) QC_HIP_CHECK(hipEventElapsedTime(&dur[u], ev[2 + 2 * u], ev[3 + 2 * u]));
+            cand.push_back(S->unit_stream); weight.push_back(S->unit_weight); total.push_back(tot);
+            if (dbg) {
+                fprintf(stderr, "[tune] cand %d total %.3f ms:", round, tot);
+                for (size_t u = 0; u < units.size(); ++u) if (!units[u].empty()) fprintf(stderr, " u%zu@s%d %.0f/%.0f", u, S->unit_stream[u], dur[u] * 1e3, S->unit_ms[u] * 1e3);
+                fprintf(stderr, "\n");
+            }
+            static const int widths[QC_TUNE_ROUNDS] = {QC_NSTREAMS, QC_NSTREAMS, 5, 4, 6, QC_NSTREAMS};   // of the *next* candidate
+            lpt(dur, widths[round]);
+        }
+        const size_t best = std::min_element(total.begin(), total.end()) - total.begin();
+        S->unit_stream = cand[best]; S->unit_weight = weight[best];
+        for (auto &e : ev) (void)hipEventDestroy(e);
+        if (fa.G0) QC_HIP_CHECK(hipMemsetAsync(fa.G0, 0, gbytes, S->stream));
     }
-    for (int k = 0; k < QC_NSTREAMS; ++k) {
-        if (!used[k]) continue;
-        QC_HIP_CHECK(hipEventRecord(S->ev_join[k], S->side[k]));
-        QC_HIP_CHECK(hipStreamWaitEvent(S->stream, S->ev_join[k], 0));
-    }
-    return QC_OK;
+    return launch_concurrent(nullptr);
 }
 
 // molint::eri replacement for tests/plumbing: unsplit slots (every quartet complete in one slot) + plain stores

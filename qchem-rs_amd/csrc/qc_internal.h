@@ -24,6 +24,7 @@ __host__ __device__ constexpr int qc_region0(int L, int lgc) {
       // primitive quartets per slot
 constexpr double QC_PRIM_CUTOFF = 1e-17; // primitive pairs whose Hermite expansion block is entirely below this are dropped
 constexpr int QC_NREP = 32;             // replicas of the Fock accumulation buffer
+constexpr int QC_TUNE_ROUNDS = 6;        // concurrent builds measured before the stream assignment is frozen
 constexpr int QC_NSTREAMS = 7;          // class kernels of one build run concurrently on this many streams
 constexpr int QC_NUNITS = 2 * (QC_LPAIR + 1) + 4;   // launch units of one build: (LAB, tier) of the column kernels + 4 bra-major launches
 
@@ -113,6 +114,7 @@ struct qc_system {
     std::vector<FockGraph> graphs;
     std::vector<float> unit_ms;              // measured serial time of each launch unit (autotuned once per shard)
     std::vector<int> unit_stream;            // side stream of each launch unit (longest-processing-time assignment)
+    std::vector<float> unit_weight;          // durations that order the launches (measured inside concurrent builds)
     int fock_mode = 0;                       // 0 direct (default), 1 stored tensor (the reference's own algorithm)
     bool use_graphs = false;                 // hipGraph replay of the build measured slower than eager multi-stream launches on ROCm 7.2
     std::string last_error;
