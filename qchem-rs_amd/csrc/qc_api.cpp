@@ -207,6 +207,7 @@ int qc_system_create(int natoms, const int32_t *Z, const double *xyz, int nshell
         S->shells.push_back(std::move(sh));
     }
     qc_build_model(S);
+    if (!S->last_error.empty()) { fprintf(stderr, "qchem_hip: %s\n", S->last_error.c_str()); delete S; return QC_ERR_UNSUPPORTED; }
     *out = S;
     return QC_OK;
 }

@@ -87,6 +87,8 @@ int qc_device_init(qc_system *S) {
     QC_HIP_CHECK(hipMemcpy(S->d_pairdata, S->pairdata.data(), S->pairdata.size() * sizeof(double), hipMemcpyHostToDevice));
     QC_HIP_CHECK(hipMalloc(&S->d_pairdataT, S->pairdataT.size() * sizeof(double)));
     QC_HIP_CHECK(hipMemcpy(S->d_pairdataT, S->pairdataT.data(), S->pairdataT.size() * sizeof(double), hipMemcpyHostToDevice));
+    QC_HIP_CHECK(hipMalloc(&S->d_pspack, (S->pspack.size() + 8) * sizeof(double)));
+    QC_HIP_CHECK(hipMemcpy(S->d_pspack, S->pspack.data(), S->pspack.size() * sizeof(double), hipMemcpyHostToDevice));
     QC_HIP_CHECK(hipMalloc(&S->d_pairs, S->pairs.size() * sizeof(QcPairDesc)));
     QC_HIP_CHECK(hipMemcpy(S->d_pairs, S->pairs.data(), S->pairs.size() * sizeof(QcPairDesc), hipMemcpyHostToDevice));
     // rows: F_{L+j}(x_k) / j!, j = 0..7, per total order L; then exp(-x_k)
@@ -119,10 +121,10 @@ void qc_device_free(qc_system *S) {
         if (c.d_bundles) { (void)hipFree(c.d_bundles); c.d_bundles = nullptr; }
         if (c.d_ketlist) { (void)hipFree(c.d_ketlist); c.d_ketlist = nullptr; }
     }
-    void *ptrs[] = {S->d_pairdata, S->d_pairdataT, S->d_pairs, S->d_boys, S->d_D, S->d_G, S->d_Gtmp, S->d_Dj, S->d_flag};
+    void *ptrs[] = {S->d_pairdata, S->d_pairdataT, S->d_pspack, S->d_pairs, S->d_boys, S->d_D, S->d_G, S->d_Gtmp, S->d_Dj, S->d_flag};
     S->d_flag = nullptr;
     for (void *p : ptrs) if (p) (void)hipFree(p);
-    S->d_pairdata = S->d_pairdataT = nullptr; S->d_pairs = nullptr; S->d_boys = S->d_D = S->d_G = S->d_Gtmp = S->d_Dj = nullptr;
+    S->d_pairdata = S->d_pairdataT = S->d_pspack = nullptr; S->d_pairs = nullptr; S->d_boys = S->d_D = S->d_G = S->d_Gtmp = S->d_Dj = nullptr;
     for (int i = 0; i < QC_NSTREAMS; ++i) {
         if (S->side[i]) (void)hipStreamDestroy(S->side[i]);
         if (S->ev_join[i]) (void)hipEventDestroy(S->ev_join[i]);
@@ -154,19 +156,22 @@ static Seg seg_of(const QcClass &c) {
 static int launch_segments(qc_system *S, int unit, const std::vector<Seg> &segs, hipStream_t st, const QcKernelArgs &base) {
     if (unit >= 2 * (QC_LPAIR + 1)) {      // bra-major launch
         QcBmArgs t{};
-        t.base = base; t.pairdataT = S->d_pairdataT;
-        int grid = 0, lds = 0, k = 0;
+        t.base = base; t.pairdataT = S->d_pairdataT; t.pspack = S->d_pspack;
+        const int v = unit - 2 * (QC_LPAIR + 1);
+        int nw = qc_bm_waves(v / 2, v % 2), iblock = 0;
+        for (const Seg &sg : segs) iblock = std::max(iblock, sg.lds);
+        while (nw > 1 && QC_BM_LDS_TABLE + nw * iblock > 150 * 1024) nw /= 2;      // Cartesian d / f bras: 36+ rows per wave
+        int grid = 0, k = 0;
         for (const Seg &sg : segs) {
-            // persistent workgroups of QC_BM_WAVES waves: at most ~3 per CU, each wave strides through the bundle list
-            grid += std::min((sg.nslots + QC_BM_WAVES - 1) / QC_BM_WAVES, 256 * 3);
+            // persistent workgroups of `nw` waves: at most ~12 waves per CU, each wave strides through the bundle list
+            grid += std::min((sg.nslots + nw - 1) / nw, 256 * 12 / nw);
             t.seg_end[k] = grid; t.seg_lab[k] = sg.c->LAB; t.seg_bundles[k] = sg.d_bundles; t.seg_ketlist[k] = sg.d_ketlist;
             t.seg_nbundles[k] = sg.nslots; t.seg_iwords[k] = sg.lds / 8;
-            lds = std::max(lds, QC_BM_LDS_TABLE + QC_BM_WAVES * sg.lds);
             ++k;
         }
         t.nseg = k;
-        const int v = unit - 2 * (QC_LPAIR + 1);
-        return qc_launch_bm(v / 2, v % 2, grid, (size_t)lds, st, t);
+        const int lds = QC_BM_LDS_TABLE + nw * iblock;
+        return qc_launch_bm(v / 2, v % 2, grid, nw, (size_t)lds, st, t);
     }
     QcTierArgs t{};
     t.base = base;

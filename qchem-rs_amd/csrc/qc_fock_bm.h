@@ -4,11 +4,14 @@
 
 // One launch = the bra-major classes of one ket type (LCD = 0: ss kets, 1: ps kets) and bra range (HI = 0: LAB <= 2,
 // 1: LAB >= 3); the grid is the concatenation of the classes' bundle lists ("segments"), one wave per bundle.
-constexpr int QC_BM_WAVES = 4;         // waves per workgroup (they share the LDS Boys table, nothing else)
+// waves per workgroup (they share the LDS Boys table, nothing else); the launcher uses fewer when the I blocks are large
+// (Cartesian d bras).  8 waves for the launches with 13-14 KB I blocks was measured: no gain, the ss-ket ones lose.
+constexpr int qc_bm_waves(int lcd, int hi) { return 4; }
 constexpr int QC_BM_LDS_TABLE = ((QC_BOYS_NGRID * 9 + 1) & ~1) * 8;   // bytes of the table at the head of the workgroup's LDS
 struct QcBmArgs {
     QcKernelArgs base;
     const double *pairdataT;
+    const double *pspack;              // packed primitive records of the ps pairs (ket side of the LCD = 1 kernels)
     int nseg;
     int seg_end[QC_MAXSEG];            // exclusive prefix of workgroup counts
     int seg_lab[QC_MAXSEG];
@@ -18,4 +21,4 @@ struct QcBmArgs {
     const int *seg_ketlist[QC_MAXSEG];
 };
 
-int qc_launch_bm(int lcd, int hi, int grid, size_t lds, hipStream_t st, const QcBmArgs &a);
+int qc_launch_bm(int lcd, int hi, int grid, int nwaves /* <= qc_bm_waves(lcd, hi) */, size_t lds, hipStream_t st, const QcBmArgs &a);

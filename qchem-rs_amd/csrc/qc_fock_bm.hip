@@ -70,6 +70,23 @@ __device__ __forceinline__ void qc_boys_lds(double x, const double *__restrict__
     }
 }
 
+// Step 2 against a ps ket in packed form: column c is the Cartesian axis c of the p function, its Hermite expansion is
+// e0[c] on the s-type function plus e1 on the first-order function of that axis - 2 FMAs per (column, bra Hermite
+// index) instead of the 4 of the dense 4 x 3 block.  `me1` = -e1 (odd ket order).
+template <int LAB>
+__device__ __forceinline__ void qc_step2_ps(double (&W)[3][qc_nherm(LAB)], const double (&e0)[3], const double me1,
+                                            const double (&R)[qc_nherm(LAB + 1)]) {
+    constexpr QcTuvTable T = qc_make_tuv();
+#pragma unroll
+    for (int h = 0; h < qc_nherm(LAB); ++h) {
+        const int t = T.t[h], u = T.u[h], v = T.v[h];
+        const double r0 = R[h];
+        W[0][h] = fma(me1, R[qc_hidx(t + 1, u, v)], fma(e0[0], r0, W[0][h]));
+        W[1][h] = fma(me1, R[qc_hidx(t, u + 1, v)], fma(e0[1], r0, W[1][h]));
+        W[2][h] = fma(me1, R[qc_hidx(t, u, v + 1)], fma(e0[2], r0, W[2][h]));
+    }
+}
+
 // One pass over the ket primitives for NIJ consecutive bra primitive pairs (NIJ = 2 shares every ket load between two
 // primitive quartets), followed by step 3 with the wave-uniform bra blocks.
 template <int LAB, int LCD, int NIJ>
@@ -77,7 +94,7 @@ __device__ __forceinline__ void qc_bm_pass(const double *__restrict__ pd, const 
                                            const int bdoff, const int strideB, const int ij, const int nab, const double *__restrict__ ketBase,
                                            const int K_cd, const int Kc1, const int maxK, double *const I) {
     constexpr int L = LAB + LCD, HAB = qc_nherm(LAB), NC = (LCD == 0) ? 1 : 3;
-    constexpr int strideK = qc_pair_stride(LCD, NC);
+    constexpr int strideK = (LCD == 0) ? qc_pair_stride(0, 1) : 8;
     constexpr int LS = 65;
     double p[NIJ], Px[NIJ], Py[NIJ], Pz[NIJ];
 #pragma unroll
@@ -92,25 +109,21 @@ __device__ __forceinline__ void qc_bm_pass(const double *__restrict__ pd, const 
         for (int c = 0; c < NC; ++c)
 #pragma unroll
             for (int h = 0; h < HAB; ++h) W[u][c][h] = 0.0;
-    // the next ket primitive's header (and, for ss kets, its single expansion value) is requested one iteration ahead
+    // the next ket primitive's record is requested one iteration ahead.  ss kets: pair-data block [q, Q | E]; ps kets:
+    // packed record [q, Q | e0x, e0y, e0z, e1] (ketBase points into pspack, stride 8)
     double4 hk = *reinterpret_cast<const double4 *>(ketBase);
+    double4 ekn4 = (LCD == 1) ? *reinterpret_cast<const double4 *>(ketBase + 4) : double4{0.0, 0.0, 0.0, 0.0};
     double ekn = (LCD == 0) ? ketBase[4] : 0.0;
     for (int kl = 0; kl < maxK; ++kl) {
         const bool valid = kl < K_cd;
         const double4 ck = hk;
         const double ek = ekn;
-        const double *__restrict__ kb = ketBase + (size_t)min(kl, Kc1) * strideK;
+        const double4 ek4 = ekn4;
         {
             const double *__restrict__ kbn = ketBase + (size_t)min(kl + 1, Kc1) * strideK;
             hk = *reinterpret_cast<const double4 *>(kbn);
             if constexpr (LCD == 0) ekn = kbn[4];
-        }
-        double ev[12];
-        if constexpr (LCD == 1) {   // ket block: E[h][col], 12 consecutive doubles behind the 32-byte header
-            const double4 e0 = *reinterpret_cast<const double4 *>(kb + 4), e1 = *reinterpret_cast<const double4 *>(kb + 8),
-                          e2 = *reinterpret_cast<const double4 *>(kb + 12);
-            ev[0] = e0.x; ev[1] = e0.y; ev[2] = e0.z; ev[3] = e0.w; ev[4] = e1.x; ev[5] = e1.y; ev[6] = e1.z; ev[7] = e1.w;
-            ev[8] = e2.x; ev[9] = e2.y; ev[10] = e2.z; ev[11] = e2.w;
+            else ekn4 = *reinterpret_cast<const double4 *>(kbn + 4);
         }
         const double q = ck.x;
 #pragma unroll
@@ -126,13 +139,8 @@ __device__ __forceinline__ void qc_bm_pass(const double *__restrict__ pd, const 
                 double e[1] = {ek * sc};
                 qc_step2<LAB, 0>(W[u][0], e, Rr);
             } else {
-#pragma unroll
-                for (int c = 0; c < 3; ++c) {
-                    double e[4];
-#pragma unroll
-                    for (int h = 0; h < 4; ++h) e[h] = ev[h * 3 + c] * sc;
-                    qc_step2<LAB, 1>(W[u][c], e, Rr);
-                }
+                const double e0[3] = {ek4.x * sc, ek4.y * sc, ek4.z * sc};
+                qc_step2_ps<LAB>(W[u], e0, -(ek4.w * sc), Rr);
             }
         }
     }
@@ -159,7 +167,8 @@ __device__ __forceinline__ void qc_bm_pass(const double *__restrict__ pd, const 
 
 template <int LAB, int LCD>
 __device__ __forceinline__ void qc_bm_body(const QcKernelArgs &a, const double *__restrict__ pdT, const QcBundle *__restrict__ bundles,
-                                           const int *__restrict__ ketlist, const int blk, const double *__restrict__ Tb, double *const Iw) {
+                                           const int *__restrict__ ketlist, const int blk, const double *__restrict__ Tb, double *const Iw,
+                                           const double *__restrict__ pspack) {
     constexpr int HAB = qc_nherm(LAB), NC = (LCD == 0) ? 1 : 3;
     constexpr int LS = 65;                                    // LDS row stride (doubles)
     constexpr bool PAIRED = 2 * NC * HAB <= 24;               // two bra primitive pairs per pass when W[2][NC][HAB] fits
@@ -184,7 +193,7 @@ __device__ __forceinline__ void qc_bm_body(const QcKernelArgs &a, const double *
     const int ket = ketlist[first + (active ? lane : 0)];
     const QcPairDesc pk = a.pairs[ket];
     const int K_cd = active ? pk.K : 0, Kc1 = max(K_cd - 1, 0);
-    const double *__restrict__ ketBase = pd + pk.doff;
+    const double *__restrict__ ketBase = (LCD == 0) ? pd + pk.doff : pspack + pk.psoff;
     double *const I = Iw + lane;                              // I[x * LS], x = ab * NC + col
 
     for (int x = 0; x < nab * NC; ++x) I[x * LS] = 0.0;
@@ -204,7 +213,8 @@ __device__ __forceinline__ void qc_bm_body(const QcKernelArgs &a, const double *
             for (int ab = 0; ab < nab; ++ab) {
                 const size_t i = offa + ab / nb, j = offb + ab % nb;
                 for (int c = 0; c < NC; ++c) {
-                    const size_t k = c0 + (nd == 1 ? c : 0), l = d0 + (nd == 1 ? 0 : c);
+                    const int fc = (LCD == 0) ? 0 : (pk.psperm >> (2 * c)) & 3;    // ps kets: column c = axis c = p function fc
+                    const size_t k = c0 + (nd == 1 ? fc : 0), l = d0 + (nd == 1 ? 0 : fc);
                     const double v = I[(ab * NC + c) * LS];
                     o[i * n3 + j * n2 + k * n1 + l] = v; o[j * n3 + i * n2 + k * n1 + l] = v;
                     o[i * n3 + j * n2 + l * n1 + k] = v; o[j * n3 + i * n2 + l * n1 + k] = v;
@@ -222,7 +232,10 @@ __device__ __forceinline__ void qc_bm_body(const QcKernelArgs &a, const double *
     // column c of this lane's ket is the function pair (c0 + kc[c], d0 + lc[c])
     int kc[NC], lc[NC];
 #pragma unroll
-    for (int c = 0; c < NC; ++c) { kc[c] = (nd == 1) ? c : 0; lc[c] = (nd == 1) ? 0 : c; }
+    for (int c = 0; c < NC; ++c) {
+        const int fc = (LCD == 0) ? 0 : (pk.psperm >> (2 * c)) & 3;     // ps kets: column c = axis c = p function fc
+        kc[c] = (nd == 1) ? fc : 0; lc[c] = (nd == 1) ? 0 : fc;
+    }
 
     // ---- exchange blocks first (they read I), per spin: Gt_ik -= cK f sum_jl I D_jl and the il / jk / jl images
     const double fk = -a.cK * f;
@@ -235,6 +248,7 @@ __device__ __forceinline__ void qc_bm_body(const QcKernelArgs &a, const double *
                 double accK[NC], accL[NC];                   // G[a_i, c_k] and G[a_i, d_l] partial sums
 #pragma unroll
                 for (int c = 0; c < NC; ++c) accK[c] = accL[c] = 0.0;
+#pragma unroll 3
                 for (int j = 0; j < nb; ++j) {
                     const double *__restrict__ Drow = Dk + (size_t)(offb + j) * n;
 #pragma unroll
@@ -249,11 +263,11 @@ __device__ __forceinline__ void qc_bm_body(const QcKernelArgs &a, const double *
                     unsafeAtomicAdd(&Grow[c0], fk * accK[0]);
                     unsafeAtomicAdd(&Grow[d0], fk * accL[0]);
                 } else if (nd == 1) {                         // columns differ in k, share l
-                    unsafeAtomicAdd(&Grow[c0 + 0], fk * accK[0]); unsafeAtomicAdd(&Grow[c0 + 1], fk * accK[1]); unsafeAtomicAdd(&Grow[c0 + 2], fk * accK[2]);
+                    unsafeAtomicAdd(&Grow[c0 + kc[0]], fk * accK[0]); unsafeAtomicAdd(&Grow[c0 + kc[1]], fk * accK[1]); unsafeAtomicAdd(&Grow[c0 + kc[2]], fk * accK[2]);
                     unsafeAtomicAdd(&Grow[d0], fk * (accL[0] + accL[1] + accL[2]));
                 } else {                                      // columns differ in l, share k
                     unsafeAtomicAdd(&Grow[c0], fk * (accK[0] + accK[1] + accK[2]));
-                    unsafeAtomicAdd(&Grow[d0 + 0], fk * accL[0]); unsafeAtomicAdd(&Grow[d0 + 1], fk * accL[1]); unsafeAtomicAdd(&Grow[d0 + 2], fk * accL[2]);
+                    unsafeAtomicAdd(&Grow[d0 + lc[0]], fk * accL[0]); unsafeAtomicAdd(&Grow[d0 + lc[1]], fk * accL[1]); unsafeAtomicAdd(&Grow[d0 + lc[2]], fk * accL[2]);
                 }
             }
             // targets on the bra function b_j: needs D[a_i, d_l] and D[a_i, c_k]
@@ -261,6 +275,7 @@ __device__ __forceinline__ void qc_bm_body(const QcKernelArgs &a, const double *
                 double accK[NC], accL[NC];
 #pragma unroll
                 for (int c = 0; c < NC; ++c) accK[c] = accL[c] = 0.0;
+#pragma unroll 3
                 for (int i = 0; i < na; ++i) {
                     const double *__restrict__ Drow = Dk + (size_t)(offa + i) * n;
 #pragma unroll
@@ -275,11 +290,11 @@ __device__ __forceinline__ void qc_bm_body(const QcKernelArgs &a, const double *
                     unsafeAtomicAdd(&Grow[c0], fk * accK[0]);
                     unsafeAtomicAdd(&Grow[d0], fk * accL[0]);
                 } else if (nd == 1) {
-                    unsafeAtomicAdd(&Grow[c0 + 0], fk * accK[0]); unsafeAtomicAdd(&Grow[c0 + 1], fk * accK[1]); unsafeAtomicAdd(&Grow[c0 + 2], fk * accK[2]);
+                    unsafeAtomicAdd(&Grow[c0 + kc[0]], fk * accK[0]); unsafeAtomicAdd(&Grow[c0 + kc[1]], fk * accK[1]); unsafeAtomicAdd(&Grow[c0 + kc[2]], fk * accK[2]);
                     unsafeAtomicAdd(&Grow[d0], fk * (accL[0] + accL[1] + accL[2]));
                 } else {
                     unsafeAtomicAdd(&Grow[c0], fk * (accK[0] + accK[1] + accK[2]));
-                    unsafeAtomicAdd(&Grow[d0 + 0], fk * accL[0]); unsafeAtomicAdd(&Grow[d0 + 1], fk * accL[1]); unsafeAtomicAdd(&Grow[d0 + 2], fk * accL[2]);
+                    unsafeAtomicAdd(&Grow[d0 + lc[0]], fk * accL[0]); unsafeAtomicAdd(&Grow[d0 + lc[1]], fk * accL[1]); unsafeAtomicAdd(&Grow[d0 + lc[2]], fk * accL[2]);
                 }
             }
         }
@@ -324,9 +339,9 @@ __device__ __forceinline__ void qc_bm_body(const QcKernelArgs &a, const double *
     }
 }
 
-// Workgroup = QC_BM_WAVES independent waves sharing the LDS Boys table of their segment's Hermite order; every wave
+// Workgroup = qc_bm_waves(LCD, HI) independent waves sharing the LDS Boys table of their segment's Hermite order; every wave
 // walks the segment's bundle list with the stride of the launch (bundles are sorted longest first).
-template <int LAB, int LCD>
+template <int LAB, int LCD, int NW>
 __device__ __forceinline__ void qc_bm_segment(const QcBmArgs &a, const int s, const int wg, const int nwg) {
     extern __shared__ double lds[];
     constexpr int L = LAB + LCD;
@@ -334,33 +349,36 @@ __device__ __forceinline__ void qc_bm_segment(const QcBmArgs &a, const int s, co
     {
         const double *__restrict__ rows = a.base.boys + (size_t)L * QC_BOYS_NGRID * 8;
         const double *__restrict__ exk = a.base.boys + (size_t)(QC_LTOT + 1) * QC_BOYS_NGRID * 8;
-        // constant trip count, fully unrolled: all loads of a thread are in flight together (one L2 round trip, not 15)
-        constexpr int NT = QC_BM_WAVES * 64, NIT = (QC_BM_TWORDS + NT - 1) / NT;
-        double v[NIT];
+        // eight loads of a thread in flight together (an L2 round trip per batch, not per element)
+        const int nt = blockDim.x;
+        for (int i0 = tid; i0 < QC_BM_TWORDS; i0 += 8 * nt) {
+            double v[8];
 #pragma unroll
-        for (int it = 0; it < NIT; ++it) {
-            const int i = min(tid + it * NT, QC_BM_TWORDS - 1);
-            const int k = i / QC_BM_TROW, j = i - k * QC_BM_TROW;
-            v[it] = (j < 8) ? rows[k * 8 + j] : exk[k];
+            for (int j = 0; j < 8; ++j) {
+                const int i = min(i0 + j * nt, QC_BM_TWORDS - 1);
+                const int k = i / QC_BM_TROW, r = i - k * QC_BM_TROW;
+                v[j] = (r < 8) ? rows[k * 8 + r] : exk[k];
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+                if (i0 + j * nt < QC_BM_TWORDS) lds[i0 + j * nt] = v[j];
         }
-#pragma unroll
-        for (int it = 0; it < NIT; ++it)
-            if (tid + it * NT < QC_BM_TWORDS) lds[tid + it * NT] = v[it];
     }
     __syncthreads();
     double *const Iw = lds + ((QC_BM_TWORDS + 1) & ~1) + (size_t)wave * a.seg_iwords[s];
     const int nb = a.seg_nbundles[s];
-    for (int b = wg * QC_BM_WAVES + wave; b < nb; b += nwg * QC_BM_WAVES)
-        qc_bm_body<LAB, LCD>(a.base, a.pairdataT, a.seg_bundles[s], a.seg_ketlist[s], b, lds, Iw);
+    const int nw = blockDim.x >> 6;                           // <= NW: fewer when the I blocks of NW waves would not fit
+    for (int b = wg * nw + wave; b < nb; b += nwg * nw)
+        qc_bm_body<LAB, LCD>(a.base, a.pairdataT, a.seg_bundles[s], a.seg_ketlist[s], b, lds, Iw, a.pspack);
 }
 
 template <int LCD, int HI>
-__global__ __launch_bounds__(QC_BM_WAVES * 64) void qc_fock_bm_kernel(const QcBmArgs a) {
+__global__ __launch_bounds__(qc_bm_waves(LCD, HI) * 64) void qc_fock_bm_kernel(const QcBmArgs a) {
     int s = 0;
     while (s + 1 < a.nseg && (int)blockIdx.x >= a.seg_end[s]) ++s;
     const int b0 = s ? a.seg_end[s - 1] : 0;
     const int wg = blockIdx.x - b0, nwg = a.seg_end[s] - b0;
-#define QC_BM_CASE(LAB) case LAB: qc_bm_segment<LAB, LCD>(a, s, wg, nwg); break;
+#define QC_BM_CASE(LAB) case LAB: qc_bm_segment<LAB, LCD, qc_bm_waves(LCD, HI)>(a, s, wg, nwg); break;
     if constexpr (LCD == 0 && HI == 0) { switch (a.seg_lab[s]) { QC_BM_CASE(0) QC_BM_CASE(1) QC_BM_CASE(2) default: break; } }
     if constexpr (LCD == 0 && HI == 1) { switch (a.seg_lab[s]) { QC_BM_CASE(3) QC_BM_CASE(4) default: break; } }
     if constexpr (LCD == 1 && HI == 0) { switch (a.seg_lab[s]) { QC_BM_CASE(1) QC_BM_CASE(2) default: break; } }
@@ -369,7 +387,7 @@ __global__ __launch_bounds__(QC_BM_WAVES * 64) void qc_fock_bm_kernel(const QcBm
 }
 
 template <int LCD, int HI>
-static int launch_bm(int grid, size_t lds, hipStream_t st, const QcBmArgs &a) {
+static int launch_bm(int grid, int nwaves, size_t lds, hipStream_t st, const QcBmArgs &a) {
     auto kern = qc_fock_bm_kernel<LCD, HI>;
     static size_t lds_allowed = 48 * 1024;
     if (lds > lds_allowed) {
@@ -377,11 +395,11 @@ static int launch_bm(int grid, size_t lds, hipStream_t st, const QcBmArgs &a) {
         if (e != hipSuccess) return QC_ERR_HIP;
         lds_allowed = lds;
     }
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(QC_BM_WAVES * 64), lds, st, a);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(nwaves * 64), lds, st, a);
     return hipGetLastError() == hipSuccess ? QC_OK : QC_ERR_HIP;
 }
 
-int qc_launch_bm(int lcd, int hi, int grid, size_t lds, hipStream_t st, const QcBmArgs &a) {
-    if (lcd == 0) return hi ? launch_bm<0, 1>(grid, lds, st, a) : launch_bm<0, 0>(grid, lds, st, a);
-    return hi ? launch_bm<1, 1>(grid, lds, st, a) : launch_bm<1, 0>(grid, lds, st, a);
+int qc_launch_bm(int lcd, int hi, int grid, int nwaves, size_t lds, hipStream_t st, const QcBmArgs &a) {
+    if (lcd == 0) return hi ? launch_bm<0, 1>(grid, nwaves, lds, st, a) : launch_bm<0, 0>(grid, nwaves, lds, st, a);
+    return hi ? launch_bm<1, 1>(grid, nwaves, lds, st, a) : launch_bm<1, 0>(grid, nwaves, lds, st, a);
 }

@@ -46,7 +46,7 @@ struct QcShell {
     std::vector<double> T;            // nfunc x ncart, rows scaled to unit self-overlap
 };
 
-// Device-visible pair descriptor (8 ints)
+// Device-visible pair descriptor (10 ints)
 struct QcPairDesc {
     int doff;     // offset (in doubles) of this pair's primitive blocks in the pair-data array
     int K;        // primitive pairs
@@ -54,6 +54,8 @@ struct QcPairDesc {
     int offa, offb;
     int L;        // la + lb
     int shA_eq_shB;
+    int psoff;    // ps pairs: offset (doubles) of the packed primitive records in the pspack array, else -1
+    int psperm;   // ps pairs: basis function of Cartesian axis a = (psperm >> 2a) & 3
 };
 
 struct QcTask { int bra, ket; };  // pair indices; (bra|ket) is one unique shell quartet
@@ -90,6 +92,7 @@ struct qc_system {
     std::vector<QcPairDesc> pairs;
     std::vector<int> pairA, pairB, pairKfull;   // shells of each stored pair; its primitive-pair count before the cut-off
     std::vector<double> pairdata;
+    std::vector<double> pspack;                 // ps pairs, 8 doubles per primitive: [q, Q(3), E_0[x,y,z], E_1] (see qc_fock_bm.hip)
     std::vector<double> pairdataT;              // same blocks with the expansion stored [ab][h] (bra side of the bra-major kernels)
     std::vector<QcClass> classes;
     int64_t nquartets = 0;
@@ -101,7 +104,7 @@ struct qc_system {
     bool own_stream = false;
     hipStream_t side[QC_NSTREAMS] = {};
     hipEvent_t ev_fork = nullptr, ev_join[QC_NSTREAMS] = {};
-    double *d_pairdata = nullptr, *d_pairdataT = nullptr;
+    double *d_pairdata = nullptr, *d_pairdataT = nullptr, *d_pspack = nullptr;
     QcPairDesc *d_pairs = nullptr;
     double *d_boys = nullptr;
     double *d_D = nullptr, *d_G = nullptr;   // 2 * n*n each (alpha/beta or Dj/Dk)

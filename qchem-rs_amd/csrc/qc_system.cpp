@@ -186,7 +186,7 @@ void qc_build_model(qc_system *S) {
     // shell pairs A >= B, with per-primitive-pair blocks [p, Px, Py, Pz, E(nherm x nab)].
     // The pair part of the ERI prefactor 2 pi^{5/2} / (p q sqrt(p+q)) is folded in as sqrt(2) pi^{5/4} / p.
     const double half_pref = std::sqrt(2.0) * std::pow(M_PI, 1.25);
-    S->pairs.clear(); S->pairA.clear(); S->pairB.clear(); S->pairKfull.clear(); S->pairdata.clear(); S->pairdataT.clear();
+    S->pairs.clear(); S->pairA.clear(); S->pairB.clear(); S->pairKfull.clear(); S->pairdata.clear(); S->pairdataT.clear(); S->pspack.clear();
     // Primitive pairs whose whole expansion block is below QC_PRIM_CUTOFF are not stored: with the Gaussian-product
     // factor exp(-mu R^2) and the coefficients folded into E, an integral is bounded by max|E_ab| max|E_cd| (times
     // O(10)), so a dropped primitive pair changes no integral by more than ~1e-16 - five orders below the 1e-10 parity
@@ -202,6 +202,9 @@ void qc_build_model(qc_system *S) {
             d.doff = (int)S->pairdata.size();
             d.K = 0;
             d.na = A.nfunc; d.nb = B.nfunc; d.offa = A.off; d.offb = B.off; d.L = A.L + B.L; d.shA_eq_shB = (a == b);
+            d.psoff = -1; d.psperm = 0;
+            const bool is_ps = (d.L == 1);
+            if (is_ps) d.psoff = (int)S->pspack.size();
             const int nab = d.na * d.nb, stride = qc_pair_stride(d.L, nab), ne = qc_nherm(d.L) * nab;
             blkbuf.assign(stride, 0.0);
             for (int i = 0; i < A.nprim; ++i)
@@ -216,6 +219,29 @@ void qc_build_model(qc_system *S) {
                     blkbuf[0] = p; blkbuf[1] = P[0]; blkbuf[2] = P[1]; blkbuf[3] = P[2];
                     S->pairdata.insert(S->pairdata.end(), blkbuf.begin(), blkbuf.end());
                     const int nh = qc_nherm(d.L);
+                    if (is_ps) {
+                        // The 4 x 3 expansion block of a p.s product has 4 distinct numbers: row 0 (the s-type Hermite
+                        // function) is dense, rows 1..3 are one value on a permutation (which p function is which axis).
+                        const double *E = blkbuf.data() + 4;             // E[h * 3 + col]
+                        int perm = 0;
+                        double e1 = 0.0, e0[3] = {0, 0, 0};
+                        bool ok = true;
+                        for (int ax = 0; ax < 3; ++ax) {
+                            int col = 0;
+                            for (int c2 = 1; c2 < 3; ++c2) if (std::fabs(E[(1 + ax) * 3 + c2]) > std::fabs(E[(1 + ax) * 3 + col])) col = c2;
+                            for (int c2 = 0; c2 < 3; ++c2) if (c2 != col && std::fabs(E[(1 + ax) * 3 + c2]) > 1e-14 * std::fabs(E[(1 + ax) * 3 + col])) ok = false;
+                            if (ax == 0) e1 = E[3 + col];
+                            else if (std::fabs(E[(1 + ax) * 3 + col] - e1) > 1e-13 * std::fabs(e1)) ok = false;
+                            perm |= col << (2 * ax);
+                            e0[ax] = E[col];
+                        }
+                        if (((perm & 3) == ((perm >> 2) & 3)) || ((perm & 3) == ((perm >> 4) & 3)) || (((perm >> 2) & 3) == ((perm >> 4) & 3))) ok = false;
+                        if (d.K > 0 && perm != d.psperm) ok = false;
+                        if (!ok) S->last_error = "p shell whose functions are not the Cartesian axes (in some order)";
+                        d.psperm = perm;
+                        const double rec[8] = {p, P[0], P[1], P[2], e0[0], e0[1], e0[2], e1};
+                        S->pspack.insert(S->pspack.end(), rec, rec + 8);
+                    }
                     const size_t t0 = S->pairdataT.size();
                     S->pairdataT.insert(S->pairdataT.end(), blkbuf.begin(), blkbuf.end());
                     for (int h = 0; h < nh; ++h)
