@@ -77,7 +77,7 @@ struct ScfWork {
     DevBuf H, S, X, t1, t2, t3, t4, Fp, Cp, C, w, ework, Fd, scal, small, CpPrev[2], CpNew[2], Fps[2];
     bool have_prev[2] = {false, false};
     int npass[2] = {3, 3};                 // refinement passes enqueued per eigensolve (follows what the last one needed)
-    bool rotate[2] = {true, true};         // large steps: warm-started Jacobi straight away instead of the refinement
+    int mode[2] = {2, 2};                  // eigensolve of the next pass: 0 refinement, 1 two Jacobi sweeps + refinement, 2 Jacobi
     int *ctl = nullptr;                    // device control words: [4 s + 0..3] eigen-refinement of spin s, [8] DIIS failure
     double *h_scal = nullptr;              // pinned read-back: 4 doubles (energy, rms^2 per spin) + 16 ints
     ~ScfWork() {
@@ -159,10 +159,17 @@ int roothaan_enqueue(qc_system *S, ScfWork &W, DeviceDiis &diis, const double *d
     if (rc != QC_OK) return rc;
     qc_gemm(st, n, n, n, 1.0, W.Fd.p, n, false, W.X.p, n, false, 0.0, W.t1.p, n);        // F X
     qc_gemm(st, n, n, n, 1.0, W.X.p, n, true, W.t1.p, n, false, 0.0, W.Fps[spin].p, n);  // X^T (F X)
-    if (W.have_prev[spin] && !W.rotate[spin])
+    if (W.have_prev[spin] && W.mode[spin] == 0)
         rc = qc_eig_refine_async(st, n, W.Fps[spin].p, W.CpPrev[spin].p, W.CpNew[spin].p, dw_out, W.ework.p, W.t1.p, W.t2.p, W.t3.p, W.t4.p,
                                  W.small.p, W.ctl + 4 * spin, W.npass[spin]);
-    else if (W.have_prev[spin])             // F' moved a lot: rotations, in the basis of the previous vectors (few sweeps)
+    else if (W.have_prev[spin] && W.mode[spin] == 1) {
+        // F' moved a lot: two sweeps of rotations in the basis of the previous vectors (Jacobi converges quadratically, the
+        // remaining coupling is then far inside the refinement's reach), finished by the GEMM-based refinement
+        rc = qc_eig_device_warm(st, n, W.Fps[spin].p, W.CpPrev[spin].p, W.CpNew[spin].p, dw_out, W.ework.p, W.t1.p, W.t2.p, 2);
+        if (rc == QC_OK)
+            rc = qc_eig_refine_async(st, n, W.Fps[spin].p, W.CpNew[spin].p, W.CpNew[spin].p, dw_out, W.ework.p, W.t1.p, W.t2.p, W.t3.p, W.t4.p,
+                                     W.small.p, W.ctl + 4 * spin, 3);
+    } else if (W.have_prev[spin])           // first passes, density far from converged: warm-started Jacobi to convergence
         rc = qc_eig_device_warm(st, n, W.Fps[spin].p, W.CpPrev[spin].p, W.CpNew[spin].p, dw_out, W.ework.p, W.t1.p, W.t2.p);
     else rc = device_sorted_eigs(S, W, W.Fps[spin].p, W.CpNew[spin].p, dw_out);          // sorted_eigs (rhf.rs:75), cold
     if (rc != QC_OK) return rc;
@@ -545,10 +552,9 @@ static int scf_iterate(qc_scf_state *st, double *energy, double *rms_out) {
     (void)hipEventElapsedTime(&ms_l, st->ev1, st->ev2);
     bool redo = false;
     for (int s = 0; s < nspin; ++s) {
-        if (!W.have_prev[s] || W.rotate[s]) continue;
-        if (h_ctl[4 * s] == 1) { W.npass[s] = std::max(1, std::min(3, h_ctl[4 * s + 3])); continue; }
+        if (!W.have_prev[s] || W.mode[s] == 2) continue;
+        if (h_ctl[4 * s] == 1) { W.npass[s] = W.mode[s] ? 3 : std::max(1, std::min(3, h_ctl[4 * s + 3])); continue; }
         W.npass[s] = 3;
-        W.rotate[s] = true;
         // the refinement wanted rotations (large step, or a degenerate cluster): repeat this spin's eigensolve the careful way
         if (!redo) QC_HIP_CHECK(hipEventRecord(st->ev1, sm));
         if ((rc = roothaan_redo_eig(S, W, st->ws.p + s * n, st->Cs.p + s * nn, s)) != QC_OK) return rc;
@@ -567,8 +573,9 @@ static int scf_iterate(qc_scf_state *st, double *energy, double *rms_out) {
     for (int s = 0; s < nspin; ++s) {
         const double rms_s = std::sqrt(W.h_scal[2 * s + 1] / n);
         e_sum += W.h_scal[2 * s]; rms_sum += rms_s;
-        // the refinement is perturbative: worth enqueueing only once the density has nearly stopped moving
-        if (!redo) W.rotate[s] = !(rms_s < 2e-3);
+        // the refinement is perturbative: on its own once the density has nearly stopped moving, behind two Jacobi sweeps
+        // while it still moves, not at all in the first wild passes
+        W.mode[s] = rms_s >= 5.0 ? 2 : (rms_s >= 1e-3 || redo) ? 1 : 0;
         std::swap(st->D[s].p, st->Dn[s].p);                              // D += 1.0 * dD
         std::swap(W.CpPrev[s].p, W.CpNew[s].p);
         W.have_prev[s] = true;

@@ -375,7 +375,7 @@ __global__ __launch_bounds__(QC_EIG_THREADS) void qc_jacobi1g_kernel(int n, cons
 }
 
 // dA: input (left intact), dV: sorted eigenvectors, dw: eigenvalues, d_work: n*n scratch
-int qc_eig_device(hipStream_t st, int n, double *dA, double *dV, double *dw, double *d_work) {
+int qc_eig_device(hipStream_t st, int n, double *dA, double *dV, double *dw, double *d_work, int max_sweeps) {
     const int m = (n + 1) & ~1, ld = m | 1;
     const size_t tail = (2 * (m / 2) + 32) * sizeof(double) + (size_t)m * sizeof(int) + 16;
     const size_t lds2 = 2 * (size_t)m * ld * sizeof(double) + tail, lds1 = (size_t)m * ld * sizeof(double) + tail;
@@ -386,14 +386,14 @@ int qc_eig_device(hipStream_t st, int n, double *dA, double *dV, double *dw, dou
         if (l1 <= 160 * 1024) {
             hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(qc_jacobi1_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)l1);
             if (e != hipSuccess) return QC_ERR_HIP;
-            hipLaunchKernelGGL(qc_jacobi1_kernel, dim3(1), dim3(QC_EIG1_THREADS), l1, st, n, dA, dV, dw, 40);
+            hipLaunchKernelGGL(qc_jacobi1_kernel, dim3(1), dim3(QC_EIG1_THREADS), l1, st, n, dA, dV, dw, max_sweeps);
             return hipGetLastError() == hipSuccess ? QC_OK : QC_ERR_HIP;
         }
     }
     const size_t lds = v_in_lds ? lds2 : lds1;
     if (lds > 160 * 1024 || !v_in_lds) {                // n > 128: the global-memory variant
         if (n > 3000) return QC_ERR_UNSUPPORTED;
-        hipLaunchKernelGGL(qc_jacobi1g_kernel, dim3(1), dim3(QC_EIG_THREADS), (size_t)n * 12 + 16, st, n, dA, d_work, dV, dw, 40);
+        hipLaunchKernelGGL(qc_jacobi1g_kernel, dim3(1), dim3(QC_EIG_THREADS), (size_t)n * 12 + 16, st, n, dA, d_work, dV, dw, max_sweeps);
         return hipGetLastError() == hipSuccess ? QC_OK : QC_ERR_HIP;
     }
     auto kern = v_in_lds ? qc_jacobi_kernel<true> : qc_jacobi_kernel<false>;
@@ -402,17 +402,18 @@ int qc_eig_device(hipStream_t st, int n, double *dA, double *dV, double *dw, dou
         if (e != hipSuccess) return QC_ERR_HIP;
     }
     static const int nthreads = getenv("QC_EIG_THREADS") ? atoi(getenv("QC_EIG_THREADS")) : QC_EIG_THREADS;
-    hipLaunchKernelGGL(kern, dim3(1), dim3(nthreads), lds, st, n, dA, d_work, dV, dw, 40);
+    hipLaunchKernelGGL(kern, dim3(1), dim3(nthreads), lds, st, n, dA, d_work, dV, dw, max_sweeps);
     return hipGetLastError() == hipSuccess ? QC_OK : QC_ERR_HIP;
 }
 
 // Warm-started variant for the SCF loop: with V0 the eigenvectors of the previous iteration's matrix,
 // B = V0^T A V0 is nearly diagonal, Jacobi needs 1-3 sweeps instead of ~8, and V = V0 Q.  The three products are
 // f64 MFMA GEMMs.  t1/t2: n*n scratch each.
-int qc_eig_device_warm(hipStream_t st, int n, double *dA, const double *dV0, double *dV, double *dw, double *d_work, double *t1, double *t2) {
+int qc_eig_device_warm(hipStream_t st, int n, double *dA, const double *dV0, double *dV, double *dw, double *d_work, double *t1, double *t2,
+                       int max_sweeps) {
     qc_gemm(st, n, n, n, 1.0, dA, n, false, dV0, n, false, 0.0, t1, n);        // A V0
     qc_gemm(st, n, n, n, 1.0, dV0, n, true, t1, n, false, 0.0, t2, n);         // V0^T (A V0)
-    int rc = qc_eig_device(st, n, t2, t1, dw, d_work);                         // Q -> t1
+    int rc = qc_eig_device(st, n, t2, t1, dw, d_work, max_sweeps);             // Q -> t1
     if (rc != QC_OK) return rc;
     qc_gemm(st, n, n, n, 1.0, dV0, n, false, t1, n, false, 0.0, dV, n);        // V = V0 Q
     return QC_OK;
