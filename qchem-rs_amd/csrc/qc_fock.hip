@@ -158,19 +158,27 @@ static int launch_segments(qc_system *S, int unit, const std::vector<Seg> &segs,
         QcBmArgs t{};
         t.base = base; t.pairdataT = S->d_pairdataT; t.pspack = S->d_pspack;
         const int v = unit - 2 * (QC_LPAIR + 1);
-        int nw = qc_bm_waves(v / 2, v % 2), iblock = 0;
-        for (const Seg &sg : segs) iblock = std::max(iblock, sg.lds);
-        while (nw > 1 && QC_BM_LDS_TABLE + nw * iblock > 150 * 1024) nw /= 2;      // Cartesian d / f bras: 36+ rows per wave
+        const int lds_max = 160 * 1024 - 512;
+        int nw = qc_bm_waves(v / 2, v % 2), iblock = 0, rows = 0;
+        for (const Seg &sg : segs) { iblock = std::max(iblock, sg.lds); rows = std::max(rows, sg.c->bm_rows); }
+        // exchange rows of a wave's current bra in LDS: (na + nb) rows x n columns per spin
+        const int rowbytes = (base.Dk1 ? 2 : 1) * rows * S->nbasis * 8;
+        t.use_rowbuf = (base.eri_out == nullptr && QC_BM_LDS_TABLE + 2 * (iblock + rowbytes) <= lds_max) ? 1 : 0;
+        const int wbytes = iblock + (t.use_rowbuf ? rowbytes : 0);
+        while (nw > 1 && QC_BM_LDS_TABLE + nw * wbytes > lds_max) nw /= 2;          // Cartesian d / f bras: 36+ rows of I per wave
         int grid = 0, k = 0;
         for (const Seg &sg : segs) {
-            // persistent workgroups of `nw` waves: at most ~12 waves per CU, each wave strides through the bundle list
-            grid += std::min((sg.nslots + nw - 1) / nw, 256 * 12 / nw);
+            // persistent workgroups of `nw` waves: at most ~12 waves per CU; a wave takes runs of consecutive bundles
+            const int run = std::max(1, std::min(8, sg.nslots / 2048));
+            const int nruns = (sg.nslots + run - 1) / run;
+            grid += std::min((nruns + nw - 1) / nw, 256 * 12 / nw);
             t.seg_end[k] = grid; t.seg_lab[k] = sg.c->LAB; t.seg_bundles[k] = sg.d_bundles; t.seg_ketlist[k] = sg.d_ketlist;
-            t.seg_nbundles[k] = sg.nslots; t.seg_iwords[k] = sg.lds / 8;
+            t.seg_nbundles[k] = sg.nslots; t.seg_iwords[k] = sg.lds / 8; t.seg_run[k] = run;
+            t.seg_rows[k] = qc_bm_grouped(sg.c->LCD, sg.c->bm_rows) ? rows : 0;      // few exchange targets per lane: direct atomics
             ++k;
         }
         t.nseg = k;
-        const int lds = QC_BM_LDS_TABLE + nw * iblock;
+        const int lds = QC_BM_LDS_TABLE + nw * wbytes;
         return qc_launch_bm(v / 2, v % 2, grid, nw, (size_t)lds, st, t);
     }
     QcTierArgs t{};

@@ -27,6 +27,10 @@
 // coefficients and exp(-x_k)): with one quartet per lane every table access is a 64-address gather, and the texture path
 // - not the VALU - was what these kernels waited for when the rows came from global memory (rocprofv3: 60 % of the
 // wave-cycles waiting to issue).  Same evaluation as qc_boys<L>.
+// f64 add into LDS through the DS unit (a generic pointer would make it a flat atomic)
+typedef __attribute__((address_space(3))) double qc_lds_double;
+__device__ __forceinline__ void qc_lds_add(double *p, double v) { (void)__builtin_amdgcn_ds_atomic_fadd_f64((qc_lds_double *)p, v); }
+
 constexpr int QC_BM_TROW = 9;
 constexpr int QC_BM_TWORDS = QC_BOYS_NGRID * QC_BM_TROW;
 
@@ -168,7 +172,7 @@ __device__ __forceinline__ void qc_bm_pass(const double *__restrict__ pd, const 
 template <int LAB, int LCD>
 __device__ __forceinline__ void qc_bm_body(const QcKernelArgs &a, const double *__restrict__ pdT, const QcBundle *__restrict__ bundles,
                                            const int *__restrict__ ketlist, const int blk, const double *__restrict__ Tb, double *const Iw,
-                                           const double *__restrict__ pspack) {
+                                           const double *__restrict__ pspack, double *const rowbuf, const int rowcap) {
     constexpr int HAB = qc_nherm(LAB), NC = (LCD == 0) ? 1 : 3;
     constexpr int LS = 65;                                    // LDS row stride (doubles)
     constexpr bool PAIRED = 2 * NC * HAB <= 24;               // two bra primitive pairs per pass when W[2][NC][HAB] fits
@@ -237,12 +241,30 @@ __device__ __forceinline__ void qc_bm_body(const QcKernelArgs &a, const double *
         kc[c] = (nd == 1) ? fc : 0; lc[c] = (nd == 1) ? 0 : fc;
     }
 
-    // ---- exchange blocks first (they read I), per spin: Gt_ik -= cK f sum_jl I D_jl and the il / jk / jl images
     const double fk = -a.cK * f;
+    // Exchange contributions land in the rows of the bra's functions (r = i, or na + j) at the columns of this lane's ket
+    // functions.  With a row buffer (LDS, per wave, zeroed between bras) they are LDS atomics, and the rows leave as one
+    // global atomic per element when the wave moves to another bra; without one they go to global memory directly.
+    auto kadd = [&](int sp, int r, int grow, int col, double v) {
+        if (rowbuf) qc_lds_add(&rowbuf[((size_t)sp * rowcap + r) * n + col], v);
+        else unsafeAtomicAdd(&(sp ? G1 : G0)[(size_t)grow * n + col], v);
+    };
+    auto kadd3 = [&](int sp, int r, int grow, const double (&accK)[NC], const double (&accL)[NC]) {
+        if constexpr (NC == 1) {
+            kadd(sp, r, grow, c0, fk * accK[0]);
+            kadd(sp, r, grow, d0, fk * accL[0]);
+        } else if (nd == 1) {                                 // columns differ in k, share l
+            kadd(sp, r, grow, c0 + kc[0], fk * accK[0]); kadd(sp, r, grow, c0 + kc[1], fk * accK[1]); kadd(sp, r, grow, c0 + kc[2], fk * accK[2]);
+            kadd(sp, r, grow, d0, fk * (accL[0] + accL[1] + accL[2]));
+        } else {                                              // columns differ in l, share k
+            kadd(sp, r, grow, c0, fk * (accK[0] + accK[1] + accK[2]));
+            kadd(sp, r, grow, d0 + lc[0], fk * accL[0]); kadd(sp, r, grow, d0 + lc[1], fk * accL[1]); kadd(sp, r, grow, d0 + lc[2], fk * accL[2]);
+        }
+    };
+    // ---- exchange blocks first (they read I), per spin: Gt_ik -= cK f sum_jl I D_jl and the il / jk / jl images
     if (active) {
         for (int s = 0; s < (uhf ? 2 : 1); ++s) {
             const double *__restrict__ Dk = s ? a.Dk1 : a.Dk0;
-            double *Gs = s ? G1 : G0;
             // targets on the bra function a_i: needs D[b_j, d_l] and D[b_j, c_k]
             for (int i = 0; i < na; ++i) {
                 double accK[NC], accL[NC];                   // G[a_i, c_k] and G[a_i, d_l] partial sums
@@ -258,17 +280,7 @@ __device__ __forceinline__ void qc_bm_body(const QcKernelArgs &a, const double *
                         accL[c] = fma(v, Drow[c0 + kc[c]], accL[c]);
                     }
                 }
-                double *Grow = Gs + (size_t)(offa + i) * n;
-                if constexpr (NC == 1) {
-                    unsafeAtomicAdd(&Grow[c0], fk * accK[0]);
-                    unsafeAtomicAdd(&Grow[d0], fk * accL[0]);
-                } else if (nd == 1) {                         // columns differ in k, share l
-                    unsafeAtomicAdd(&Grow[c0 + kc[0]], fk * accK[0]); unsafeAtomicAdd(&Grow[c0 + kc[1]], fk * accK[1]); unsafeAtomicAdd(&Grow[c0 + kc[2]], fk * accK[2]);
-                    unsafeAtomicAdd(&Grow[d0], fk * (accL[0] + accL[1] + accL[2]));
-                } else {                                      // columns differ in l, share k
-                    unsafeAtomicAdd(&Grow[c0], fk * (accK[0] + accK[1] + accK[2]));
-                    unsafeAtomicAdd(&Grow[d0 + lc[0]], fk * accL[0]); unsafeAtomicAdd(&Grow[d0 + lc[1]], fk * accL[1]); unsafeAtomicAdd(&Grow[d0 + lc[2]], fk * accL[2]);
-                }
+                kadd3(s, i, offa + i, accK, accL);
             }
             // targets on the bra function b_j: needs D[a_i, d_l] and D[a_i, c_k]
             for (int j = 0; j < nb; ++j) {
@@ -285,17 +297,7 @@ __device__ __forceinline__ void qc_bm_body(const QcKernelArgs &a, const double *
                         accL[c] = fma(v, Drow[c0 + kc[c]], accL[c]);
                     }
                 }
-                double *Grow = Gs + (size_t)(offb + j) * n;
-                if constexpr (NC == 1) {
-                    unsafeAtomicAdd(&Grow[c0], fk * accK[0]);
-                    unsafeAtomicAdd(&Grow[d0], fk * accL[0]);
-                } else if (nd == 1) {
-                    unsafeAtomicAdd(&Grow[c0 + kc[0]], fk * accK[0]); unsafeAtomicAdd(&Grow[c0 + kc[1]], fk * accK[1]); unsafeAtomicAdd(&Grow[c0 + kc[2]], fk * accK[2]);
-                    unsafeAtomicAdd(&Grow[d0], fk * (accL[0] + accL[1] + accL[2]));
-                } else {
-                    unsafeAtomicAdd(&Grow[c0], fk * (accK[0] + accK[1] + accK[2]));
-                    unsafeAtomicAdd(&Grow[d0 + lc[0]], fk * accL[0]); unsafeAtomicAdd(&Grow[d0 + lc[1]], fk * accL[1]); unsafeAtomicAdd(&Grow[d0 + lc[2]], fk * accL[2]);
-                }
+                kadd3(s, na + j, offb + j, accK, accL);
             }
         }
     }
@@ -365,11 +367,47 @@ __device__ __forceinline__ void qc_bm_segment(const QcBmArgs &a, const int s, co
         }
     }
     __syncthreads();
-    double *const Iw = lds + ((QC_BM_TWORDS + 1) & ~1) + (size_t)wave * a.seg_iwords[s];
-    const int nb = a.seg_nbundles[s];
-    const int nw = blockDim.x >> 6;                           // <= NW: fewer when the I blocks of NW waves would not fit
-    for (int b = wg * nw + wave; b < nb; b += nwg * nw)
-        qc_bm_body<LAB, LCD>(a.base, a.pairdataT, a.seg_bundles[s], a.seg_ketlist[s], b, lds, Iw, a.pspack);
+    const int nw = blockDim.x >> 6;                           // <= NW: fewer when the LDS blocks of NW waves would not fit
+    const int n = a.base.n, lane = tid & 63;
+    const int rowcap = a.seg_rows[s], nsp = a.base.Dk1 ? 2 : 1;
+    const int rowwords = a.use_rowbuf ? nsp * rowcap * n : 0;
+    double *const wbase = lds + ((QC_BM_TWORDS + 1) & ~1) + (size_t)wave * (a.seg_iwords[s] + rowwords);
+    double *const Iw = wbase;
+    double *const rowbuf = rowwords ? wbase + a.seg_iwords[s] : nullptr;
+    for (int x = lane; x < rowwords; x += 64) rowbuf[x] = 0.0;
+    const QcBundle *__restrict__ bundles = a.seg_bundles[s];
+    // the rows a wave has accumulated for bra pair `bra` leave as one global atomic per touched element
+    auto flush_rows = [&](int bra) {
+        const QcPairDesc pb = a.base.pairs[bra];
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        for (int sp = 0; sp < nsp; ++sp) {
+            double *G = (sp ? a.base.G1 : a.base.G0) + (size_t)(((wg * nw + wave) % a.base.nrep)) * a.base.rep_stride;
+            for (int r = 0; r < pb.na + pb.nb; ++r) {
+                const int grow = r < pb.na ? pb.offa + r : pb.offb + r - pb.na;
+                double *row = rowbuf + ((size_t)sp * rowcap + r) * n;
+                for (int col = lane; col < n; col += 64) {
+                    const double v = row[col];
+                    if (v != 0.0) { unsafeAtomicAdd(&G[(size_t)grow * n + col], v); row[col] = 0.0; }
+                }
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    };
+    const int nb = a.seg_nbundles[s], T = a.seg_run[s];
+    for (int run = wg * nw + wave; run * T < nb; run += nwg * nw) {
+        int cur = -1;
+        const int b1 = min(nb, run * T + T);
+        for (int b = run * T; b < b1; ++b) {
+            if (rowbuf) {
+                const int bra = __builtin_amdgcn_readfirstlane(bundles[b].bra);
+                if (bra != cur) { if (cur >= 0) flush_rows(cur); cur = bra; }
+            }
+            qc_bm_body<LAB, LCD>(a.base, a.pairdataT, bundles, a.seg_ketlist[s], b, lds, Iw, a.pspack, rowbuf, rowcap);
+        }
+        if (rowbuf && cur >= 0) flush_rows(cur);
+    }
 }
 
 template <int LCD, int HI>

@@ -314,7 +314,8 @@ void qc_make_slots(const qc_system *S, const std::vector<QcTask> &tasks, int itm
 // Bra-major work units: the tasks of one bra pair, kets sorted by primitive count (so the lanes of a wave run nearly
 // equal trip counts), cut into bundles of at most 64 kets; with itmax > 0 a bundle is further cut along the bra primitive
 // pairs so that a lane evaluates about itmax primitive quartets.
-void qc_make_bundles(const qc_system *S, const std::vector<QcTask> &tasks, int itmax, std::vector<QcBundle> &bundles, std::vector<int> &ketlist) {
+void qc_make_bundles(const qc_system *S, const std::vector<QcTask> &tasks, int itmax, std::vector<QcBundle> &bundles, std::vector<int> &ketlist,
+                     bool group_by_bra) {
     bundles.clear(); ketlist.clear();
     std::vector<QcTask> t(tasks);
     std::stable_sort(t.begin(), t.end(), [&](const QcTask &x, const QcTask &y) {
@@ -333,8 +334,10 @@ void qc_make_bundles(const qc_system *S, const std::vector<QcTask> &tasks, int i
             bundles.push_back(QcBundle{t[i].bra, (int)((int64_t)Kab * s / nparts), (int)((int64_t)Kab * (s + 1) / nparts), first, (int)(j - i), maxK, 0, 0});
         i = j;
     }
-    // long bundles first: the tail of the launch is made of short ones
-    std::stable_sort(bundles.begin(), bundles.end(), [](const QcBundle &x, const QcBundle &y) {
+    // long bundles first: the tail of the launch is made of short ones.  With `group_by_bra` the bundles of one bra stay
+    // together (a wave takes runs of consecutive bundles and keeps the bra's exchange rows in LDS between them).
+    std::stable_sort(bundles.begin(), bundles.end(), [group_by_bra](const QcBundle &x, const QcBundle &y) {
+        if (group_by_bra && x.bra != y.bra) return x.bra < y.bra;
         return (int64_t)(x.ij_hi - x.ij_lo) * x.maxK > (int64_t)(y.ij_hi - y.ij_lo) * y.maxK;
     });
 }
@@ -367,7 +370,11 @@ void qc_build_shards(qc_system *S) {
         const int64_t want_waves = 256 * 8, G = 64 >> c.LGC;
         int itmax = (int)std::min<int64_t>(QC_SLOT_ITMAX, std::max<int64_t>((c.LAB + c.LCD <= 2) ? 8 : 2, tot_pq / (want_waves * G)));
         c.slots.clear(); c.bundles.clear(); c.ketlist.clear();
-        if (c.bm) qc_make_bundles(S, c.shard, itmax, c.bundles, c.ketlist);
+        if (c.bm) {
+            c.bm_rows = 0;
+            for (const auto &t : c.shard) c.bm_rows = std::max(c.bm_rows, S->pairs[t.bra].na + S->pairs[t.bra].nb);
+            qc_make_bundles(S, c.shard, itmax, c.bundles, c.ketlist, qc_bm_grouped(c.LCD, c.bm_rows));
+        }
         else qc_make_slots(S, c.shard, itmax, c.slots);
         c.prim_quartets = 0; c.bytes_alg = 0; c.flops_alg = 0;
         int words = 0;
@@ -394,7 +401,11 @@ void qc_build_shards(qc_system *S) {
         c.lds_bytes = words * 8 * (64 >> c.LGC);
         if (c.bm) {   // I[nab * ncd][65]: one column per lane
             int mx = 0;
-            for (const auto &t : c.shard) mx = std::max(mx, S->pairs[t.bra].na * S->pairs[t.bra].nb * S->pairs[t.ket].na * S->pairs[t.ket].nb);
+            c.bm_rows = 0;
+            for (const auto &t : c.shard) {
+                mx = std::max(mx, S->pairs[t.bra].na * S->pairs[t.bra].nb * S->pairs[t.ket].na * S->pairs[t.ket].nb);
+                c.bm_rows = std::max(c.bm_rows, S->pairs[t.bra].na + S->pairs[t.bra].nb);
+            }
             c.slot_words = mx;
             c.lds_bytes = mx * 65 * 8;
         }
