@@ -168,13 +168,11 @@ static int launch_segments(qc_system *S, int unit, const std::vector<Seg> &segs,
         while (nw > 1 && QC_BM_LDS_TABLE + nw * wbytes > lds_max) nw /= 2;          // Cartesian d / f bras: 36+ rows of I per wave
         int grid = 0, k = 0;
         for (const Seg &sg : segs) {
-            // persistent workgroups of `nw` waves: at most ~12 waves per CU; a wave takes runs of consecutive bundles
-            const int run = std::max(1, std::min(8, sg.nslots / 2048));
-            const int nruns = (sg.nslots + run - 1) / run;
-            grid += std::min((nruns + nw - 1) / nw, 256 * 12 / nw);
+            // persistent workgroups of `nw` waves: at most ~12 waves per CU, each wave strides through the bundle list
+            grid += std::min((sg.nslots + nw - 1) / nw, 256 * 12 / nw);
             t.seg_end[k] = grid; t.seg_lab[k] = sg.c->LAB; t.seg_bundles[k] = sg.d_bundles; t.seg_ketlist[k] = sg.d_ketlist;
-            t.seg_nbundles[k] = sg.nslots; t.seg_iwords[k] = sg.lds / 8; t.seg_run[k] = run;
-            t.seg_rows[k] = qc_bm_grouped(sg.c->LCD, sg.c->bm_rows) ? rows : 0;      // few exchange targets per lane: direct atomics
+            t.seg_nbundles[k] = sg.nslots; t.seg_iwords[k] = sg.lds / 8;
+            t.seg_rows[k] = rows;
             ++k;
         }
         t.nseg = k;

@@ -17,8 +17,7 @@ struct QcBmArgs {
     int seg_lab[QC_MAXSEG];
     int seg_nbundles[QC_MAXSEG];
     int seg_iwords[QC_MAXSEG];         // doubles of one wave's I block (nab * ncd * 65)
-    int seg_rows[QC_MAXSEG];           // most bra functions (na + nb) of the segment's bundles: rows of a wave's exchange buffer
-    int seg_run[QC_MAXSEG];            // consecutive bundles (sorted by bra) a wave takes at a time
+    int seg_rows[QC_MAXSEG];           // most bra functions (na + nb) of the segment's bundles: rows of a wave's exchange buffer (0: none)
     int use_rowbuf;                    // exchange rows accumulate in LDS (n small enough), else global atomics per bundle
     const QcBundle *seg_bundles[QC_MAXSEG];
     const int *seg_ketlist[QC_MAXSEG];

@@ -243,8 +243,8 @@ __device__ __forceinline__ void qc_bm_body(const QcKernelArgs &a, const double *
 
     const double fk = -a.cK * f;
     // Exchange contributions land in the rows of the bra's functions (r = i, or na + j) at the columns of this lane's ket
-    // functions.  With a row buffer (LDS, per wave, zeroed between bras) they are LDS atomics, and the rows leave as one
-    // global atomic per element when the wave moves to another bra; without one they go to global memory directly.
+    // functions.  With a row buffer (LDS, per wave) they are DS atomics and the rows leave as one global atomic per
+    // touched element after the bundle; without one they go to global memory directly.
     auto kadd = [&](int sp, int r, int grow, int col, double v) {
         if (rowbuf) qc_lds_add(&rowbuf[((size_t)sp * rowcap + r) * n + col], v);
         else unsafeAtomicAdd(&(sp ? G1 : G0)[(size_t)grow * n + col], v);
@@ -376,7 +376,8 @@ __device__ __forceinline__ void qc_bm_segment(const QcBmArgs &a, const int s, co
     double *const rowbuf = rowwords ? wbase + a.seg_iwords[s] : nullptr;
     for (int x = lane; x < rowwords; x += 64) rowbuf[x] = 0.0;
     const QcBundle *__restrict__ bundles = a.seg_bundles[s];
-    // the rows a wave has accumulated for bra pair `bra` leave as one global atomic per touched element
+    // the rows a wave has accumulated for the bundle of bra pair `bra` leave as one global atomic per touched element:
+    // the 64 kets of a bundle share most of their functions, so the lanes' contributions combine 2-5x in LDS first
     auto flush_rows = [&](int bra) {
         const QcPairDesc pb = a.base.pairs[bra];
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
@@ -395,18 +396,10 @@ __device__ __forceinline__ void qc_bm_segment(const QcBmArgs &a, const int s, co
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
     };
-    const int nb = a.seg_nbundles[s], T = a.seg_run[s];
-    for (int run = wg * nw + wave; run * T < nb; run += nwg * nw) {
-        int cur = -1;
-        const int b1 = min(nb, run * T + T);
-        for (int b = run * T; b < b1; ++b) {
-            if (rowbuf) {
-                const int bra = __builtin_amdgcn_readfirstlane(bundles[b].bra);
-                if (bra != cur) { if (cur >= 0) flush_rows(cur); cur = bra; }
-            }
-            qc_bm_body<LAB, LCD>(a.base, a.pairdataT, bundles, a.seg_ketlist[s], b, lds, Iw, a.pspack, rowbuf, rowcap);
-        }
-        if (rowbuf && cur >= 0) flush_rows(cur);
+    const int nb = a.seg_nbundles[s];
+    for (int b = wg * nw + wave; b < nb; b += nwg * nw) {
+        qc_bm_body<LAB, LCD>(a.base, a.pairdataT, bundles, a.seg_ketlist[s], b, lds, Iw, a.pspack, rowbuf, rowcap);
+        if (rowbuf) flush_rows(__builtin_amdgcn_readfirstlane(bundles[b].bra));
     }
 }
 

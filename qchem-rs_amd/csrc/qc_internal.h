@@ -184,11 +184,7 @@ inline int qc_shard_owner(size_t i, int nranks, size_t ci) {
 }
 void qc_make_slots(const qc_system *S, const std::vector<QcTask> &tasks, int itmax, std::vector<QcSlot> &out);
 // group tasks by bra into bundles of <= 64 kets (sorted by primitive count); itmax > 0 also cuts the bra primitive range
-void qc_make_bundles(const qc_system *S, const std::vector<QcTask> &tasks, int itmax, std::vector<QcBundle> &bundles, std::vector<int> &ketlist,
-                     bool group_by_bra = false);
-// bra-major classes whose lanes send enough exchange contributions (columns x bra functions) to be worth collecting in
-// an LDS row buffer per bra: their bundles are kept grouped by bra
-inline bool qc_bm_grouped(int LCD, int rows) { return (LCD == 0 ? 1 : 3) * rows >= 6; }
+void qc_make_bundles(const qc_system *S, const std::vector<QcTask> &tasks, int itmax, std::vector<QcBundle> &bundles, std::vector<int> &ketlist);
 inline int qc_unit_of(int LAB, int LCD, bool bm) { return bm ? 2 * (QC_LPAIR + 1) + 2 * LCD + (LAB >= 3 ? 1 : 0) : 2 * LAB + (LCD >= 4 ? 1 : 0); }
 void qc_dots(hipStream_t st, int n, const double *x, const double *const *ys, int ny, double *out);  // device ptr list
 void qc_lincomb(hipStream_t st, int n, const double *const *Fs, const double *c, int m, double *out);   // out = sum c_i Fs_i

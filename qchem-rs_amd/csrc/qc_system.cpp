@@ -314,8 +314,7 @@ void qc_make_slots(const qc_system *S, const std::vector<QcTask> &tasks, int itm
 // Bra-major work units: the tasks of one bra pair, kets sorted by primitive count (so the lanes of a wave run nearly
 // equal trip counts), cut into bundles of at most 64 kets; with itmax > 0 a bundle is further cut along the bra primitive
 // pairs so that a lane evaluates about itmax primitive quartets.
-void qc_make_bundles(const qc_system *S, const std::vector<QcTask> &tasks, int itmax, std::vector<QcBundle> &bundles, std::vector<int> &ketlist,
-                     bool group_by_bra) {
+void qc_make_bundles(const qc_system *S, const std::vector<QcTask> &tasks, int itmax, std::vector<QcBundle> &bundles, std::vector<int> &ketlist) {
     bundles.clear(); ketlist.clear();
     std::vector<QcTask> t(tasks);
     std::stable_sort(t.begin(), t.end(), [&](const QcTask &x, const QcTask &y) {
@@ -334,10 +333,8 @@ void qc_make_bundles(const qc_system *S, const std::vector<QcTask> &tasks, int i
             bundles.push_back(QcBundle{t[i].bra, (int)((int64_t)Kab * s / nparts), (int)((int64_t)Kab * (s + 1) / nparts), first, (int)(j - i), maxK, 0, 0});
         i = j;
     }
-    // long bundles first: the tail of the launch is made of short ones.  With `group_by_bra` the bundles of one bra stay
-    // together (a wave takes runs of consecutive bundles and keeps the bra's exchange rows in LDS between them).
-    std::stable_sort(bundles.begin(), bundles.end(), [group_by_bra](const QcBundle &x, const QcBundle &y) {
-        if (group_by_bra && x.bra != y.bra) return x.bra < y.bra;
+    // long bundles first: the tail of the launch is made of short ones
+    std::stable_sort(bundles.begin(), bundles.end(), [](const QcBundle &x, const QcBundle &y) {
         return (int64_t)(x.ij_hi - x.ij_lo) * x.maxK > (int64_t)(y.ij_hi - y.ij_lo) * y.maxK;
     });
 }
@@ -373,7 +370,7 @@ void qc_build_shards(qc_system *S) {
         if (c.bm) {
             c.bm_rows = 0;
             for (const auto &t : c.shard) c.bm_rows = std::max(c.bm_rows, S->pairs[t.bra].na + S->pairs[t.bra].nb);
-            qc_make_bundles(S, c.shard, itmax, c.bundles, c.ketlist, qc_bm_grouped(c.LCD, c.bm_rows));
+            qc_make_bundles(S, c.shard, itmax, c.bundles, c.ketlist);
         }
         else qc_make_slots(S, c.shard, itmax, c.slots);
         c.prim_quartets = 0; c.bytes_alg = 0; c.flops_alg = 0;
