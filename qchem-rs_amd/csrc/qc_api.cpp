@@ -529,19 +529,17 @@ static int scf_iterate(qc_scf_state *st, double *energy, double *rms_out) {
     // behind unsignalled barriers while the main queue still works, and with 8 hardware queues on 4 pipes the blocked
     // queues stall their pipe neighbours - 1.6 ms per pass instead of 0.6.)
     QC_HIP_CHECK(hipEventRecord(st->ev1, sm));
-    QC_HIP_CHECK(hipMemsetAsync(W.ctl, 0, 16 * sizeof(int), sm));
-    for (int s = 0; s < nspin; ++s)
+    for (int s = 0; s < nspin; ++s)                                       // (the control words were cleared by the previous pass)
         if ((rc = roothaan_enqueue(S, W, *st->diis[s], st->G.p + s * nn, st->D[s].p, st->ws.p + s * n, st->Cs.p + s * nn, s)) != QC_OK) return rc;
+    int *h_ctl = reinterpret_cast<int *>(W.h_scal + 4);
     auto density_and_scalars = [&](int s) -> int {
         if (st->nocc[s] > 0) qc_gemm(sm, n, n, st->nocc[s], st->uhf ? 1.0 : 2.0, st->Cs.p + s * nn, n, false, st->Cs.p + s * nn, n, true, 0.0, st->Dn[s].p, n);
         else QC_HIP_CHECK(hipMemsetAsync(st->Dn[s].p, 0, nn * sizeof(double), sm));
-        qc_energy_rms(sm, n, st->Dn[s].p, st->D[s].p, W.H.p, st->G.p + s * nn, W.scal.p + 2 * s);
+        // energy and rms straight into pinned host memory; the last spin's kernel also hands over and clears the control words
+        qc_energy_rms(sm, n, st->Dn[s].p, st->D[s].p, W.H.p, st->G.p + s * nn, W.h_scal + 2 * s, s == nspin - 1 ? W.ctl : nullptr, h_ctl);
         return QC_OK;
     };
     for (int s = 0; s < nspin; ++s) if ((rc = density_and_scalars(s)) != QC_OK) return rc;
-    int *h_ctl = reinterpret_cast<int *>(W.h_scal + 4);
-    QC_HIP_CHECK(hipMemcpyAsync(W.h_scal, W.scal.p, 4 * sizeof(double), hipMemcpyDeviceToHost, sm));
-    QC_HIP_CHECK(hipMemcpyAsync(h_ctl, W.ctl, 16 * sizeof(int), hipMemcpyDeviceToHost, sm));
     QC_HIP_CHECK(hipEventRecord(st->ev2, sm));
     QC_HIP_CHECK(wait_event(st->ev2));
     if (h_ctl[8] != 0) return QC_DIIS_SINGULAR;                          // "DIIS failed", rhf.rs:73
@@ -562,7 +560,6 @@ static int scf_iterate(qc_scf_state *st, double *energy, double *rms_out) {
         redo = true;
     }
     if (redo) {
-        QC_HIP_CHECK(hipMemcpyAsync(W.h_scal, W.scal.p, 4 * sizeof(double), hipMemcpyDeviceToHost, sm));
         QC_HIP_CHECK(hipEventRecord(st->ev2, sm));
         QC_HIP_CHECK(wait_event(st->ev2));
         float ms_r = 0;

@@ -191,7 +191,7 @@ void qc_lincomb(hipStream_t st, int n, const double *const *Fs, const double *c,
 void qc_scale_cols_invsqrt(hipStream_t st, int n, const double *U, const double *Lam, double *out);
 int qc_device_reshard(qc_system *S);
 void qc_energy_rms(hipStream_t st, int n, const double *Dnew, const double *Dold, const double *H, const double *G,
-                   double *out2);  // out2[0] = 0.5 tr(Dnew (2H+G)), out2[1] = sum_i (Dnew-Dold)_ii^2
+                   double *out2, int *ctl = nullptr, int *ctl_out = nullptr);  // out2[0] = 0.5 tr(Dnew (2H+G)), out2[1] = sum_i (Dnew-Dold)_ii^2
 
 #define QC_HIP_CHECK(expr)                                                                  \
     do {                                                                                    \

@@ -16,16 +16,17 @@ typedef double double4_t __attribute__((ext_vector_type(4)));
 // C = alpha * op(A) * op(B) + beta * C with v_mfma_f64_16x16x4_f64.  One wave per 16x16 tile of C.
 // Operand lane maps (cdna_hip_programming.md section 3): lane l holds A[i = l & 15][k = l >> 4] and
 // B[k = l >> 4][j = l & 15]; result register r holds C[row = (l >> 4) + 4 r][col = l & 15].
-__global__ __launch_bounds__(64) void qc_gemm_kernel(int m, int n, int k, double alpha, const double *__restrict__ A, int lda, int ta,
-                                                     const double *__restrict__ B, int ldb, int tb, double beta, double *__restrict__ C,
-                                                     int ldc, const int *__restrict__ skip) {
-    if (skip && *skip != 0) return;                        // device-side control flow of the sync-free SCF step
+struct QcGemmArgs { int m, n, k; double alpha; const double *A; int lda, ta; const double *B; int ldb, tb; double beta; double *C; int ldc; };
+
+__device__ __forceinline__ void qc_gemm_tile(const QcGemmArgs &g) {
+    const int m = g.m, n = g.n, k = g.k;
+    const double *__restrict__ A = g.A, *__restrict__ B = g.B;
     const int lane = threadIdx.x, li = lane & 15, lk = lane >> 4;
     const int row0 = blockIdx.y * 16, col0 = blockIdx.x * 16;
     const int ai = row0 + li, bj = col0 + li;
     const bool aok = ai < m, bok = bj < n;
-    const size_t a_i = ta ? (size_t)ai : (size_t)ai * lda, a_k = ta ? (size_t)lda : 1;
-    const size_t b_j = tb ? (size_t)bj * ldb : (size_t)bj, b_k = tb ? 1 : (size_t)ldb;
+    const size_t a_i = g.ta ? (size_t)ai : (size_t)ai * g.lda, a_k = g.ta ? (size_t)g.lda : 1;
+    const size_t b_j = g.tb ? (size_t)bj * g.ldb : (size_t)bj, b_k = g.tb ? 1 : (size_t)g.ldb;
     double4_t acc = {0.0, 0.0, 0.0, 0.0};
     for (int k0 = 0; k0 < k; k0 += 16) {
         double av[4], bv[4];
@@ -43,17 +44,37 @@ __global__ __launch_bounds__(64) void qc_gemm_kernel(int m, int n, int k, double
         for (int r = 0; r < 4; ++r) {
             const int row = row0 + lk + 4 * r;
             if (row < m) {
-                double *c = &C[(size_t)row * ldc + bj];
-                *c = (beta == 0.0) ? alpha * acc[r] : fma(alpha, acc[r], beta * *c);
+                double *c = &g.C[(size_t)row * g.ldc + bj];
+                *c = (g.beta == 0.0) ? g.alpha * acc[r] : fma(g.alpha, acc[r], g.beta * *c);
             }
         }
     }
 }
 
+__global__ __launch_bounds__(64) void qc_gemm_kernel(const QcGemmArgs g, const int *__restrict__ skip) {
+    if (skip && *skip != 0) return;                        // device-side control flow of the sync-free SCF step
+    qc_gemm_tile(g);
+}
+
+// two independent products of the same shape in one launch (blockIdx.z picks the problem)
+__global__ __launch_bounds__(64) void qc_gemm2_kernel(const QcGemmArgs g0, const QcGemmArgs g1, const int *__restrict__ skip) {
+    if (skip && *skip != 0) return;
+    qc_gemm_tile(blockIdx.z ? g1 : g0);
+}
+
 void qc_gemm(hipStream_t st, int m, int n, int k, double alpha, const double *A, int lda, bool ta, const double *B, int ldb, bool tb,
              double beta, double *C, int ldc, const int *skip) {
     dim3 grid((n + 15) / 16, (m + 15) / 16);
-    hipLaunchKernelGGL(qc_gemm_kernel, grid, dim3(64), 0, st, m, n, k, alpha, A, lda, ta ? 1 : 0, B, ldb, tb ? 1 : 0, beta, C, ldc, skip);
+    const QcGemmArgs g{m, n, k, alpha, A, lda, ta ? 1 : 0, B, ldb, tb ? 1 : 0, beta, C, ldc};
+    hipLaunchKernelGGL(qc_gemm_kernel, grid, dim3(64), 0, st, g, skip);
+}
+
+// C0 = op(A0) op(B0), C1 = op(A1) op(B1), all n x n
+static void qc_gemm_pair(hipStream_t st, int n, const double *A0, bool ta0, const double *B0, double *C0, const double *A1, bool ta1,
+                         const double *B1, double *C1, const int *skip) {
+    dim3 grid((n + 15) / 16, (n + 15) / 16, 2);
+    const QcGemmArgs g0{n, n, n, 1.0, A0, n, ta0 ? 1 : 0, B0, n, 0, 0.0, C0, n}, g1{n, n, n, 1.0, A1, n, ta1 ? 1 : 0, B1, n, 0, 0.0, C1, n};
+    hipLaunchKernelGGL(qc_gemm2_kernel, grid, dim3(64), 0, st, g0, g1, skip);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -436,9 +457,13 @@ int qc_eig_device_warm(hipStream_t st, int n, double *dA, const double *dV0, dou
 //        [5] max |a_ij| / g over regular pairs (size of the first-order update)  [6] 1 if some index has > 1 strong partner
 constexpr double QC_REF_TAU = 1e-3, QC_REF_TINY = 1e-13, QC_REF_GFLOOR = 1e-8;
 
+__device__ __forceinline__ double qc_refine_m(int n, int x, const double *__restrict__ S, const double *__restrict__ XtX,
+                                              const double *__restrict__ lam, double tiny, double gfloor, const int *__restrict__ partner);
+
+// `M` (sync-free variant only): the update matrix I + E is written by this kernel as well, saving a launch per pass
 __global__ __launch_bounds__(1024) void qc_refine_stats_kernel(int n, const double *__restrict__ S, const double *__restrict__ XtX,
                                                                 double *__restrict__ lam, double *__restrict__ stats, int *__restrict__ partner,
-                                                                int *__restrict__ ctl) {
+                                                                int *__restrict__ ctl, double *__restrict__ M) {
     if (ctl && ctl[0] != 0) return;
     __shared__ double red[4 * 16];
     __shared__ double sh_scale;
@@ -505,39 +530,48 @@ __global__ __launch_bounds__(1024) void qc_refine_stats_kernel(int n, const doub
             }
         }
     }
+    if (M) {
+        __syncthreads();                                     // partner[], lam[], the decision: written by this workgroup
+        if (ctl[0] != 0) return;
+        const double scl = sh_scale;
+        for (int x = tid; x < n * n; x += 1024) M[x] = qc_refine_m(n, x, S, XtX, lam, QC_REF_TINY * scl, QC_REF_GFLOOR * scl, partner);
+    }
 }
 
-// M = I + E with exact rotations on the strong pairs
+// element x of M = I + E, with exact rotations on the strong pairs
+__device__ __forceinline__ double qc_refine_m(int n, int x, const double *__restrict__ S, const double *__restrict__ XtX,
+                                              const double *__restrict__ lam, double tiny, double gfloor, const int *__restrict__ partner) {
+    const int i = x / n, j = x - i * n;
+    const double r = (i == j ? 1.0 : 0.0) - XtX[x];
+    double m;
+    if (i == j) {
+        m = 1.0 + 0.5 * r;
+        const int pj = partner[i];
+        if (pj >= 0) {                                   // cosine of this index's rotation
+            const double a = 0.5 * (S[(size_t)i * n + pj] + S[(size_t)pj * n + i]) - 0.5 * (lam[i] + lam[pj]) * XtX[(size_t)i * n + pj];
+            const double theta = (lam[pj] - lam[i]) / (2.0 * a);
+            const double t = (theta >= 0.0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(fma(theta, theta, 1.0)));
+            m = 1.0 / sqrt(fma(t, t, 1.0)) + 0.5 * r;
+        }
+    } else {
+        const double sij = 0.5 * (S[x] + S[(size_t)j * n + i]);      // A is symmetric only to rounding: use the symmetric part
+        const double a = sij + 0.5 * (lam[i] + lam[j]) * r, g = lam[j] - lam[i];
+        if (partner[i] == j) {                           // sine: x_j' = c x_j + s x_i
+            const double theta = g / (2.0 * a);
+            const double t = (theta >= 0.0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(fma(theta, theta, 1.0)));
+            m = t / sqrt(fma(t, t, 1.0));
+        } else if (fabs(a) <= tiny || fabs(g) <= gfloor) m = 0.5 * r;
+        else m = (sij + lam[j] * r) / g;
+    }
+    return m;
+}
+
 __global__ void qc_refine_update_kernel(int n, const double *__restrict__ S, const double *__restrict__ XtX, const double *__restrict__ lam,
                                         const double *__restrict__ stats, const int *__restrict__ partner, double *__restrict__ M,
                                         const int *__restrict__ ctl) {
     if (ctl && ctl[0] != 0) return;
     const double scale = stats[2], tiny = QC_REF_TINY * scale, gfloor = QC_REF_GFLOOR * scale;
-    for (int x = blockIdx.x * blockDim.x + threadIdx.x; x < n * n; x += gridDim.x * blockDim.x) {
-        const int i = x / n, j = x - i * n;
-        const double r = (i == j ? 1.0 : 0.0) - XtX[x];
-        double m;
-        if (i == j) {
-            m = 1.0 + 0.5 * r;
-            const int pj = partner[i];
-            if (pj >= 0) {                                   // cosine of this index's rotation
-                const double a = 0.5 * (S[(size_t)i * n + pj] + S[(size_t)pj * n + i]) - 0.5 * (lam[i] + lam[pj]) * XtX[(size_t)i * n + pj];
-                const double theta = (lam[pj] - lam[i]) / (2.0 * a);
-                const double t = (theta >= 0.0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(fma(theta, theta, 1.0)));
-                m = 1.0 / sqrt(fma(t, t, 1.0)) + 0.5 * r;
-            }
-        } else {
-            const double sij = 0.5 * (S[x] + S[(size_t)j * n + i]);      // A is symmetric only to rounding: use the symmetric part
-            const double a = sij + 0.5 * (lam[i] + lam[j]) * r, g = lam[j] - lam[i];
-            if (partner[i] == j) {                           // sine: x_j' = c x_j + s x_i
-                const double theta = g / (2.0 * a);
-                const double t = (theta >= 0.0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(fma(theta, theta, 1.0)));
-                m = t / sqrt(fma(t, t, 1.0));
-            } else if (fabs(a) <= tiny || fabs(g) <= gfloor) m = 0.5 * r;
-            else m = (sij + lam[j] * r) / g;
-        }
-        M[x] = m;
-    }
+    for (int x = blockIdx.x * blockDim.x + threadIdx.x; x < n * n; x += gridDim.x * blockDim.x) M[x] = qc_refine_m(n, x, S, XtX, lam, tiny, gfloor, partner);
 }
 
 // ascending eigenvalues + columns permuted alongside (utils.rs:28)
@@ -588,7 +622,7 @@ int qc_eig_device_refine(hipStream_t st, int n, double *dA, const double *dV0, d
         qc_gemm(st, n, n, n, 1.0, dA, n, false, X, n, false, 0.0, t1, n);          // A X
         qc_gemm(st, n, n, n, 1.0, X, n, true, t1, n, false, 0.0, t2, n);           // S = X^T A X
         qc_gemm(st, n, n, n, 1.0, X, n, true, X, n, false, 0.0, t3, n);            // X^T X
-        hipLaunchKernelGGL(qc_refine_stats_kernel, dim3(1), dim3(1024), 0, st, n, t2, t3, lam, stats, partner, (int *)nullptr);
+        hipLaunchKernelGGL(qc_refine_stats_kernel, dim3(1), dim3(1024), 0, st, n, t2, t3, lam, stats, partner, (int *)nullptr, (double *)nullptr);
         if (hipMemcpyAsync(hs, stats, 7 * sizeof(double), hipMemcpyDeviceToHost, st) != hipSuccess) return QC_ERR_HIP;
         if (hipStreamSynchronize(st) != hipSuccess) return QC_ERR_HIP;
         const double scale = fmax(hs[2], 1e-300), orth = hs[1], nstrong = hs[3], cmax = hs[4], emax = hs[5], multi = hs[6];
@@ -663,17 +697,14 @@ __global__ __launch_bounds__(1024) void qc_refine_finish_kernel(int n, const dou
 
 int qc_eig_refine_async(hipStream_t st, int n, double *dA, const double *dV0, double *dV, double *dw, double *d_work, double *t1, double *t2,
                         double *t3, double *t4, double *small, int *ctl, int npass) {
-    const size_t nn = (size_t)n * n;
     double *lam = small, *stats = small + n;
     int *partner = reinterpret_cast<int *>(small + n + 8);
     // ctl[0..3] must be zero on entry (the SCF step clears all control words with one memset)
     const double *X = dV0;                                    // pass 0 reads the start vectors in place, later passes t4
     for (int pass = 0; pass < npass; ++pass) {
-        qc_gemm(st, n, n, n, 1.0, dA, n, false, X, n, false, 0.0, t1, n, ctl);          // A X
+        qc_gemm_pair(st, n, dA, false, X, t1, X, true, X, t3, ctl);                     // A X  and  X^T X in one launch
         qc_gemm(st, n, n, n, 1.0, X, n, true, t1, n, false, 0.0, t2, n, ctl);           // S = X^T A X
-        qc_gemm(st, n, n, n, 1.0, X, n, true, X, n, false, 0.0, t3, n, ctl);            // X^T X
-        hipLaunchKernelGGL(qc_refine_stats_kernel, dim3(1), dim3(1024), 0, st, n, t2, t3, lam, stats, partner, ctl);
-        hipLaunchKernelGGL(qc_refine_update_kernel, dim3((unsigned)((nn + 255) / 256)), dim3(256), 0, st, n, t2, t3, lam, stats, partner, t1, (const int *)ctl);
+        hipLaunchKernelGGL(qc_refine_stats_kernel, dim3(1), dim3(1024), 0, st, n, t2, t3, lam, stats, partner, ctl, t1);   // + M = I + E -> t1
         qc_gemm(st, n, n, n, 1.0, X, n, false, t1, n, false, 0.0, d_work, n, ctl);      // X (I + E)
         hipLaunchKernelGGL(qc_refine_finish_kernel, dim3(1), dim3(1024), n * sizeof(int), st, n, lam, d_work, t4, dw, dV, ctl, pass == npass - 1 ? 1 : 0);
         X = t4;
@@ -937,8 +968,10 @@ void qc_dots(hipStream_t st, int n, const double *x, const double *const *ys, in
 }
 
 // out2[0] = 0.5 tr(Dnew (2H + G)),  out2[1] = sum_i (Dnew - Dold)_ii^2      (rhf.rs:84-88)
+// `out2` may be pinned host memory (the SCF pass reads its scalars without a copy); with `ctl` the control words are
+// copied next to them (ctl_out) and cleared for the next pass.
 __global__ __launch_bounds__(256) void qc_energy_rms_kernel(int n, const double *Dn, const double *Do, const double *H, const double *G,
-                                                            double *out2) {
+                                                            double *out2, int *ctl, int *ctl_out) {
     __shared__ double sh[4];
     double e = 0.0, r = 0.0;
     for (int x = threadIdx.x; x < n * n; x += 256) {
@@ -949,9 +982,12 @@ __global__ __launch_bounds__(256) void qc_energy_rms_kernel(int n, const double 
     e = block_sum_256(e, sh);
     r = block_sum_256(r, sh);
     if (threadIdx.x == 0) { out2[0] = 0.5 * e; out2[1] = r; }
+    if (ctl && threadIdx.x < 16) { ctl_out[threadIdx.x] = ctl[threadIdx.x]; ctl[threadIdx.x] = 0; }
+    __threadfence_system();
 }
-void qc_energy_rms(hipStream_t st, int n, const double *Dnew, const double *Dold, const double *H, const double *G, double *out2) {
-    hipLaunchKernelGGL(qc_energy_rms_kernel, dim3(1), dim3(256), 0, st, n, Dnew, Dold, H, G, out2);
+void qc_energy_rms(hipStream_t st, int n, const double *Dnew, const double *Dold, const double *H, const double *G, double *out2, int *ctl,
+                   int *ctl_out) {
+    hipLaunchKernelGGL(qc_energy_rms_kernel, dim3(1), dim3(256), 0, st, n, Dnew, Dold, H, G, out2, ctl, ctl_out);
 }
 
 // out = sum_i c[i] * Fs[i]   (diis.rs:52-58)
