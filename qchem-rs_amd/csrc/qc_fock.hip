@@ -163,7 +163,8 @@ static int launch_segments(qc_system *S, int unit, const std::vector<Seg> &segs,
         for (const Seg &sg : segs) { iblock = std::max(iblock, sg.lds); rows = std::max(rows, sg.c->bm_rows); }
         // exchange rows of a wave's current bra in LDS: (na + nb) rows x n columns per spin
         const int rowbytes = (base.Dk1 ? 2 : 1) * rows * S->nbasis * 8;
-        t.use_rowbuf = (base.eri_out == nullptr && QC_BM_LDS_TABLE + 2 * (iblock + rowbytes) <= lds_max) ? 1 : 0;
+        // (QC_BM_NO_ROWBUF forces the large-n fallback - direct global atomics per bundle - so that tests can reach it)
+        t.use_rowbuf = (base.eri_out == nullptr && QC_BM_LDS_TABLE + 2 * (iblock + rowbytes) <= lds_max && !getenv("QC_BM_NO_ROWBUF")) ? 1 : 0;
         const int wbytes = iblock + (t.use_rowbuf ? rowbytes : 0);
         while (nw > 1 && QC_BM_LDS_TABLE + nw * wbytes > lds_max) nw /= 2;          // Cartesian d / f bras: 36+ rows of I per wave
         int grid = 0, k = 0;

@@ -86,6 +86,22 @@ def test_fock_uhf_matches_dense_contraction(mol, basis):
     assert np.abs(Gb - Gb_ref).max() < TOL_INT * scale
 
 
+def test_fock_without_the_lds_row_buffer(monkeypatch):
+    """The bra-major kernels' large-n fallback (exchange contributions as global atomics per bundle, no LDS row buffer)
+    gives the same G for both spins' code paths."""
+    monkeypatch.setenv("QC_BM_NO_ROWBUF", "1")
+    q, s, o = _sys("water", "cc-pVDZ")
+    I = o.eri()
+    D = _rand_sym(s.n, 11)
+    G_ref = o.g_rhf(D, I)
+    assert np.abs(s.fock_rhf(D) - G_ref).max() < TOL_INT * max(1.0, np.abs(G_ref).max())
+    Da, Db = _rand_sym(s.n, 12), _rand_sym(s.n, 13)
+    Ga, Gb = s.fock_uhf(Da, Db)
+    Ga_ref, Gb_ref = o.g_uhf(Da, Db, I), o.g_uhf(Db, Da, I)
+    assert np.abs(Ga - Ga_ref).max() < TOL_INT * max(1.0, np.abs(Ga_ref).max())
+    assert np.abs(Gb - Gb_ref).max() < TOL_INT * max(1.0, np.abs(Gb_ref).max())
+
+
 def test_fock_linearity_and_symmetry_benzene_ccpvdz():
     """Full-size property test (BASELINE config 5, n = 114): G is linear in D and symmetric."""
     q, s, o = _sys("benzene", "cc-pVDZ")
