@@ -139,7 +139,7 @@ void qc_device_free(qc_system *S) {
 
 static QcKernelArgs base_args(qc_system *S, const QcFockArgs &fa) {
     QcKernelArgs a{};
-    a.pairs = S->d_pairs; a.pairdata = S->d_pairdata; a.boys = S->d_boys; a.n = S->nbasis;
+    a.pairs = S->d_pairs; a.pairdata = S->d_pairdata; a.pairdataT = S->d_pairdataT; a.boys = S->d_boys; a.n = S->nbasis;
     a.Dj = fa.Dj; a.Dk0 = fa.Dk0; a.Dk1 = fa.Dk1; a.G0 = fa.G0; a.G1 = fa.G1; a.cK = fa.cK; a.eri_out = fa.eri_out;
     a.nrep = fa.nrep > 0 ? fa.nrep : 1; a.rep_stride = fa.rep_stride;
     return a;

@@ -25,6 +25,7 @@
 struct QcKernelArgs {
     const QcPairDesc *pairs;
     const double *pairdata;
+    const double *pairdataT;  // same blocks, expansion stored [ab][h] (A operand of the MFMA step 3)
     const double *boys;
     int n;
     const double *Dj, *Dk0, *Dk1;
@@ -214,6 +215,18 @@ __device__ __forceinline__ void qc_fock_body(const QcKernelArgs &a, const QcSlot
     double *const Rw = lds + (size_t)g * slot_words;       // this group's private LDS region
     double *const Iblk = Rw + qc_region0(L, LGC);
     const size_t rep = (size_t)(blk % a.nrep) * a.rep_stride;   // accumulation replica of this workgroup
+    constexpr bool MFMA = qc_use_mfma(LAB, LCD) && LGC == 6;   // contractions on the matrix cores (one slot per wave)
+    if constexpr (MFMA) {
+        int *const tab = reinterpret_cast<int *>(Rw + slot_words - 48);
+        for (int h = lane; h < qc_nherm(QC_LPAIR); h += 64) {       // (N, s, v) of Hermite index h, packed
+            int N = 0;
+            while (qc_nherm(N) <= h) ++N;
+            const int r = h - (N ? qc_nherm(N - 1) : 0);
+            const int sv = (int)((sqrtf(8.0f * r + 1.0f) - 1.0f) * 0.5f + 1e-3f);
+            tab[h] = N | (sv << 8) | ((r - sv * (sv + 1) / 2) << 16);
+        }
+        __syncthreads();
+    }
 
     for (int wave = blk; wave * G < nslots; wave += nblk) {
         const int slot = wave * G + g;
@@ -250,6 +263,113 @@ __device__ __forceinline__ void qc_fock_body(const QcKernelArgs &a, const QcSlot
         const double *braBase = pd + pb.doff, *ketBase = pd + pk.doff;
         const int npass = (LGC == 6) ? (ncd + 63) / 64 : 1;  // > 1 only for ket pairs with more than 64 function pairs
 
+        if constexpr (MFMA) {
+          // ---- high-order kets (LCD >= 4): both Hermite contractions on the matrix cores.  One slot per wave.
+          //   step 2  W[h1][c] += sum_h2 Rm[h1][h2] Ee[h2][c],  Rm[h1][h2] = (-1)^{|h2|} R_{h1+h2},  Ee = E_cd,kl * pref
+          //   step 3  I[ab][c] += sum_h1 Et[ab][h1] W[h1][c]
+          // as v_mfma_f64_16x16x4 tiles.  The VALU form reads one R value from LDS per FMA in every lane (7056 reads
+          // per lane for (ff|ff)); here the gathered Rm fragment is spread over the wave (110 reads per lane) and the W
+          // accumulators - result layout C[4r + (l >> 4)][l & 15] - are, register for register, the B operands
+          // B[k = l >> 4][j = l & 15] of step 3's k-steps, so nothing moves between the two products.
+          typedef double qc_d4 __attribute__((ext_vector_type(4)));
+          constexpr int MT = (HAB + 15) / 16, KS = (HCD + 3) / 4;
+          const int i16 = lane & 15, q4 = lane >> 4;
+          int *const tab = reinterpret_cast<int *>(Rw + slot_words - 48);   // (N, s = u+v, v) of every Hermite index
+          int n1[MT], s1[MT], v1[MT];
+#pragma unroll
+          for (int mt = 0; mt < MT; ++mt) {
+              const int t = tab[min(16 * mt + i16, HAB - 1)];
+              n1[mt] = t & 255; s1[mt] = (t >> 8) & 255; v1[mt] = t >> 16;
+          }
+          const double *__restrict__ pdT = a.pairdataT;
+          for (int pass = 0; pass < npass; ++pass) {
+            const int col0 = pass * 64;
+            const int NT = min(4, (ncd - col0 + 15) / 16);
+            qc_d4 Wacc[MT][4];
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < 4; ++nt) Wacc[mt][nt] = qc_d4{0.0, 0.0, 0.0, 0.0};
+            int cur_ij = -1;
+            auto flush = [&](int ij) {
+                const double *__restrict__ Et = pdT + pb.doff + (size_t)ij * strideB + 4;     // [ab][h]
+                const int MI = (nab + 15) / 16;
+                for (int it = 0; it < MI; ++it) {
+                    const int ab = 16 * it + i16;
+                    double av[MT][4];                            // A fragments of this row tile: Et[ab][h1], shared by the column tiles
+#pragma unroll
+                    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const int h1 = 16 * mt + 4 * r + q4;
+                            av[mt][r] = (ab < nab && h1 < HAB) ? Et[(size_t)ab * HAB + h1] : 0.0;
+                        }
+#pragma unroll
+                    for (int nt = 0; nt < 4; ++nt) {
+                        if (nt >= NT) break;
+                        qc_d4 acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[mt][r], Wacc[mt][nt][r], acc, 0, 0, 0);
+                        const int c = col0 + 16 * nt + i16;
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const int abr = 16 * it + q4 + 4 * r;
+                            if (abr < nab && c < ncd) Iblk[abr * ncd + c] += acc[r];      // this lane alone owns the element
+                        }
+                    }
+                }
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                    for (int nt = 0; nt < 4; ++nt) Wacc[mt][nt] = qc_d4{0.0, 0.0, 0.0, 0.0};
+            };
+            const int K_cd = pk.K;
+            int ij = sl.lo / K_cd, kl = sl.lo - ij * K_cd;
+            for (int itq = 0; itq < len; ++itq) {
+                if (ij != cur_ij) {
+                    if (cur_ij >= 0) flush(cur_ij);
+                    cur_ij = ij;
+                }
+                const double4 cb = *reinterpret_cast<const double4 *>(braBase + (size_t)ij * strideB);
+                const double *ket = ketBase + (size_t)kl * strideK;
+                const double4 ck = *reinterpret_cast<const double4 *>(ket);
+                const double p = cb.x, q = ck.x;
+                const double X = cb.y - ck.y, Y = cb.z - ck.z, Z = cb.w - ck.w;
+                const double pref = rsqrt(p + q);
+                const double alpha = p * q * (pref * pref);
+                double F[L + 1];
+                qc_boys<L>(alpha * (X * X + Y * Y + Z * Z), a.boys, F);
+                __syncthreads();                  // previous iteration's readers of Rw are done
+                qc_build_r<L>(Rw, lane, 64, alpha, X, Y, Z, F);
+                const double *Ecd = ket + 4;
+                for (int ks = 0; ks < KS; ++ks) {
+                    const int h2 = 4 * ks + q4;
+                    const bool h2ok = h2 < HCD;
+                    const int t2 = tab[h2ok ? h2 : 0];
+                    const int n2 = t2 & 255, s2 = (t2 >> 8) & 255, v2 = t2 >> 16;
+                    const double sg = h2ok ? ((n2 & 1) ? -pref : pref) : 0.0;      // sign of the ket order, scale, validity
+                    double bv[4];
+#pragma unroll
+                    for (int nt = 0; nt < 4; ++nt) {
+                        const int c = col0 + 16 * nt + i16;
+                        bv[nt] = (h2ok && nt < NT && c < ncd) ? Ecd[(size_t)h2 * ncd + c] : 0.0;
+                    }
+#pragma unroll
+                    for (int mt = 0; mt < MT; ++mt) {
+                        const int N = n1[mt] + n2, ss = s1[mt] + s2;
+                        const double av = (16 * mt + i16 < HAB) ? sg * Rw[N * (N + 1) * (N + 2) / 6 + ss * (ss + 1) / 2 + v1[mt] + v2] : 0.0;
+#pragma unroll
+                        for (int nt = 0; nt < 4; ++nt)
+                            if (nt < NT) Wacc[mt][nt] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv[nt], Wacc[mt][nt], 0, 0, 0);
+                    }
+                }
+                if (++kl == K_cd) { kl = 0; ++ij; }
+            }
+            if (cur_ij >= 0) flush(cur_ij);
+          }
+        } else {
         for (int pass = 0; pass < npass; ++pass) {
             const int col = pass * 64 + li;
             const bool colok = col < ncd;
@@ -385,6 +505,7 @@ __device__ __forceinline__ void qc_fock_body(const QcKernelArgs &a, const QcSlot
             }
             }
             if (cur_ij >= 0) flush(cur_ij);
+        }
         }
         __syncthreads();
 

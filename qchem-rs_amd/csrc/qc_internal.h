@@ -29,6 +29,10 @@ constexpr int QC_NSTREAMS = 7;          // class kernels of one build run concur
 constexpr int QC_NUNITS = 2 * (QC_LPAIR + 1) + 4;   // launch units of one build: (LAB, tier) of the column kernels + 4 bra-major launches
 
 __host__ __device__ constexpr int qc_nherm(int L) { return (L + 1) * (L + 2) * (L + 3) / 6; }
+// Classes whose two Hermite contractions run as f64 MFMA tiles (one slot per wave): high-order kets against bras with
+// enough Hermite functions to fill 16-row tiles.  Measured on H2O/cc-pVTZ and benzene/cc-pVDZ: below these bounds the
+// padded tiles and the lost second slot per wave cost more than the LDS reads they save.
+__host__ __device__ constexpr bool qc_use_mfma(int LAB, int LCD) { return LCD >= 4 && LAB >= 3; }
 __host__ __device__ constexpr int qc_ncart(int L) { return (L + 1) * (L + 2) / 2; }
 // Hermite index of (t,u,v): grouped by total order N = t+u+v, then t descending, then u descending.
 __host__ __device__ constexpr int qc_hidx(int t, int u, int v) {
@@ -175,7 +179,7 @@ void qc_sub_transpose(hipStream_t st, int n, const double *M, double *out);     
 void qc_symmetrize_add(hipStream_t st, int n, const double *Gt, double *G);              // G = Gt + Gt^T
 void qc_reduce_replicas(hipStream_t st, size_t count, int nrep, size_t stride, double *Gt);  // Gt[0] += sum_r>0 Gt[r]
 void qc_count_diff(hipStream_t st, size_t count, const double *a, const double *b, int *flag);
-int qc_lgc_for(int lcd, int ncd);
+int qc_lgc_for(int lab, int lcd, int ncd);
 // owner of the i-th (cost-sorted) quartet of launch class `ci`: boustrophedon deal, start rank rotated per class
 inline int qc_shard_owner(size_t i, int nranks, size_t ci) {
     const size_t round = i / nranks, pos = i % nranks;

@@ -271,7 +271,7 @@ void qc_build_model(qc_system *S) {
             if (dn.L <= 1 && dn.L + dw.L <= QC_LREG) {
                 bucket[(((dw.L * (QC_LPAIR + 1) + dn.L) * 7) + 0) * 2 + 1].push_back(QcTask{wide, narrow});
             } else {
-                bucket[(((dn.L * (QC_LPAIR + 1) + dw.L) * 7) + qc_lgc_for(dw.L, dw.na * dw.nb)) * 2].push_back(QcTask{narrow, wide});
+                bucket[(((dn.L * (QC_LPAIR + 1) + dw.L) * 7) + qc_lgc_for(dn.L, dw.L, dw.na * dw.nb)) * 2].push_back(QcTask{narrow, wide});
             }
         }
     S->classes.clear();
@@ -288,7 +288,8 @@ void qc_build_model(qc_system *S) {
 }
 
 // Lane-group widths the kernels are instantiated for, per ket Hermite order (gen_step2.py emits the same table).
-int qc_lgc_for(int lcd, int ncd) {
+int qc_lgc_for(int lab, int lcd, int ncd) {
+    if (qc_use_mfma(lab, lcd)) return 6;            // matrix-core classes: one slot per wave, always the full wave
     static const int allowed[QC_LPAIR + 1][4] = {{0, -1, -1, -1}, {2, -1, -1, -1}, {3, 4, -1, -1}, {3, 4, 5, -1}, {5, 6, -1, -1}, {6, -1, -1, -1}, {6, -1, -1, -1}};
     for (int i = 0; i < 4 && allowed[lcd][i] >= 0; ++i)
         if ((1 << allowed[lcd][i]) >= ncd) return allowed[lcd][i];
@@ -392,7 +393,7 @@ void qc_build_shards(qc_system *S) {
             const int ncd = k.na * k.nb, nab = b.na * b.nb;
             const int w = qc_region0(b.L + k.L, c.LGC) + nab * ncd + nab + ncd + 2 * (b.na * k.na + b.na * k.nb + b.nb * k.na + b.nb * k.nb) +
                           nab * qc_nherm(b.L);
-            words = std::max(words, w);
+            words = std::max(words, w + (k.L >= 4 ? 48 : 0));   // + the Hermite index table of the MFMA path
         }
         c.slot_words = words;
         c.lds_bytes = words * 8 * (64 >> c.LGC);
