@@ -64,6 +64,10 @@ double qc_nuclear_repulsion(const qc_system *sys);/* compute_nuclear_repulsion, 
 int qc_overlap(const qc_system *sys, double *out);
 int qc_kinetic(const qc_system *sys, double *out);
 int qc_nuclear(const qc_system *sys, double *out);
+/* The same three matrices computed on the GPU (qc_one_electron.hip; what the SCF drivers use): which = 0 overlap,
+ * 1 kinetic, 2 nuclear attraction; out: n*n doubles on the host.  The three entry points above run on the host and need
+ * no device. */
+int qc_one_electron_gpu(qc_system *sys, int which, double *out);
 
 /* ---- two-electron integrals: replaces molint::eri (rhf.rs:45, uhf.rs:55).  GPU.  out = n^4 doubles on the host,
  * row-major (i,j,k,l), chemists' notation (ij|kl) - the index order rhf.rs:60-61 reads.  Plumbing/tests only: the SCF

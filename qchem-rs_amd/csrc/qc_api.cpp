@@ -105,19 +105,21 @@ int device_sorted_eigs(qc_system *S, ScfWork &W, double *dA, double *dV, double 
 int scf_setup(qc_system *S, ScfWork &W, std::vector<double> &h_eht) {
     const int n = S->nbasis;
     const size_t nn = (size_t)n * n;
-    std::vector<double> s(nn), t(nn), v(nn), h(nn);
-    qc_host_one_electron(S, 0, s.data());
-    qc_host_one_electron(S, 1, t.data());
-    qc_host_one_electron(S, 2, v.data());
-    for (size_t k = 0; k < nn; ++k) h[k] = t[k] + v[k];
+    // S, T, V on the device (molint::overlap / kinetic / nuclear, rhf.rs:41-43); H = T + V (rhf.rs:48)
+    hipStream_t st = S->stream;
+    int rc1 = qc_one_electron_device(S, 0, W.S.p);
+    if (rc1 == QC_OK) rc1 = qc_one_electron_device(S, 1, W.t1.p);
+    if (rc1 == QC_OK) rc1 = qc_one_electron_device(S, 2, W.t2.p);
+    if (rc1 != QC_OK) return rc1;
+    qc_axpby(st, n, 1.0, W.t1.p, 1.0, W.t2.p, W.H.p);
+    std::vector<double> s(nn), h(nn);
+    QC_HIP_CHECK(hipMemcpyAsync(s.data(), W.S.p, nn * sizeof(double), hipMemcpyDeviceToHost, st));
+    QC_HIP_CHECK(hipMemcpyAsync(h.data(), W.H.p, nn * sizeof(double), hipMemcpyDeviceToHost, st));
+    QC_HIP_CHECK(hipStreamSynchronize(st));
     h_eht.assign(nn, 0.0);
     for (int i = 0; i < n; ++i)
         for (int j = i; j < n; ++j)
             h_eht[(size_t)i * n + j] = h_eht[(size_t)j * n + i] = 1.75 * s[(size_t)i * n + j] * (h[(size_t)i * n + i] + h[(size_t)j * n + j]) / 2.0;
-    hipStream_t st = S->stream;
-    QC_HIP_CHECK(hipMemcpyAsync(W.S.p, s.data(), nn * sizeof(double), hipMemcpyHostToDevice, st));
-    QC_HIP_CHECK(hipMemcpyAsync(W.H.p, h.data(), nn * sizeof(double), hipMemcpyHostToDevice, st));
-    QC_HIP_CHECK(hipStreamSynchronize(st));
     // X = U (diag((U^T S U)_ii^-1/2) U^T): note the diagonal of the product, not the returned eigenvalues
     int rc = device_sorted_eigs(S, W, W.S.p, W.Cp.p, W.w.p);          // U (column order is immaterial for X)
     if (rc != QC_OK) return rc;
@@ -245,6 +247,19 @@ double qc_nuclear_repulsion(const qc_system *S) {
 int qc_overlap(const qc_system *S, double *out) { if (!S || !out) return QC_ERR_INVALID; qc_host_one_electron(S, 0, out); return QC_OK; }
 int qc_kinetic(const qc_system *S, double *out) { if (!S || !out) return QC_ERR_INVALID; qc_host_one_electron(S, 1, out); return QC_OK; }
 int qc_nuclear(const qc_system *S, double *out) { if (!S || !out) return QC_ERR_INVALID; qc_host_one_electron(S, 2, out); return QC_OK; }
+
+int qc_one_electron_gpu(qc_system *S, int which, double *out) {
+    if (!S || !out) return QC_ERR_INVALID;
+    int rc = qc_device_init(S);
+    if (rc != QC_OK) return rc;
+    const size_t nn = (size_t)S->nbasis * S->nbasis;
+    DevBuf M;
+    if (M.alloc(nn) != QC_OK) return QC_ERR_HIP;
+    if ((rc = qc_one_electron_device(S, which, M.p)) != QC_OK) return rc;
+    QC_HIP_CHECK(hipMemcpyAsync(out, M.p, nn * sizeof(double), hipMemcpyDeviceToHost, S->stream));
+    QC_HIP_CHECK(hipStreamSynchronize(S->stream));
+    return QC_OK;
+}
 
 int qc_set_stream(qc_system *S, void *hip_stream) {
     if (!S) return QC_ERR_INVALID;

@@ -121,10 +121,10 @@ void qc_device_free(qc_system *S) {
         if (c.d_bundles) { (void)hipFree(c.d_bundles); c.d_bundles = nullptr; }
         if (c.d_ketlist) { (void)hipFree(c.d_ketlist); c.d_ketlist = nullptr; }
     }
-    void *ptrs[] = {S->d_pairdata, S->d_pairdataT, S->d_pspack, S->d_pairs, S->d_boys, S->d_D, S->d_G, S->d_Gtmp, S->d_Dj, S->d_flag};
+    void *ptrs[] = {S->d_shells, S->d_pairdata, S->d_pairdataT, S->d_pspack, S->d_pairs, S->d_boys, S->d_D, S->d_G, S->d_Gtmp, S->d_Dj, S->d_flag};
     S->d_flag = nullptr;
     for (void *p : ptrs) if (p) (void)hipFree(p);
-    S->d_pairdata = S->d_pairdataT = S->d_pspack = nullptr; S->d_pairs = nullptr; S->d_boys = S->d_D = S->d_G = S->d_Gtmp = S->d_Dj = nullptr;
+    S->d_shells = nullptr; S->d_pairdata = S->d_pairdataT = S->d_pspack = nullptr; S->d_pairs = nullptr; S->d_boys = S->d_D = S->d_G = S->d_Gtmp = S->d_Dj = nullptr;
     for (int i = 0; i < QC_NSTREAMS; ++i) {
         if (S->side[i]) (void)hipStreamDestroy(S->side[i]);
         if (S->ev_join[i]) (void)hipEventDestroy(S->ev_join[i]);

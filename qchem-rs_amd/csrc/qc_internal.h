@@ -110,6 +110,8 @@ struct qc_system {
     hipStream_t side[QC_NSTREAMS] = {};
     hipEvent_t ev_fork = nullptr, ev_join[QC_NSTREAMS] = {};
     double *d_pairdata = nullptr, *d_pairdataT = nullptr, *d_pspack = nullptr;
+    void *d_shells = nullptr;                // shells / primitives / transforms / nuclei for the one-electron kernels (one blob)
+    size_t shell_blob_off[5] = {};
     QcPairDesc *d_pairs = nullptr;
     double *d_boys = nullptr;
     double *d_D = nullptr, *d_G = nullptr;   // 2 * n*n each (alpha/beta or Dj/Dk)
@@ -156,6 +158,7 @@ struct QcFockArgs {
     size_t rep_stride;    // doubles between replicas
 };
 int qc_launch_eri_full(qc_system *S, double *d_out);
+int qc_one_electron_device(qc_system *S, int which /* 0 S, 1 T, 2 V */, double *d_out);
 void qc_drop_graphs(qc_system *S);
 int qc_launch_fock_classes(qc_system *S, const QcFockArgs &a, float *class_ms /*nullable*/, float *unit_ms = nullptr /*nullable, 14*/);
 int qc_fock_build_device(qc_system *S, const double *dDa, const double *dDb, double *dGa, double *dGb, bool uhf, int *twin_cache = nullptr);

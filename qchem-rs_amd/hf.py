@@ -37,7 +37,7 @@ _ERR = {-1: "invalid argument", -2: "no gfx950 device visible (there is no CPU f
         -4: "RCCL error", -5: "unsupported (angular momentum > f, or n too large for the in-LDS eigensolver)"}
 
 EXPORTS = ["qc_system_create", "qc_system_destroy", "qc_nbasis", "qc_nelectrons", "qc_nshells", "qc_nquartets",
-           "qc_nuclear_repulsion", "qc_overlap", "qc_kinetic", "qc_nuclear", "qc_eri_full", "qc_fock_rhf", "qc_fock_uhf",
+           "qc_nuclear_repulsion", "qc_overlap", "qc_kinetic", "qc_nuclear", "qc_one_electron_gpu", "qc_eri_full", "qc_fock_rhf", "qc_fock_uhf",
            "qc_fock_rhf_device", "qc_fock_uhf_device", "qc_sym_eig", "qc_scf_rhf", "qc_scf_uhf", "qc_comm_unique_id",
            "qc_comm_init", "qc_set_shard", "qc_plan_shard", "qc_set_stream", "qc_device_ready", "qc_work_stats_get",
            "qc_fock_profile", "qc_plan_shard_quartets", "qc_scf_begin_rhf", "qc_scf_begin_uhf", "qc_scf_iterate",
@@ -96,6 +96,7 @@ def lib():
         L.qc_nuclear_repulsion.argtypes = [vp]; L.qc_nuclear_repulsion.restype = C.c_double
         for f in ("qc_overlap", "qc_kinetic", "qc_nuclear", "qc_eri_full"):
             getattr(L, f).argtypes = [vp, _dp]
+        L.qc_one_electron_gpu.argtypes = [vp, C.c_int, _dp]
         L.qc_fock_rhf.argtypes = [vp, _dp, _dp]
         L.qc_fock_uhf.argtypes = [vp, _dp, _dp, _dp, _dp]
         L.qc_fock_rhf_device.argtypes = [vp, vp, vp]
@@ -171,6 +172,12 @@ class System:
     def overlap(self): return self._mat("qc_overlap")
     def kinetic(self): return self._mat("qc_kinetic")
     def nuclear(self): return self._mat("qc_nuclear")
+
+    def one_electron_gpu(self, which: int):
+        """S (0), T (1) or V (2) computed by the GPU kernels the SCF drivers use (qc_one_electron.hip)."""
+        M = np.zeros((self.n, self.n))
+        _check(lib().qc_one_electron_gpu(self._h, which, M.reshape(-1)), "qc_one_electron_gpu")
+        return M
 
     def eri(self):
         I = np.zeros((self.n,) * 4); _check(lib().qc_eri_full(self._h, I.reshape(-1)), "qc_eri_full"); return I

@@ -86,6 +86,17 @@ def test_fock_uhf_matches_dense_contraction(mol, basis):
     assert np.abs(Gb - Gb_ref).max() < TOL_INT * scale
 
 
+@pytest.mark.parametrize("mol,basis", [("hydrogen", "STO-3G"), ("water", "6-31G_st_st"), ("water", "cc-pVTZ"), ("oxygen", "cc-pVDZ")])
+def test_one_electron_matrices_on_the_gpu(mol, basis):
+    """S, T, V from qc_one_electron.hip (what the SCF drivers use) == the oracle's molint::overlap/kinetic/nuclear
+    restatement (rhf.rs:41-43), s to f shells, Cartesian and pure."""
+    q, s, o = _sys(mol, basis)
+    for which, ref in ((0, o.overlap()), (1, o.kinetic()), (2, o.nuclear())):
+        M = s.one_electron_gpu(which)
+        assert np.abs(M - ref).max() < 1e-11 * max(1.0, np.abs(ref).max())
+        assert np.abs(M - M.T).max() == 0.0
+
+
 def test_fock_without_the_lds_row_buffer(monkeypatch):
     """The bra-major kernels' large-n fallback (exchange contributions as global atomics per bundle, no LDS row buffer)
     gives the same G for both spins' code paths."""
