@@ -129,6 +129,10 @@ int qc_scf_begin_uhf(qc_system *sys, int n_alpha, int n_beta, qc_scf_state **out
 int qc_scf_iterate(qc_scf_state *st, double *electronic_energy, double *density_rms);
 int qc_scf_orbital_energies(qc_scf_state *st, int spin, double *out_n);
 int qc_scf_density(qc_scf_state *st, int spin, double *out_nxn);
+/* <S^2> of the current UHF determinant: Sz (Sz + 1) + N_beta - tr(D_alpha S D_beta S), Sz = (N_alpha - N_beta) / 2.
+ * The reference leaves open shells as a TODO (uhf.rs:42, main.rs:111); this is the diagnostic that goes with the
+ * n_alpha / n_beta extension.  RHF states return 0. */
+int qc_scf_spin_square(qc_scf_state *st, double *s2);
 int qc_scf_timings(qc_scf_state *st, double *ms_setup, double *ms_fock, double *ms_linalg);
 void qc_scf_end(qc_scf_state *st);
 

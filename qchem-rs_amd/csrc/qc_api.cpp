@@ -647,6 +647,29 @@ int qc_scf_density(qc_scf_state *st, int spin, double *out) {
     QC_HIP_CHECK(hipMemcpy(out, st->D[spin].p, nn * sizeof(double), hipMemcpyDeviceToHost));
     return QC_OK;
 }
+int qc_scf_spin_square(qc_scf_state *st, double *s2) {
+    if (!st || !s2) return QC_ERR_INVALID;
+    *s2 = 0.0;
+    if (!st->uhf) return QC_OK;
+    qc_system *S = st->S;
+    ScfWork &W = st->W;
+    const int n = S->nbasis;
+    hipStream_t sm = S->stream;
+    qc_gemm(sm, n, n, n, 1.0, st->D[0].p, n, false, W.S.p, n, false, 0.0, W.t1.p, n);      // D_alpha S
+    qc_gemm(sm, n, n, n, 1.0, st->D[1].p, n, false, W.S.p, n, false, 0.0, W.t2.p, n);      // D_beta S
+    // tr(A B) = sum_ij A_ij B_ji: one dot product of A with B^T - reuse the DIIS dot kernel on (A, B^T)
+    qc_sub_transpose(sm, n, W.t2.p, W.t3.p);                                                // t3 = B - B^T
+    qc_axpby(sm, n, 1.0, W.t2.p, -1.0, W.t3.p, W.t4.p);                                    // t4 = B^T
+    const double *ys[1] = {W.t4.p};
+    qc_dots(sm, n, W.t1.p, ys, 1, W.scal.p);
+    double tr = 0.0;
+    QC_HIP_CHECK(hipMemcpyAsync(&tr, W.scal.p, sizeof(double), hipMemcpyDeviceToHost, sm));
+    QC_HIP_CHECK(hipStreamSynchronize(sm));
+    const double sz = 0.5 * (st->nocc[0] - st->nocc[1]);
+    *s2 = sz * (sz + 1.0) + st->nocc[1] - tr;
+    return QC_OK;
+}
+
 int qc_set_fock_mode(qc_system *S, int mode) {
     if (!S || (mode != 0 && mode != 1)) return QC_ERR_INVALID;
     S->fock_mode = mode;

@@ -41,7 +41,7 @@ EXPORTS = ["qc_system_create", "qc_system_destroy", "qc_nbasis", "qc_nelectrons"
            "qc_fock_rhf_device", "qc_fock_uhf_device", "qc_sym_eig", "qc_scf_rhf", "qc_scf_uhf", "qc_comm_unique_id",
            "qc_comm_init", "qc_set_shard", "qc_plan_shard", "qc_set_stream", "qc_device_ready", "qc_work_stats_get",
            "qc_fock_profile", "qc_plan_shard_quartets", "qc_scf_begin_rhf", "qc_scf_begin_uhf", "qc_scf_iterate",
-           "qc_scf_orbital_energies", "qc_scf_density", "qc_scf_timings", "qc_scf_end", "qc_fock_profile_tiers", "qc_sym_eig_warm", "qc_set_fock_mode", "qc_scf_tensor_ms"]
+           "qc_scf_orbital_energies", "qc_scf_density", "qc_scf_spin_square", "qc_scf_timings", "qc_scf_end", "qc_fock_profile_tiers", "qc_sym_eig_warm", "qc_set_fock_mode", "qc_scf_tensor_ms"]
 
 
 class QcError(RuntimeError):
@@ -122,6 +122,7 @@ def lib():
         L.qc_scf_iterate.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_double)]
         L.qc_scf_orbital_energies.argtypes = [vp, C.c_int, _dp]
         L.qc_scf_density.argtypes = [vp, C.c_int, _dp]
+        L.qc_scf_spin_square.argtypes = [vp, C.POINTER(C.c_double)]
         L.qc_scf_timings.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double)]
         L.qc_scf_end.argtypes = [vp]; L.qc_scf_end.restype = None
         _lib = L
@@ -285,6 +286,10 @@ class ScfStepper:
 
     def density(self, spin=0):
         D = np.zeros((self.system.n, self.system.n)); _check(lib().qc_scf_density(self._st, spin, D), "qc_scf_density"); return D
+
+    def spin_square(self) -> float:
+        """<S^2> of the current UHF determinant (0 for RHF)."""
+        v = C.c_double(); _check(lib().qc_scf_spin_square(self._st, C.byref(v)), "qc_scf_spin_square"); return v.value
 
     def tensor_ms(self):
         return lib().qc_scf_tensor_ms(self._st)

@@ -97,6 +97,21 @@ def test_one_electron_matrices_on_the_gpu(mol, basis):
         assert np.abs(M - M.T).max() == 0.0
 
 
+def test_uhf_spin_square_of_triplet_oxygen():
+    """<S^2> from the library == Sz(Sz+1) + N_beta - tr(D_a S D_b S) evaluated with numpy on its densities and the oracle's
+    overlap; a triplet UHF determinant is slightly contaminated: a little above 2."""
+    q, s, o = _sys("oxygen", "cc-pVDZ")
+    st = q.ScfStepper(s, uhf=True, n_alpha=9, n_beta=7)
+    for _ in range(25):
+        st.iterate()
+    Da, Db, S = st.density(0), st.density(1), o.overlap()
+    ref = 1.0 * 2.0 + 7 - np.trace(Da @ S @ Db @ S)
+    s2 = st.spin_square()
+    st.close()
+    assert abs(s2 - ref) < 1e-10
+    assert 2.0 < s2 < 2.1
+
+
 def test_fock_without_the_lds_row_buffer(monkeypatch):
     """The bra-major kernels' large-n fallback (exchange contributions as global atomics per bundle, no LDS row buffer)
     gives the same G for both spins' code paths."""
