@@ -391,9 +391,11 @@ void qc_build_shards(qc_system *S) {
                            2.0 * ca * cb * cc * cd * hcd + 12.0 * na * nb * nc * nd;
             // LDS doubles one lane group needs for this quartet (layout in qc_fock_kernel.h)
             const int ncd = k.na * k.nb, nab = b.na * b.nb;
+            // (the matrix-core classes read the bra block straight from memory: a 48-double Hermite index table instead of
+            // the staged [ab][h] block)
             const int w = qc_region0(b.L + k.L, c.LGC) + nab * ncd + nab + ncd + 2 * (b.na * k.na + b.na * k.nb + b.nb * k.na + b.nb * k.nb) +
-                          nab * qc_nherm(b.L);
-            words = std::max(words, w + (k.L >= 4 ? 48 : 0));   // + the Hermite index table of the MFMA path
+                          (qc_use_mfma(c.LAB, c.LCD) ? 48 : nab * qc_nherm(b.L));
+            words = std::max(words, w);
         }
         c.slot_words = words;
         c.lds_bytes = words * 8 * (64 >> c.LGC);

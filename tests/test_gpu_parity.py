@@ -97,6 +97,33 @@ def test_one_electron_matrices_on_the_gpu(mol, basis):
         assert np.abs(M - M.T).max() == 0.0
 
 
+def test_cartesian_f_shells_fock_matches_dense_contraction(tmp_path):
+    """cc-pVTZ with every d and f shell switched to Cartesian functions (6 and 10 per shell) on O2: the (ff|ff) quartets then
+    have 100 x 100 function pairs - more columns than a wave has lanes (several column passes) and more rows than four
+    16-row MFMA tiles - paths no shipped basis reaches."""
+    import json
+    import qchem_rs_amd as q
+    from oracle.oracle import Oracle
+    from conftest import data
+    b = json.load(open(data("basis", "cc-pVTZ.json")))
+    for el in b["elements"].values():
+        for sh in el["electron_shells"]:
+            if sh["angular_momentum"][0] >= 2:
+                sh["function_type"] = "gto_cartesian"
+    f = tmp_path / "cc-pVTZ-cart.json"
+    f.write_text(json.dumps(b))
+    m = q.MolecularSystem.load(data("mol", "oxygen.json"), q.BasisSet.load(str(f)))
+    s, o = q.System(m), Oracle(m)
+    assert s.n == 2 * (4 + 3 * 3 + 2 * 6 + 10)
+    I = o.eri()
+    D = _rand_sym(s.n, 21)
+    G_ref = o.g_rhf(D, I)
+    G = s.fock_rhf(D)
+    assert np.abs(G - G_ref).max() < TOL_INT * max(1.0, np.abs(G_ref).max())
+    for which, ref in ((0, o.overlap()), (1, o.kinetic()), (2, o.nuclear())):
+        assert np.abs(s.one_electron_gpu(which) - ref).max() < 1e-11 * max(1.0, np.abs(ref).max())
+
+
 def test_uhf_spin_square_of_triplet_oxygen():
     """<S^2> from the library == Sz(Sz+1) + N_beta - tr(D_a S D_b S) evaluated with numpy on its densities and the oracle's
     overlap; a triplet UHF determinant is slightly contaminated: a little above 2."""
