@@ -206,6 +206,9 @@ def main():
             line["scaling_reference"] = {"workload": WORKLOADS["c6h6_ccpvdz"][2] + " direct-SCF iteration", "n_gpus": 1,
                                          "value": s2.n_quartets() * k2 / dt2, "ms_per_step": dt2 * 1e3 / k2, "steps": k2,
                                          "fock_build_ms": tm2["fock"], "unique_quartets": int(s2.n_quartets())}
+            if not args.no_cpu_baseline:      # the oracle on a bounded sample of the same 1.1 M quartets (~10 s of one host core)
+                line["scaling_reference"]["cpu_baseline"] = cpu_baseline(m2, budget_s=10.0)
+            s2.close()
         if key in ("h2o_ccpvtz", "h2o_sto3g", "c6h6_ccpvdz"):
             # the reference's own (conventional) algorithm on the same GPU: tensor resident in HBM, one streaming GEMV per pass
             s3 = q.System(mol); s3.set_fock_mode("stored")
