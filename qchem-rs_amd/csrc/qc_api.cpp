@@ -587,7 +587,7 @@ static int scf_iterate(qc_scf_state *st, double *energy, double *rms_out) {
         e_sum += W.h_scal[2 * s]; rms_sum += rms_s;
         // the refinement is perturbative: on its own once the density has nearly stopped moving, behind two Jacobi sweeps
         // while it still moves, not at all in the first wild passes
-        W.mode[s] = rms_s >= 5.0 ? 2 : (rms_s >= 1e-3 || redo) ? 1 : 0;
+        W.mode[s] = rms_s >= 1.0 ? 2 : (rms_s >= 1e-3 || redo) ? 1 : 0;
         std::swap(st->D[s].p, st->Dn[s].p);                              // D += 1.0 * dD
         std::swap(W.CpPrev[s].p, W.CpNew[s].p);
         W.have_prev[s] = true;
