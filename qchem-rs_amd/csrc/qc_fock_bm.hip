@@ -96,7 +96,7 @@ __device__ __forceinline__ void qc_step2_ps(double (&W)[3][qc_nherm(LAB)], const
 template <int LAB, int LCD, int NIJ>
 __device__ __forceinline__ void qc_bm_pass(const double *__restrict__ pd, const double *__restrict__ pdT, const double *__restrict__ Tb,
                                            const int bdoff, const int strideB, const int ij, const int nab, const double *__restrict__ ketBase,
-                                           const int klo, const int klen, const int maxK, double *const I) {
+                                           const int K_cd, const int Kc1, const int maxK, double *const I) {
     constexpr int L = LAB + LCD, HAB = qc_nherm(LAB), NC = (LCD == 0) ? 1 : 3;
     constexpr int strideK = (LCD == 0) ? qc_pair_stride(0, 1) : 8;
     constexpr int LS = 65;
@@ -115,19 +115,16 @@ __device__ __forceinline__ void qc_bm_pass(const double *__restrict__ pd, const 
             for (int h = 0; h < HAB; ++h) W[u][c][h] = 0.0;
     // the next ket primitive's record is requested one iteration ahead.  ss kets: pair-data block [q, Q | E]; ps kets:
     // packed record [q, Q | e0x, e0y, e0z, e1] (ketBase points into pspack, stride 8)
-    // this lane's ket primitives: klo .. klo + klen - 1 (klen = 0: idle, it keeps reading primitive klo)
-    const int klast = max(klen - 1, 0);
-    const double *__restrict__ kb0 = ketBase + (size_t)klo * strideK;
-    double4 hk = *reinterpret_cast<const double4 *>(kb0);
-    double4 ekn4 = (LCD == 1) ? *reinterpret_cast<const double4 *>(kb0 + 4) : double4{0.0, 0.0, 0.0, 0.0};
-    double ekn = (LCD == 0) ? kb0[4] : 0.0;
+    double4 hk = *reinterpret_cast<const double4 *>(ketBase);
+    double4 ekn4 = (LCD == 1) ? *reinterpret_cast<const double4 *>(ketBase + 4) : double4{0.0, 0.0, 0.0, 0.0};
+    double ekn = (LCD == 0) ? ketBase[4] : 0.0;
     for (int kl = 0; kl < maxK; ++kl) {
-        const bool valid = kl < klen;
+        const bool valid = kl < K_cd;
         const double4 ck = hk;
         const double ek = ekn;
         const double4 ek4 = ekn4;
         {
-            const double *__restrict__ kbn = kb0 + (size_t)min(kl + 1, klast) * strideK;
+            const double *__restrict__ kbn = ketBase + (size_t)min(kl + 1, Kc1) * strideK;
             hk = *reinterpret_cast<const double4 *>(kbn);
             if constexpr (LCD == 0) ekn = kbn[4];
             else ekn4 = *reinterpret_cast<const double4 *>(kbn + 4);
@@ -199,11 +196,7 @@ __device__ __forceinline__ void qc_bm_body(const QcKernelArgs &a, const double *
     const bool active = lane < nket;
     const int ket = ketlist[first + (active ? lane : 0)];
     const QcPairDesc pk = a.pairs[ket];
-    const int kpart = __builtin_amdgcn_readfirstlane(bd.kpart), nkp = __builtin_amdgcn_readfirstlane(bd.nkparts);
-    const int K_cd = active ? pk.K : 0;
-    int klo = (int)((long long)K_cd * kpart / nkp);
-    const int klen = (int)((long long)K_cd * (kpart + 1) / nkp) - klo;
-    if (klen == 0) klo = 0;                                   // stay inside the ket's block
+    const int K_cd = active ? pk.K : 0, Kc1 = max(K_cd - 1, 0);
     const double *__restrict__ ketBase = (LCD == 0) ? pd + pk.doff : pspack + pk.psoff;
     double *const I = Iw + lane;                              // I[x * LS], x = ab * NC + col
 
@@ -211,8 +204,8 @@ __device__ __forceinline__ void qc_bm_body(const QcKernelArgs &a, const double *
 
     int ij = ij_lo;
     if constexpr (PAIRED)
-        for (; ij + 1 < ij_hi; ij += 2) qc_bm_pass<LAB, LCD, 2>(pd, pdT, Tb, bdoff, strideB, ij, nab, ketBase, klo, klen, maxK, I);
-    for (; ij < ij_hi; ++ij) qc_bm_pass<LAB, LCD, 1>(pd, pdT, Tb, bdoff, strideB, ij, nab, ketBase, klo, klen, maxK, I);
+        for (; ij + 1 < ij_hi; ij += 2) qc_bm_pass<LAB, LCD, 2>(pd, pdT, Tb, bdoff, strideB, ij, nab, ketBase, K_cd, Kc1, maxK, I);
+    for (; ij < ij_hi; ++ij) qc_bm_pass<LAB, LCD, 1>(pd, pdT, Tb, bdoff, strideB, ij, nab, ketBase, K_cd, Kc1, maxK, I);
 
     const int nd = pk.nb;                                     // (nc, nd) = (1,1), (3,1) or (1,3)
     const int c0 = pk.offa, d0 = pk.offb;

@@ -65,9 +65,8 @@ struct QcPairDesc {
 struct QcTask { int bra, ket; };  // pair indices; (bra|ket) is one unique shell quartet
 struct QcSlot { int bra, ket, lo, hi; };  // a quartet restricted to primitive quartets [lo, hi): the kernels' work unit
 // Work unit of the bra-major kernels (narrow kets, qc_fock_bm.hip): one wave = one bra pair restricted to the bra
-// primitive pairs [ij_lo, ij_hi), against up to 64 ket pairs (one per lane) ketlist[first .. first + nket); of every ket the
-// part `kpart` of `nkparts` equal parts of its primitive pairs (maxK = the longest such part: the wave's trip count).
-struct QcBundle { int bra, ij_lo, ij_hi, first, nket, maxK, kpart, nkparts; };
+// primitive pairs [ij_lo, ij_hi), against up to 64 ket pairs (one per lane) ketlist[first .. first + nket).
+struct QcBundle { int bra, ij_lo, ij_hi, first, nket, maxK, pad0, pad1; };
 
 struct QcClass {
     int LAB, LCD, LGC;            // Hermite orders of bra / ket pairs; log2 of the lane-group width C

@@ -322,30 +322,17 @@ void qc_make_bundles(const qc_system *S, const std::vector<QcTask> &tasks, int i
         if (x.bra != y.bra) return x.bra < y.bra;
         return S->pairs[x.ket].K > S->pairs[y.ket].K;
     });
-    // Cut along the bra primitive pairs.  If that leaves the class with few waves (small molecules: a handful of bundles,
-    // each a long serial loop over 64 ket primitives), cut along the kets' own primitives as well; every part digests its
-    // own partial block, so large classes - where there are waves enough - are not cut this way.
-    for (int split_kets = 0; split_kets < 2; ++split_kets) {
-        bundles.clear(); ketlist.clear();
-        for (size_t i = 0; i < t.size();) {
-            size_t j = i;
-            while (j < t.size() && t[j].bra == t[i].bra && j - i < 64) ++j;
-            const int Kab = S->pairs[t[i].bra].K, maxK = S->pairs[t[i].ket].K;
-            const int first = (int)ketlist.size();
-            for (size_t k = i; k < j; ++k) ketlist.push_back(t[k].ket);
-            int nparts = 1, nk = 1;
-            if (itmax > 0) {
-                const int64_t want = std::max<int64_t>(1, ((int64_t)Kab * maxK + itmax - 1) / itmax);
-                nparts = (int)std::min<int64_t>(Kab, want);
-                if (split_kets) nk = (int)std::min<int64_t>(std::min<int64_t>(8, maxK), (want + nparts - 1) / nparts);
-            }
-            for (int s = 0; s < nparts; ++s)
-                for (int kp = 0; kp < nk; ++kp)
-                    bundles.push_back(QcBundle{t[i].bra, (int)((int64_t)Kab * s / nparts), (int)((int64_t)Kab * (s + 1) / nparts), first, (int)(j - i),
-                                               (maxK + nk - 1) / nk, kp, nk});
-            i = j;
-        }
-        if (itmax <= 0 || bundles.size() >= 512) break;
+    for (size_t i = 0; i < t.size();) {
+        size_t j = i;
+        while (j < t.size() && t[j].bra == t[i].bra && j - i < 64) ++j;
+        const int Kab = S->pairs[t[i].bra].K, maxK = S->pairs[t[i].ket].K;
+        const int first = (int)ketlist.size();
+        for (size_t k = i; k < j; ++k) ketlist.push_back(t[k].ket);
+        int nparts = 1;
+        if (itmax > 0) nparts = std::min<int64_t>(Kab, std::max<int64_t>(1, ((int64_t)Kab * maxK + itmax - 1) / itmax));
+        for (int s = 0; s < nparts; ++s)
+            bundles.push_back(QcBundle{t[i].bra, (int)((int64_t)Kab * s / nparts), (int)((int64_t)Kab * (s + 1) / nparts), first, (int)(j - i), maxK, 0, 0});
+        i = j;
     }
     // long bundles first: the tail of the launch is made of short ones
     std::stable_sort(bundles.begin(), bundles.end(), [](const QcBundle &x, const QcBundle &y) {
