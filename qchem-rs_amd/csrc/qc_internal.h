@@ -32,7 +32,7 @@ __host__ __device__ constexpr int qc_nherm(int L) { return (L + 1) * (L + 2) * (
 // Classes whose two Hermite contractions run as f64 MFMA tiles (one slot per wave): high-order kets against bras with
 // enough Hermite functions to fill 16-row tiles.  Measured on H2O/cc-pVTZ and benzene/cc-pVDZ: below these bounds the
 // padded tiles and the lost second slot per wave cost more than the LDS reads they save.
-__host__ __device__ constexpr bool qc_use_mfma(int LAB, int LCD) { return LCD >= 4 && LAB >= 3; }
+__host__ __device__ constexpr bool qc_use_mfma(int LAB, int LCD) { return LCD >= 5 && LAB >= 3; }
 __host__ __device__ constexpr int qc_ncart(int L) { return (L + 1) * (L + 2) / 2; }
 // Hermite index of (t,u,v): grouped by total order N = t+u+v, then t descending, then u descending.
 __host__ __device__ constexpr int qc_hidx(int t, int u, int v) {
