@@ -21,6 +21,7 @@
 //     J/K block updates are reduced over LDS and flushed with global_atomic_add_f64 into one of `nrep` replicas.
 #pragma once
 #include "qc_internal.h"
+#include <utility>
 
 struct QcKernelArgs {
     const QcPairDesc *pairs;
@@ -97,6 +98,74 @@ __device__ __forceinline__ void qc_step2_rolled(double (&W)[qc_nherm(LAB)], cons
             }
         }
     }
+}
+
+
+// Step 2 with the R table spread over the registers of each 16-lane row (groups of 16, 32 or 64 lanes: LGC >= 4).
+// Lane l keeps R[16 k + (l & 15)] in Rd[k]; `v_fmac_f64_dpp ... row_newbcast:j` multiplies lane j's copy into every
+// lane of the row at the full FP64 rate, so an FMA costs no LDS read at all (the rolled form above pays one
+// 512-byte ds_read per FMA, and the four SIMDs of a CU share one 128 B/clk LDS port).  Fully unrolled: the R index
+// of every (h1, h2) is a compile-time constant; the ket coefficients e[h2] arrive in batches, one batch ahead.
+template <int K>
+__device__ __forceinline__ void qc_fmac_bc(double &acc, double r, double e) {
+    asm("v_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(r), "v"(e), "n"(K));
+}
+template <int H1, int H2>
+__host__ __device__ constexpr int qc_ridx() {
+    constexpr QcTuvTable T = qc_make_tuv();
+    return qc_hidx(T.t[H1] + T.t[H2], T.u[H1] + T.u[H2], T.v[H1] + T.v[H2]);
+}
+template <int H>
+__host__ __device__ constexpr int qc_order_of() {
+    constexpr QcTuvTable T = qc_make_tuv();
+    return T.t[H] + T.u[H] + T.v[H];
+}
+template <int LAB, int NR, int H2, int... H1>
+__device__ __forceinline__ void qc_step2_dpp_row(double (&W)[qc_nherm(LAB)], const double (&Rd)[NR], double e,
+                                                 std::integer_sequence<int, H1...>) {
+    (qc_fmac_bc<(qc_ridx<H1, H2>() & 15)>(W[H1], Rd[qc_ridx<H1, H2>() >> 4], e), ...);
+}
+// floor(x / d) for 0 <= x < 2^16, d <= 128 from inv = 1 / d (1 ulp): three instructions instead of the ~35 of a u32 division
+__device__ __forceinline__ int qc_fdiv(int x, float inv) { return (int)(((float)x + 0.5f) * inv); }
+// acc[j] += sum_h E_j[h] W[h] for four rows at once; row j's coefficients sit in the lanes of each 16-lane row (Er[j][h >> 4], lane h & 15)
+template <int HAB, int NRE, int... H>
+__device__ __forceinline__ void qc_dot4_bc(double (&acc)[4], const double (&Er)[4][NRE], const double (&W)[HAB], std::integer_sequence<int, H...>) {
+    ((qc_fmac_bc<(H & 15)>(acc[0], Er[0][H >> 4], W[H]), qc_fmac_bc<(H & 15)>(acc[1], Er[1][H >> 4], W[H]),
+      qc_fmac_bc<(H & 15)>(acc[2], Er[2][H >> 4], W[H]), qc_fmac_bc<(H & 15)>(acc[3], Er[3][H >> 4], W[H])), ...);
+}
+constexpr int QC_DPP_BATCH = 8;
+template <int LAB, int NR, int H0, int... J>
+__device__ __forceinline__ void qc_step2_dpp_batch(double (&W)[qc_nherm(LAB)], const double (&Rd)[NR], const double (&e)[QC_DPP_BATCH],
+                                                   double sc, std::integer_sequence<int, J...>) {
+    (qc_step2_dpp_row<LAB, NR, H0 + J>(W, Rd, e[J] * ((qc_order_of<H0 + J>() & 1) ? -sc : sc),
+                                       std::make_integer_sequence<int, qc_nherm(LAB)>{}), ...);
+}
+template <int LAB, int LCD, int NR, int H0>
+__device__ __forceinline__ void qc_step2_dpp_from(double (&W)[qc_nherm(LAB)], const double (&Rd)[NR], const double (&e)[QC_DPP_BATCH],
+                                                  const double *__restrict__ Ecd, int ncd, double sc) {
+    constexpr int HCD = qc_nherm(LCD), NB = (HCD - H0 < QC_DPP_BATCH) ? HCD - H0 : QC_DPP_BATCH;
+    if constexpr (H0 + NB < HCD) {
+        double en[QC_DPP_BATCH];
+#pragma unroll
+        for (int j = 0; j < QC_DPP_BATCH; ++j) en[j] = (H0 + NB + j < HCD) ? Ecd[(size_t)(H0 + NB + j) * ncd] : 0.0;
+        __builtin_amdgcn_sched_barrier(0);          // the next batch is requested before this one's FMAs
+        qc_step2_dpp_batch<LAB, NR, H0>(W, Rd, e, sc, std::make_integer_sequence<int, NB>{});
+        qc_step2_dpp_from<LAB, LCD, NR, H0 + NB>(W, Rd, en, Ecd, ncd, sc);
+    } else {
+        qc_step2_dpp_batch<LAB, NR, H0>(W, Rd, e, sc, std::make_integer_sequence<int, NB>{});
+    }
+}
+template <int LAB, int LCD>
+__device__ __forceinline__ void qc_step2_dpp(double (&W)[qc_nherm(LAB)], const double *__restrict__ Ecd, int ncd, double sc,
+                                             const double *__restrict__ Rw, int lane) {
+    constexpr int HR = qc_nherm(LAB + LCD), NR = (HR + 15) / 16, HCD = qc_nherm(LCD);
+    double e[QC_DPP_BATCH];
+#pragma unroll
+    for (int j = 0; j < QC_DPP_BATCH; ++j) e[j] = (j < HCD) ? Ecd[(size_t)j * ncd] : 0.0;
+    double Rd[NR];
+#pragma unroll
+    for (int k = 0; k < NR; ++k) Rd[k] = Rw[min(16 * k + (lane & 15), HR - 1)];
+    qc_step2_dpp_from<LAB, LCD, NR, 0>(W, Rd, e, Ecd, ncd, sc);
 }
 
 
@@ -210,7 +279,8 @@ __device__ __forceinline__ void qc_fock_body(const QcKernelArgs &a, const QcSlot
     const double *__restrict__ pd = a.pairdata;
     const int n = a.n;
     const bool uhf = a.Dk1 != nullptr;
-    constexpr bool HOIST = (L <= QC_LHOIST) && (LGC > 0);
+    constexpr bool HOIST = qc_hoisted(L, LGC);
+    constexpr int CH = qc_hoist_chunk(L, LGC);            // primitive quartets per chunk of the hoisted path
     constexpr int NHP = qc_nherm(L) | 1;                    // padded table length of the hoisted path
     double *const Rw = lds + (size_t)g * slot_words;       // this group's private LDS region
     double *const Iblk = Rw + qc_region0(L, LGC);
@@ -235,6 +305,7 @@ __device__ __forceinline__ void qc_fock_body(const QcKernelArgs &a, const QcSlot
         const QcPairDesc pb = a.pairs[sl.bra], pk = a.pairs[sl.ket];
         const int na = pb.na, nb = pb.nb, nc = pk.na, nd = pk.nb;
         const int nab = na * nb, ncd = nc * nd;
+        const float inb = __builtin_amdgcn_rcpf((float)nb), inc = __builtin_amdgcn_rcpf((float)nc), ind = __builtin_amdgcn_rcpf((float)nd);
         double *tDj_ab = Iblk + nab * ncd, *tDj_cd = tDj_ab + nab;
         double *tK = tDj_cd + ncd;   // per spin: Dk_ac, Dk_ad, Dk_bc, Dk_bd
         const int ktile = na * nc + na * nd + nb * nc + nb * nd;
@@ -243,15 +314,15 @@ __device__ __forceinline__ void qc_fock_body(const QcKernelArgs &a, const QcSlot
         if (active) {
             for (int i = li; i < nab * ncd; i += C) Iblk[i] = 0.0;
             if (a.eri_out == nullptr) {   // stage the density tiles this quartet touches
-                for (int i = li; i < nab; i += C) tDj_ab[i] = a.Dj[(size_t)(pb.offa + i / nb) * n + pb.offb + i % nb];
-                for (int i = li; i < ncd; i += C) tDj_cd[i] = a.Dj[(size_t)(pk.offa + i / nd) * n + pk.offb + i % nd];
+                for (int i = li; i < nab; i += C) { const int r = qc_fdiv(i, inb); tDj_ab[i] = a.Dj[(size_t)(pb.offa + r) * n + pb.offb + i - r * nb]; }
+                for (int i = li; i < ncd; i += C) { const int r = qc_fdiv(i, ind); tDj_cd[i] = a.Dj[(size_t)(pk.offa + r) * n + pk.offb + i - r * nd]; }
                 for (int s = 0; s < (uhf ? 2 : 1); ++s) {
                     const double *Dk = s ? a.Dk1 : a.Dk0;
                     double *t0 = tK + s * ktile, *t1 = t0 + na * nc, *t2 = t1 + na * nd, *t3 = t2 + nb * nc;
-                    for (int i = li; i < na * nc; i += C) t0[i] = Dk[(size_t)(pb.offa + i / nc) * n + pk.offa + i % nc];
-                    for (int i = li; i < na * nd; i += C) t1[i] = Dk[(size_t)(pb.offa + i / nd) * n + pk.offb + i % nd];
-                    for (int i = li; i < nb * nc; i += C) t2[i] = Dk[(size_t)(pb.offb + i / nc) * n + pk.offa + i % nc];
-                    for (int i = li; i < nb * nd; i += C) t3[i] = Dk[(size_t)(pb.offb + i / nd) * n + pk.offb + i % nd];
+                    for (int i = li; i < na * nc; i += C) { const int r = qc_fdiv(i, inc); t0[i] = Dk[(size_t)(pb.offa + r) * n + pk.offa + i - r * nc]; }
+                    for (int i = li; i < na * nd; i += C) { const int r = qc_fdiv(i, ind); t1[i] = Dk[(size_t)(pb.offa + r) * n + pk.offb + i - r * nd]; }
+                    for (int i = li; i < nb * nc; i += C) { const int r = qc_fdiv(i, inc); t2[i] = Dk[(size_t)(pb.offb + r) * n + pk.offa + i - r * nc]; }
+                    for (int i = li; i < nb * nd; i += C) { const int r = qc_fdiv(i, ind); t3[i] = Dk[(size_t)(pb.offb + r) * n + pk.offb + i - r * nd]; }
                 }
             }
         }
@@ -383,10 +454,30 @@ __device__ __forceinline__ void qc_fock_body(const QcKernelArgs &a, const QcSlot
                 // then read back as broadcasts.  Writer and reader lanes are the same lanes of one wave (this code runs
                 // under a group-uniform, possibly wave-divergent condition), DS operations of a wave execute in order,
                 // so wavefront-scope fences (compiler ordering only) are sufficient - no s_barrier here.
+                if constexpr (LGC >= 4) {
+                    // groups made of whole 16-lane rows: four [ab] rows of the transposed block at a time, straight from
+                    // memory into the row's lanes, and the dot products by row broadcasts - no staging, no LDS reads
+                    constexpr int NRE = (HAB + 15) / 16;
+                    const double *__restrict__ Et = a.pairdataT + pb.doff + (size_t)ij * strideB + 4;     // [ab][h]
+                    const int l16 = lane & 15;
+                    for (int ab0 = 0; ab0 < nab; ab0 += 4) {
+                        double Er[4][NRE];
+#pragma unroll
+                        for (int j = 0; j < 4; ++j)
+#pragma unroll
+                            for (int k = 0; k < NRE; ++k) Er[j][k] = Et[(size_t)min(ab0 + j, nab - 1) * HAB + min(16 * k + l16, HAB - 1)];
+                        double acc[4] = {0.0, 0.0, 0.0, 0.0};
+                        qc_dot4_bc<HAB, NRE>(acc, Er, W, std::make_integer_sequence<int, HAB>{});
+#pragma unroll
+                        for (int j = 0; j < 4; ++j)
+                            if (ab0 + j < nab && colok) Iblk[(ab0 + j) * ncd + col] += acc[j];   // column `col` of this slot belongs to this lane alone
+                    }
+                } else {
                 const double *Eab = braBase + (size_t)ij * strideB + 4;
+                const float inab = __builtin_amdgcn_rcpf((float)nab);
                 __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");   // earlier readers of Es are done (program order)
                 for (int x = li; x < HAB * nab; x += C) {
-                    const int h = x / nab, ab = x - h * nab;
+                    const int h = qc_fdiv(x, inab), ab = x - h * nab;
                     Es[ab * HAB + h] = Eab[x];
                 }
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -399,6 +490,7 @@ __device__ __forceinline__ void qc_fock_body(const QcKernelArgs &a, const QcSlot
                     for (int h = 0; h < HAB; ++h) acc = fma(row[h], W[h], acc);
                     if (colok) Iblk[ab * ncd + col] += acc;      // column `col` of this slot belongs to this lane alone
                 }
+                }
             };
 
             const int K_cd = pk.K;
@@ -407,13 +499,13 @@ __device__ __forceinline__ void qc_fock_body(const QcKernelArgs &a, const QcSlot
                 // the C lanes of a group evaluate C *consecutive* primitive quartets of their slot at once (phase A,
                 // tables in registers, then parked in the group's LDS region) and afterwards walk through them one by
                 // one, every lane contracting its own ket column (phase B).  Same-wave LDS hand-off: wavefront fences.
-                double *const meta = Rw + C * NHP;
-                // this lane's primitive quartet of the current chunk: starts at sl.lo + li, advances by C per chunk
+                double *const meta = Rw + CH * NHP;
+                // this lane's primitive quartet of the current chunk: starts at sl.lo + li, advances by CH per chunk
                 int ijA, klA;
                 { const int pq0 = sl.lo + li; ijA = pq0 / K_cd; klA = pq0 - ijA * K_cd; }
-                for (int it0 = 0; it0 < maxlen; it0 += C) {
+                for (int it0 = 0; it0 < maxlen; it0 += CH) {
                     {
-                        const bool vA = it0 + li < len;
+                        const bool vA = li < CH && it0 + li < len;
                         const int ijC = vA ? ijA : 0, klC = vA ? klA : 0;      // stay inside the pair blocks when idle
                         const double4 cb = *reinterpret_cast<const double4 *>(braBase + (size_t)ijC * strideB);
                         const double4 ck = *reinterpret_cast<const double4 *>(ketBase + (size_t)klC * strideK);
@@ -425,18 +517,20 @@ __device__ __forceinline__ void qc_fock_body(const QcKernelArgs &a, const QcSlot
                         qc_boys<L>(alpha * (X * X + Y * Y + Z * Z), a.boys, F);
                         qc_rtab<L>(alpha, X, Y, Z, F, Rr);
                         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");    // phase-B readers of the previous chunk
-                        double *mine = Rw + li * NHP;
+                        if (CH == C || li < CH) {
+                            double *mine = Rw + li * NHP;
 #pragma unroll
-                        for (int h = 0; h < qc_nherm(L); ++h) mine[h] = Rr[h];
-                        meta[2 * li] = vA ? pref : 0.0;
-                        reinterpret_cast<int2 *>(meta)[2 * li + 1] = make_int2(ijC, klC * strideK + 4);   // ket block offset
+                            for (int h = 0; h < qc_nherm(L); ++h) mine[h] = Rr[h];
+                            meta[2 * li] = vA ? pref : 0.0;
+                            reinterpret_cast<int2 *>(meta)[2 * li + 1] = make_int2(ijC, klC * strideK + 4);   // ket block offset
+                        }
                         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                         __builtin_amdgcn_wave_barrier();
                         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-                        klA += C;
+                        klA += CH;
                         while (klA >= K_cd) { klA -= K_cd; ++ijA; }
                     }
-                    const int nB = min(C, maxlen - it0);
+                    const int nB = min(CH, maxlen - it0);
                     for (int s = 0; s < nB; ++s) {
                         {
                             const bool valid = it0 + s < len;
@@ -448,12 +542,16 @@ __device__ __forceinline__ void qc_fock_body(const QcKernelArgs &a, const QcSlot
                                 for (int h = 0; h < HAB; ++h) W[h] = 0.0;
                                 cur_ij = ik.x;
                             }
-                            double e[HCD];
                             const double sc = (valid && colok) ? pref : 0.0;
                             const double *Ecd = ketBase + ik.y + (colok ? col : 0);
+                            if constexpr (LGC >= 4) {          // R values by row broadcast out of registers
+                                qc_step2_dpp<LAB, LCD>(W, Ecd, ncd, sc, Rw + s * NHP, lane);
+                            } else {
+                                double e[HCD];
 #pragma unroll
-                            for (int h = 0; h < HCD; ++h) e[h] = Ecd[h * ncd] * sc;
-                            qc_step2<LAB, LCD>(W, e, Rw + s * NHP);
+                                for (int h = 0; h < HCD; ++h) e[h] = Ecd[h * ncd] * sc;
+                                qc_step2<LAB, LCD>(W, e, Rw + s * NHP);
+                            }
                         }
                     }
                 }
@@ -500,7 +598,8 @@ __device__ __forceinline__ void qc_fock_body(const QcKernelArgs &a, const QcSlot
                 } else {
                     __syncthreads();                  // previous iteration's readers of Rw are done
                     qc_build_r<L>(Rw, li, C, alpha, X, Y, Z, F);
-                    qc_step2_rolled<LAB, LCD>(W, Ecd, ncd, sc, Rw);
+                    if constexpr (LGC >= 4) qc_step2_dpp<LAB, LCD>(W, Ecd, ncd, sc, Rw, lane);
+                    else qc_step2_rolled<LAB, LCD>(W, Ecd, ncd, sc, Rw);
                 }
             }
             }
@@ -532,14 +631,16 @@ __device__ __forceinline__ void qc_fock_body(const QcKernelArgs &a, const QcSlot
                 for (int ab = li; ab < nab; ab += C) {
                     double s = 0.0;
                     for (int cd = 0; cd < ncd; ++cd) s = fma(Iblk[ab * ncd + cd], tDj_cd[cd], s);
-                    const size_t o = (size_t)(pb.offa + ab / nb) * n + pb.offb + ab % nb;
+                    const int r = qc_fdiv(ab, inb);
+                    const size_t o = (size_t)(pb.offa + r) * n + pb.offb + ab - r * nb;
                     unsafeAtomicAdd(&G0[o], fj * s);
                     if (uhf) unsafeAtomicAdd(&G1[o], fj * s);
                 }
                 for (int cd = li; cd < ncd; cd += C) {
                     double s = 0.0;
                     for (int ab = 0; ab < nab; ++ab) s = fma(Iblk[ab * ncd + cd], tDj_ab[ab], s);
-                    const size_t o = (size_t)(pk.offa + cd / nd) * n + pk.offb + cd % nd;
+                    const int r = qc_fdiv(cd, ind);
+                    const size_t o = (size_t)(pk.offa + r) * n + pk.offb + cd - r * nd;
                     unsafeAtomicAdd(&G0[o], fj * s);
                     if (uhf) unsafeAtomicAdd(&G1[o], fj * s);
                 }
@@ -549,28 +650,28 @@ __device__ __forceinline__ void qc_fock_body(const QcKernelArgs &a, const QcSlot
                     double *Gs = s ? G1 : G0;
                     const double *t_ac = tK + s * ktile, *t_ad = t_ac + na * nc, *t_bc = t_ad + na * nd, *t_bd = t_bc + nb * nc;
                     for (int x = li; x < na * nc; x += C) {          // (i,k) <- sum_{j,l} I[ij,kl] D[j,l]
-                        const int i = x / nc, k = x - i * nc;
+                        const int i = qc_fdiv(x, inc), k = x - i * nc;
                         double acc = 0.0;
                         for (int j = 0; j < nb; ++j)
                             for (int l = 0; l < nd; ++l) acc = fma(Iblk[(i * nb + j) * ncd + k * nd + l], t_bd[j * nd + l], acc);
                         unsafeAtomicAdd(&Gs[(size_t)(pb.offa + i) * n + pk.offa + k], fk * acc);
                     }
                     for (int x = li; x < na * nd; x += C) {          // (i,l) <- sum_{j,k} I[ij,kl] D[j,k]
-                        const int i = x / nd, l = x - i * nd;
+                        const int i = qc_fdiv(x, ind), l = x - i * nd;
                         double acc = 0.0;
                         for (int j = 0; j < nb; ++j)
                             for (int k = 0; k < nc; ++k) acc = fma(Iblk[(i * nb + j) * ncd + k * nd + l], t_bc[j * nc + k], acc);
                         unsafeAtomicAdd(&Gs[(size_t)(pb.offa + i) * n + pk.offb + l], fk * acc);
                     }
                     for (int x = li; x < nb * nc; x += C) {          // (j,k) <- sum_{i,l} I[ij,kl] D[i,l]
-                        const int j = x / nc, k = x - j * nc;
+                        const int j = qc_fdiv(x, inc), k = x - j * nc;
                         double acc = 0.0;
                         for (int i = 0; i < na; ++i)
                             for (int l = 0; l < nd; ++l) acc = fma(Iblk[(i * nb + j) * ncd + k * nd + l], t_ad[i * nd + l], acc);
                         unsafeAtomicAdd(&Gs[(size_t)(pb.offb + j) * n + pk.offa + k], fk * acc);
                     }
                     for (int x = li; x < nb * nd; x += C) {          // (j,l) <- sum_{i,k} I[ij,kl] D[i,k]
-                        const int j = x / nd, l = x - j * nd;
+                        const int j = qc_fdiv(x, ind), l = x - j * nd;
                         double acc = 0.0;
                         for (int i = 0; i < na; ++i)
                             for (int k = 0; k < nc; ++k) acc = fma(Iblk[(i * nb + j) * ncd + k * nd + l], t_ac[i * nc + k], acc);
@@ -599,7 +700,7 @@ struct QcTierArgs {
 };
 
 template <int LAB, int TIER>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu((TIER == 0 && LAB <= 4) ? 2 : 1)))
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu((TIER == 0 && LAB <= 2) ? 2 : 1)))
 void qc_fock_tier_kernel(const QcTierArgs a) {
     // the high-L tiers are few, long, latency-bound waves: let them win issue arbitration against the many short
     // low-L waves they share a SIMD with

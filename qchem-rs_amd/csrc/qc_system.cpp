@@ -392,9 +392,9 @@ void qc_build_shards(qc_system *S) {
             // LDS doubles one lane group needs for this quartet (layout in qc_fock_kernel.h)
             const int ncd = k.na * k.nb, nab = b.na * b.nb;
             // (the matrix-core classes read the bra block straight from memory: a 48-double Hermite index table instead of
-            // the staged [ab][h] block)
+            // the staged [ab][h] block; groups of whole 16-lane rows read it by row broadcasts and stage nothing)
             const int w = qc_region0(b.L + k.L, c.LGC) + nab * ncd + nab + ncd + 2 * (b.na * k.na + b.na * k.nb + b.nb * k.na + b.nb * k.nb) +
-                          (qc_use_mfma(c.LAB, c.LCD) ? 48 : nab * qc_nherm(b.L));
+                          (qc_use_mfma(c.LAB, c.LCD) ? 48 : (c.LGC >= 4 ? 0 : nab * qc_nherm(b.L)));
             words = std::max(words, w);
         }
         c.slot_words = words;
