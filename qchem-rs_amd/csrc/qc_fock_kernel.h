@@ -140,34 +140,49 @@ __device__ __forceinline__ void qc_step2_dpp_batch(double (&W)[qc_nherm(LAB)], c
     (qc_step2_dpp_row<LAB, NR, H0 + J>(W, Rd, e[J] * ((qc_order_of<H0 + J>() & 1) ? -sc : sc),
                                        std::make_integer_sequence<int, qc_nherm(LAB)>{}), ...);
 }
+// Batches H0.. of one primitive quartet.  Before the FMAs of the last batch the first coefficients (eN) and the R
+// registers (RdN) of the *next* primitive quartet are requested, so a step never starts by waiting for its operands.
 template <int LAB, int LCD, int NR, int H0>
 __device__ __forceinline__ void qc_step2_dpp_from(double (&W)[qc_nherm(LAB)], const double (&Rd)[NR], const double (&e)[QC_DPP_BATCH],
-                                                  const double *__restrict__ Ecd, int ncd, double sc) {
-    constexpr int HCD = qc_nherm(LCD), NB = (HCD - H0 < QC_DPP_BATCH) ? HCD - H0 : QC_DPP_BATCH;
+                                                  const double *__restrict__ Ecd, int ncd, double sc,
+                                                  const double *__restrict__ EcdN, const double *__restrict__ RwN, int l16,
+                                                  double (&eN)[QC_DPP_BATCH], double (&RdN)[NR]) {
+    constexpr int HCD = qc_nherm(LCD), HR = qc_nherm(LAB + LCD), NB = (HCD - H0 < QC_DPP_BATCH) ? HCD - H0 : QC_DPP_BATCH;
     if constexpr (H0 + NB < HCD) {
         double en[QC_DPP_BATCH];
 #pragma unroll
         for (int j = 0; j < QC_DPP_BATCH; ++j) en[j] = (H0 + NB + j < HCD) ? Ecd[(size_t)(H0 + NB + j) * ncd] : 0.0;
         __builtin_amdgcn_sched_barrier(0);          // the next batch is requested before this one's FMAs
         qc_step2_dpp_batch<LAB, NR, H0>(W, Rd, e, sc, std::make_integer_sequence<int, NB>{});
-        qc_step2_dpp_from<LAB, LCD, NR, H0 + NB>(W, Rd, en, Ecd, ncd, sc);
+        qc_step2_dpp_from<LAB, LCD, NR, H0 + NB>(W, Rd, en, Ecd, ncd, sc, EcdN, RwN, l16, eN, RdN);
     } else {
+#pragma unroll
+        for (int j = 0; j < QC_DPP_BATCH; ++j) eN[j] = (j < HCD) ? EcdN[(size_t)j * ncd] : 0.0;
+#pragma unroll
+        for (int k = 0; k < NR; ++k) RdN[k] = RwN[min(16 * k + l16, HR - 1)];
+        __builtin_amdgcn_sched_barrier(0);
         qc_step2_dpp_batch<LAB, NR, H0>(W, Rd, e, sc, std::make_integer_sequence<int, NB>{});
     }
 }
+// operands of the first primitive quartet of a run
+template <int LAB, int LCD, int NR>
+__device__ __forceinline__ void qc_step2_dpp_first(const double *__restrict__ Ecd, int ncd, const double *__restrict__ Rw, int l16,
+                                                   double (&e)[QC_DPP_BATCH], double (&Rd)[NR]) {
+    constexpr int HCD = qc_nherm(LCD), HR = qc_nherm(LAB + LCD);
+#pragma unroll
+    for (int j = 0; j < QC_DPP_BATCH; ++j) e[j] = (j < HCD) ? Ecd[(size_t)j * ncd] : 0.0;
+#pragma unroll
+    for (int k = 0; k < NR; ++k) Rd[k] = Rw[min(16 * k + l16, HR - 1)];
+}
+// one primitive quartet on its own (cooperative-table classes: the table of the next one does not exist yet)
 template <int LAB, int LCD>
 __device__ __forceinline__ void qc_step2_dpp(double (&W)[qc_nherm(LAB)], const double *__restrict__ Ecd, int ncd, double sc,
                                              const double *__restrict__ Rw, int lane) {
-    constexpr int HR = qc_nherm(LAB + LCD), NR = (HR + 15) / 16, HCD = qc_nherm(LCD);
-    double e[QC_DPP_BATCH];
-#pragma unroll
-    for (int j = 0; j < QC_DPP_BATCH; ++j) e[j] = (j < HCD) ? Ecd[(size_t)j * ncd] : 0.0;
-    double Rd[NR];
-#pragma unroll
-    for (int k = 0; k < NR; ++k) Rd[k] = Rw[min(16 * k + (lane & 15), HR - 1)];
-    qc_step2_dpp_from<LAB, LCD, NR, 0>(W, Rd, e, Ecd, ncd, sc);
+    constexpr int NR = (qc_nherm(LAB + LCD) + 15) / 16;
+    double e[QC_DPP_BATCH], Rd[NR], eN[QC_DPP_BATCH], RdN[NR];
+    qc_step2_dpp_first<LAB, LCD, NR>(Ecd, ncd, Rw, lane & 15, e, Rd);
+    qc_step2_dpp_from<LAB, LCD, NR, 0>(W, Rd, e, Ecd, ncd, sc, Ecd, Rw, lane & 15, eN, RdN);
 }
-
 
 // Boys function F_0..F_L at x.  Inside the table: Horner evaluation of the 8-term Taylor expansion of the top order
 // about the nearest grid point x_k (rows hold F_{L+j}(x_k) / j!), exp(-x) = exp(-x_k) * exp(x_k - x) from the grid value
@@ -531,6 +546,38 @@ __device__ __forceinline__ void qc_fock_body(const QcKernelArgs &a, const QcSlot
                         while (klA >= K_cd) { klA -= K_cd; ++ijA; }
                     }
                     const int nB = min(CH, maxlen - it0);
+                    if constexpr (LGC >= 4) {
+                        // R values by row broadcasts out of registers; the operands of step s + 1 (its record, first ket
+                        // coefficients and R registers) are requested while step s computes
+                        constexpr int NR = (qc_nherm(L) + 15) / 16;
+                        const int l16 = lane & 15, colo = colok ? col : 0;
+                        double prefN = meta[0];
+                        int2 ikN = reinterpret_cast<const int2 *>(meta)[1];
+                        double eA[QC_DPP_BATCH], RdA[NR];
+                        qc_step2_dpp_first<LAB, LCD, NR>(ketBase + ikN.y + colo, ncd, Rw, l16, eA, RdA);
+                        for (int s = 0; s < nB; ++s) {
+                            const bool valid = it0 + s < len;
+                            const double pref = prefN;
+                            const int2 ik = ikN;
+                            const int sn = min(s + 1, nB - 1);
+                            prefN = meta[2 * sn];
+                            ikN = reinterpret_cast<const int2 *>(meta)[2 * sn + 1];
+                            if (valid && ik.x != cur_ij) {
+                                if (cur_ij >= 0) flush(cur_ij);
+#pragma unroll
+                                for (int h = 0; h < HAB; ++h) W[h] = 0.0;
+                                cur_ij = ik.x;
+                            }
+                            const double sc = (valid && colok) ? pref : 0.0;
+                            double ec[QC_DPP_BATCH], Rdc[NR];
+#pragma unroll
+                            for (int j = 0; j < QC_DPP_BATCH; ++j) ec[j] = eA[j];
+#pragma unroll
+                            for (int k = 0; k < NR; ++k) Rdc[k] = RdA[k];
+                            qc_step2_dpp_from<LAB, LCD, NR, 0>(W, Rdc, ec, ketBase + ik.y + colo, ncd, sc, ketBase + ikN.y + colo,
+                                                               Rw + sn * NHP, l16, eA, RdA);
+                        }
+                    } else {
                     for (int s = 0; s < nB; ++s) {
                         {
                             const bool valid = it0 + s < len;
@@ -544,15 +591,12 @@ __device__ __forceinline__ void qc_fock_body(const QcKernelArgs &a, const QcSlot
                             }
                             const double sc = (valid && colok) ? pref : 0.0;
                             const double *Ecd = ketBase + ik.y + (colok ? col : 0);
-                            if constexpr (LGC >= 4) {          // R values by row broadcast out of registers
-                                qc_step2_dpp<LAB, LCD>(W, Ecd, ncd, sc, Rw + s * NHP, lane);
-                            } else {
-                                double e[HCD];
+                            double e[HCD];
 #pragma unroll
-                                for (int h = 0; h < HCD; ++h) e[h] = Ecd[h * ncd] * sc;
-                                qc_step2<LAB, LCD>(W, e, Rw + s * NHP);
-                            }
+                            for (int h = 0; h < HCD; ++h) e[h] = Ecd[h * ncd] * sc;
+                            qc_step2<LAB, LCD>(W, e, Rw + s * NHP);
                         }
+                    }
                     }
                 }
             } else {

@@ -17,7 +17,7 @@ constexpr int QC_LREG = 4;               // total Hermite orders up to this keep
 constexpr int QC_LHOIST = 4;             // ... and up to this the C lanes of a group evaluate C primitive quartets' tables at once
 constexpr int QC_LHOIST_DPP = 6;         // ... and up to this when the group spans whole 16-lane rows (step 2 by DPP row broadcasts)
 // primitive quartets whose tables one group evaluates per chunk of the hoisted path
-__host__ __device__ constexpr int qc_hoist_chunk(int L, int lgc) { return L <= QC_LHOIST ? (1 << lgc) : (L == 5 ? 16 : 8); }
+__host__ __device__ constexpr int qc_hoist_chunk(int L, int lgc) { return (L <= QC_LHOIST && lgc < 3) ? (1 << lgc) : 8; }
 __host__ __device__ constexpr bool qc_hoisted(int L, int lgc) { return lgc > 0 && (L <= QC_LHOIST || (lgc >= 4 && L <= QC_LHOIST_DPP)); }
 // doubles at the head of a lane group's LDS region: the hoisted register tables of one chunk + their (pref, ij/kl)
 // records, or the cooperative R work array (L > QC_LREG)
