@@ -475,17 +475,27 @@ __device__ __forceinline__ void qc_fock_body(const QcKernelArgs &a, const QcSlot
                     constexpr int NRE = (HAB + 15) / 16;
                     const double *__restrict__ Et = a.pairdataT + pb.doff + (size_t)ij * strideB + 4;     // [ab][h]
                     const int l16 = lane & 15;
+                    double Er[4][NRE];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+#pragma unroll
+                        for (int k = 0; k < NRE; ++k) Er[j][k] = Et[(size_t)min(j, nab - 1) * HAB + min(16 * k + l16, HAB - 1)];
                     for (int ab0 = 0; ab0 < nab; ab0 += 4) {
-                        double Er[4][NRE];
+                        double En[4][NRE];                       // the next four rows are requested before these are used
 #pragma unroll
                         for (int j = 0; j < 4; ++j)
 #pragma unroll
-                            for (int k = 0; k < NRE; ++k) Er[j][k] = Et[(size_t)min(ab0 + j, nab - 1) * HAB + min(16 * k + l16, HAB - 1)];
+                            for (int k = 0; k < NRE; ++k) En[j][k] = Et[(size_t)min(ab0 + 4 + j, nab - 1) * HAB + min(16 * k + l16, HAB - 1)];
+                        __builtin_amdgcn_sched_barrier(0);
                         double acc[4] = {0.0, 0.0, 0.0, 0.0};
                         qc_dot4_bc<HAB, NRE>(acc, Er, W, std::make_integer_sequence<int, HAB>{});
 #pragma unroll
                         for (int j = 0; j < 4; ++j)
                             if (ab0 + j < nab && colok) Iblk[(ab0 + j) * ncd + col] += acc[j];   // column `col` of this slot belongs to this lane alone
+#pragma unroll
+                        for (int j = 0; j < 4; ++j)
+#pragma unroll
+                            for (int k = 0; k < NRE; ++k) Er[j][k] = En[j][k];
                     }
                 } else {
                 const double *Eab = braBase + (size_t)ij * strideB + 4;
@@ -674,6 +684,7 @@ __device__ __forceinline__ void qc_fock_body(const QcKernelArgs &a, const QcSlot
                 const double fj = 2.0 * f;
                 for (int ab = li; ab < nab; ab += C) {
                     double s = 0.0;
+#pragma unroll 4
                     for (int cd = 0; cd < ncd; ++cd) s = fma(Iblk[ab * ncd + cd], tDj_cd[cd], s);
                     const int r = qc_fdiv(ab, inb);
                     const size_t o = (size_t)(pb.offa + r) * n + pb.offb + ab - r * nb;
@@ -682,6 +693,7 @@ __device__ __forceinline__ void qc_fock_body(const QcKernelArgs &a, const QcSlot
                 }
                 for (int cd = li; cd < ncd; cd += C) {
                     double s = 0.0;
+#pragma unroll 4
                     for (int ab = 0; ab < nab; ++ab) s = fma(Iblk[ab * ncd + cd], tDj_ab[ab], s);
                     const int r = qc_fdiv(cd, ind);
                     const size_t o = (size_t)(pk.offa + r) * n + pk.offb + cd - r * nd;
@@ -697,6 +709,7 @@ __device__ __forceinline__ void qc_fock_body(const QcKernelArgs &a, const QcSlot
                         const int i = qc_fdiv(x, inc), k = x - i * nc;
                         double acc = 0.0;
                         for (int j = 0; j < nb; ++j)
+#pragma unroll 3
                             for (int l = 0; l < nd; ++l) acc = fma(Iblk[(i * nb + j) * ncd + k * nd + l], t_bd[j * nd + l], acc);
                         unsafeAtomicAdd(&Gs[(size_t)(pb.offa + i) * n + pk.offa + k], fk * acc);
                     }
@@ -704,6 +717,7 @@ __device__ __forceinline__ void qc_fock_body(const QcKernelArgs &a, const QcSlot
                         const int i = qc_fdiv(x, ind), l = x - i * nd;
                         double acc = 0.0;
                         for (int j = 0; j < nb; ++j)
+#pragma unroll 3
                             for (int k = 0; k < nc; ++k) acc = fma(Iblk[(i * nb + j) * ncd + k * nd + l], t_bc[j * nc + k], acc);
                         unsafeAtomicAdd(&Gs[(size_t)(pb.offa + i) * n + pk.offb + l], fk * acc);
                     }
@@ -711,6 +725,7 @@ __device__ __forceinline__ void qc_fock_body(const QcKernelArgs &a, const QcSlot
                         const int j = qc_fdiv(x, inc), k = x - j * nc;
                         double acc = 0.0;
                         for (int i = 0; i < na; ++i)
+#pragma unroll 3
                             for (int l = 0; l < nd; ++l) acc = fma(Iblk[(i * nb + j) * ncd + k * nd + l], t_ad[i * nd + l], acc);
                         unsafeAtomicAdd(&Gs[(size_t)(pb.offb + j) * n + pk.offa + k], fk * acc);
                     }
@@ -718,6 +733,7 @@ __device__ __forceinline__ void qc_fock_body(const QcKernelArgs &a, const QcSlot
                         const int j = qc_fdiv(x, ind), l = x - j * nd;
                         double acc = 0.0;
                         for (int i = 0; i < na; ++i)
+#pragma unroll 3
                             for (int k = 0; k < nc; ++k) acc = fma(Iblk[(i * nb + j) * ncd + k * nd + l], t_ac[i * nc + k], acc);
                         unsafeAtomicAdd(&Gs[(size_t)(pb.offb + j) * n + pk.offb + l], fk * acc);
                     }

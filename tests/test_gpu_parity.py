@@ -327,7 +327,7 @@ def test_uhf_triplet_oxygen_extension():
     assert ref["status"] == 0
     st = q.ScfStepper(s, uhf=True, n_alpha=9, n_beta=7)
     e = rms = None
-    for _ in range(2001):
+    for _ in range(20001):
         e, rms = st.iterate()
         if rms / 2.0 < 1e-10:                                  # uhf.rs:139
             break
@@ -339,8 +339,10 @@ def test_uhf_triplet_oxygen_extension():
     I, H = o.eri(), o.kinetic() + o.nuclear()
     evar = lambda A, B: 0.5 * np.sum(A * (2 * H + o.g_uhf(A, B, I))) + 0.5 * np.sum(B * (2 * H + o.g_uhf(B, A, I)))
     assert abs(evar(Da, Db) - evar(ref["density_alpha"], ref["density_beta"])) < 1e-9
-    # (2) the energy as the reference reports it (stale G): first order in the residual on both sides
-    assert abs(e + s.nuclear_repulsion() - ref["total_energy"]) < 5 * TOL_E
+    # (2) the energy as the reference reports it (stale G): first order in the distance to the fixed point on both sides,
+    # and while the iteration crawls that distance is many times the step the stopping rule looks at (a contraction factor
+    # of 0.99 puts a 1e-10 step 1e-8 away), so this is a plausibility bound, not the parity statement - (1) is
+    assert abs(e + s.nuclear_repulsion() - ref["total_energy"]) < 50 * TOL_E
 
 
 @pytest.mark.parametrize("mol,basis", [("water", "STO-3G"), ("water", "cc-pVTZ"), ("ethylene", "6-31G_st_st")])
