@@ -15,11 +15,6 @@
 //     atomic per element; the ket-side J and the four K blocks are per-lane atomics into the replica of the wave.
 #include "qc_fock_kernel.h"
 #include "gen/qc_rtab.h"
-#include "gen/qc_step2_lab0.h"
-#include "gen/qc_step2_lab1.h"
-#include "gen/qc_step2_lab2.h"
-#include "gen/qc_step2_lab3.h"
-#include "gen/qc_step2_lab4.h"
 
 #include "qc_fock_bm.h"
 
@@ -140,8 +135,9 @@ __device__ __forceinline__ void qc_bm_pass(const double *__restrict__ pd, const 
             qc_rtab<L>(alpha, X, Y, Z, F, Rr);
             const double sc = valid ? pref : 0.0;
             if constexpr (LCD == 0) {
-                double e[1] = {ek * sc};
-                qc_step2<LAB, 0>(W[u][0], e, Rr);
+                const double e = ek * sc;               // ss ket: a single Hermite function, W[h] += e R_h
+#pragma unroll
+                for (int h = 0; h < qc_nherm(LAB); ++h) W[u][0][h] = fma(e, Rr[h], W[u][0][h]);
             } else {
                 const double e0[3] = {ek4.x * sc, ek4.y * sc, ek4.z * sc};
                 qc_step2_ps<LAB>(W[u], e0, -(ek4.w * sc), Rr);

@@ -37,9 +37,6 @@ struct QcKernelArgs {
     double *eri_out;
 };
 
-template <int LAB, int LCD>
-__device__ __forceinline__ void qc_step2(double (&W)[qc_nherm(LAB)], const double (&e)[qc_nherm(LCD)], const double *__restrict__ R);
-
 template <int L>
 __device__ __forceinline__ void qc_rtab(double alpha, double X, double Y, double Z, const double (&F)[L + 1], double (&R)[qc_nherm(L)]);
 
@@ -53,53 +50,6 @@ __host__ __device__ constexpr QcTuvTable qc_make_tuv() {
             for (int u = N - t; u >= 0; --u) { T.t[k] = (unsigned char)t; T.u[k] = (unsigned char)u; T.v[k] = (unsigned char)(N - t - u); ++k; }
     return T;
 }
-
-// Step 2 as loops, for the classes whose R table lives in LDS (LAB + LCD > QC_LREG).  The ket Hermite index
-// h2 = (t2,u2,v2) runs in wave-uniform scalar loops; for every h2 the HAB accumulators are updated by an unrolled body whose
-// R offset  hidx(h1 + h2) = T3(N1 + N2) + T2(s1 + s2) + v1 + v2  (T3(N) = N(N+1)(N+2)/6, T2(s) = s(s+1)/2, s = u + v) is
-// two scalar table look-ups plus constants.  A lane keeps only W[HAB] live - the fully unrolled form needed 512
-// registers and scratch for every class with a wide ket, and its code did not fit the instruction cache.
-template <int LAB, int LCD>
-__device__ __forceinline__ void qc_step2_rolled(double (&W)[qc_nherm(LAB)], const double *__restrict__ Ecd, int ncd, double sc,
-                                                const double *__restrict__ R) {
-    constexpr QcTuvTable T = qc_make_tuv();
-    constexpr int HAB = qc_nherm(LAB);
-    constexpr int B = 14;                     // R values fetched from LDS per batch before the FMAs that consume them
-    const double *e_ptr = Ecd;
-    double e_next = *e_ptr;
-    for (int N2 = 0; N2 <= LCD; ++N2) {
-        const double sgn = (N2 & 1) ? -sc : sc;
-        int off3[LAB + 1];
-#pragma unroll
-        for (int k = 0; k <= LAB; ++k) off3[k] = (k + N2) * (k + N2 + 1) * (k + N2 + 2) / 6;
-        for (int t2 = N2; t2 >= 0; --t2) {
-            for (int u2 = N2 - t2; u2 >= 0; --u2) {
-                const int v2 = N2 - t2 - u2, s2 = N2 - t2;
-                const double e = e_next * sgn;
-                e_ptr += ncd;
-                if (!(N2 == LCD && t2 == 0 && u2 == 0)) e_next = *e_ptr;     // next ket Hermite coefficient, one iteration ahead
-                int off2[LAB + 1];
-#pragma unroll
-                for (int k = 0; k <= LAB; ++k) off2[k] = (k + s2) * (k + s2 + 1) / 2 + v2;
-#pragma unroll
-                for (int h0 = 0; h0 < HAB; h0 += B) {
-                    double r[B];
-#pragma unroll
-                    for (int i = 0; i < B; ++i) {
-                        const int h1 = (h0 + i < HAB) ? h0 + i : HAB - 1;
-                        const int N1 = T.t[h1] + T.u[h1] + T.v[h1], s1 = T.u[h1] + T.v[h1], v1 = T.v[h1];
-                        r[i] = R[off3[N1] + off2[s1] + v1];
-                    }
-                    __builtin_amdgcn_sched_barrier(0);          // all loads of the batch are in flight before the first FMA waits
-#pragma unroll
-                    for (int i = 0; i < B; ++i)
-                        if (h0 + i < HAB) W[h0 + i] = fma(e, r[i], W[h0 + i]);
-                }
-            }
-        }
-    }
-}
-
 
 // Step 2 with the R table spread over the registers of each 16-lane row (groups of 16, 32 or 64 lanes: LGC >= 4).
 // Lane l keeps R[16 k + (l & 15)] in Rd[k]; `v_fmac_f64_dpp ... row_newbcast:j` multiplies lane j's copy into every
@@ -288,17 +238,18 @@ template <int LAB, int LCD, int LGC>
 __device__ __forceinline__ void qc_fock_body(const QcKernelArgs &a, const QcSlot *__restrict__ slots, const int nslots, const int slot_words,
                                              const int blk, const int nblk) {
     constexpr int L = LAB + LCD, HAB = qc_nherm(LAB), HCD = qc_nherm(LCD);
+    static_assert(LGC >= 4, "a lane group is made of whole 16-lane rows (DPP row broadcasts)");
     constexpr int C = 1 << LGC, G = 64 >> LGC;
     extern __shared__ double lds[];
     const int lane = threadIdx.x, g = lane >> LGC, li = lane & (C - 1);
     const double *__restrict__ pd = a.pairdata;
     const int n = a.n;
     const bool uhf = a.Dk1 != nullptr;
-    constexpr bool HOIST = qc_hoisted(L, LGC);
-    constexpr int CH = qc_hoist_chunk(L, LGC);            // primitive quartets per chunk of the hoisted path
+    constexpr bool HOIST = qc_hoisted(L);
+    constexpr int CH = QC_HOIST_CHUNK;                    // primitive quartets per chunk of the hoisted path
     constexpr int NHP = qc_nherm(L) | 1;                    // padded table length of the hoisted path
     double *const Rw = lds + (size_t)g * slot_words;       // this group's private LDS region
-    double *const Iblk = Rw + qc_region0(L, LGC);
+    double *const Iblk = Rw + qc_region0(L);
     const size_t rep = (size_t)(blk % a.nrep) * a.rep_stride;   // accumulation replica of this workgroup
     constexpr bool MFMA = qc_use_mfma(LAB, LCD) && LGC == 6;   // contractions on the matrix cores (one slot per wave)
     if constexpr (MFMA) {
@@ -324,7 +275,6 @@ __device__ __forceinline__ void qc_fock_body(const QcKernelArgs &a, const QcSlot
         double *tDj_ab = Iblk + nab * ncd, *tDj_cd = tDj_ab + nab;
         double *tK = tDj_cd + ncd;   // per spin: Dk_ac, Dk_ad, Dk_bc, Dk_bd
         const int ktile = na * nc + na * nd + nb * nc + nb * nd;
-        double *Es = tK + 2 * ktile; // staged bra expansion block [ab][h]
 
         if (active) {
             for (int i = li; i < nab * ncd; i += C) Iblk[i] = 0.0;
@@ -469,7 +419,7 @@ __device__ __forceinline__ void qc_fock_body(const QcKernelArgs &a, const QcSlot
                 // then read back as broadcasts.  Writer and reader lanes are the same lanes of one wave (this code runs
                 // under a group-uniform, possibly wave-divergent condition), DS operations of a wave execute in order,
                 // so wavefront-scope fences (compiler ordering only) are sufficient - no s_barrier here.
-                if constexpr (LGC >= 4) {
+                {
                     // groups made of whole 16-lane rows: four [ab] rows of the transposed block at a time, straight from
                     // memory into the row's lanes, and the dot products by row broadcasts - no staging, no LDS reads
                     constexpr int NRE = (HAB + 15) / 16;
@@ -497,24 +447,6 @@ __device__ __forceinline__ void qc_fock_body(const QcKernelArgs &a, const QcSlot
 #pragma unroll
                             for (int k = 0; k < NRE; ++k) Er[j][k] = En[j][k];
                     }
-                } else {
-                const double *Eab = braBase + (size_t)ij * strideB + 4;
-                const float inab = __builtin_amdgcn_rcpf((float)nab);
-                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");   // earlier readers of Es are done (program order)
-                for (int x = li; x < HAB * nab; x += C) {
-                    const int h = qc_fdiv(x, inab), ab = x - h * nab;
-                    Es[ab * HAB + h] = Eab[x];
-                }
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                __builtin_amdgcn_wave_barrier();
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-                for (int ab = 0; ab < nab; ++ab) {
-                    const double *row = Es + ab * HAB;
-                    double acc = 0.0;
-#pragma unroll
-                    for (int h = 0; h < HAB; ++h) acc = fma(row[h], W[h], acc);
-                    if (colok) Iblk[ab * ncd + col] += acc;      // column `col` of this slot belongs to this lane alone
-                }
                 }
             };
 
@@ -542,7 +474,7 @@ __device__ __forceinline__ void qc_fock_body(const QcKernelArgs &a, const QcSlot
                         qc_boys<L>(alpha * (X * X + Y * Y + Z * Z), a.boys, F);
                         qc_rtab<L>(alpha, X, Y, Z, F, Rr);
                         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");    // phase-B readers of the previous chunk
-                        if (CH == C || li < CH) {
+                        if (li < CH) {
                             double *mine = Rw + li * NHP;
 #pragma unroll
                             for (int h = 0; h < qc_nherm(L); ++h) mine[h] = Rr[h];
@@ -556,7 +488,7 @@ __device__ __forceinline__ void qc_fock_body(const QcKernelArgs &a, const QcSlot
                         while (klA >= K_cd) { klA -= K_cd; ++ijA; }
                     }
                     const int nB = min(CH, maxlen - it0);
-                    if constexpr (LGC >= 4) {
+                    {
                         // R values by row broadcasts out of registers; the operands of step s + 1 (its record, first ket
                         // coefficients and R registers) are requested while step s computes
                         constexpr int NR = (qc_nherm(L) + 15) / 16;
@@ -587,26 +519,6 @@ __device__ __forceinline__ void qc_fock_body(const QcKernelArgs &a, const QcSlot
                             qc_step2_dpp_from<LAB, LCD, NR, 0>(W, Rdc, ec, ketBase + ik.y + colo, ncd, sc, ketBase + ikN.y + colo,
                                                                Rw + sn * NHP, l16, eA, RdA);
                         }
-                    } else {
-                    for (int s = 0; s < nB; ++s) {
-                        {
-                            const bool valid = it0 + s < len;
-                            const double pref = meta[2 * s];
-                            const int2 ik = reinterpret_cast<const int2 *>(meta)[2 * s + 1];
-                            if (valid && ik.x != cur_ij) {
-                                if (cur_ij >= 0) flush(cur_ij);
-#pragma unroll
-                                for (int h = 0; h < HAB; ++h) W[h] = 0.0;
-                                cur_ij = ik.x;
-                            }
-                            const double sc = (valid && colok) ? pref : 0.0;
-                            const double *Ecd = ketBase + ik.y + (colok ? col : 0);
-                            double e[HCD];
-#pragma unroll
-                            for (int h = 0; h < HCD; ++h) e[h] = Ecd[h * ncd] * sc;
-                            qc_step2<LAB, LCD>(W, e, Rw + s * NHP);
-                        }
-                    }
                     }
                 }
             } else {
@@ -642,19 +554,9 @@ __device__ __forceinline__ void qc_fock_body(const QcKernelArgs &a, const QcSlot
                 qc_boys<L>(alpha * (X * X + Y * Y + Z * Z), a.boys, F);
                 const double sc = (valid && colok) ? pref : 0.0;
                 const double *Ecd = ket + 4 + (colok ? col : 0);
-                if constexpr (L <= QC_LREG) {         // small tables: every lane keeps its own copy in registers
-                    double e[HCD];
-#pragma unroll
-                    for (int h = 0; h < HCD; ++h) e[h] = Ecd[h * ncd] * sc;
-                    double Rr[qc_nherm(L)];
-                    qc_rtab<L>(alpha, X, Y, Z, F, Rr);
-                    qc_step2<LAB, LCD>(W, e, Rr);
-                } else {
-                    __syncthreads();                  // previous iteration's readers of Rw are done
-                    qc_build_r<L>(Rw, li, C, alpha, X, Y, Z, F);
-                    if constexpr (LGC >= 4) qc_step2_dpp<LAB, LCD>(W, Ecd, ncd, sc, Rw, lane);
-                    else qc_step2_rolled<LAB, LCD>(W, Ecd, ncd, sc, Rw);
-                }
+                __syncthreads();                  // previous iteration's readers of Rw are done
+                qc_build_r<L>(Rw, li, C, alpha, X, Y, Z, F);
+                qc_step2_dpp<LAB, LCD>(W, Ecd, ncd, sc, Rw, lane);
             }
             }
             if (cur_ij >= 0) flush(cur_ij);
@@ -773,7 +675,7 @@ void qc_fock_tier_kernel(const QcTierArgs a) {
     const int nslots = a.seg_nslots[s], words = a.seg_words[s];
 #define QC_CASE(LCD, LGC) case ((LCD) << 4 | (LGC)): qc_fock_body<LAB, LCD, LGC>(a.base, slots, nslots, words, blk, nblk); break;
     if constexpr (TIER == 0) {
-        switch (a.seg_code[s]) { QC_CASE(2, 3) QC_CASE(2, 4) QC_CASE(3, 3) QC_CASE(3, 4) QC_CASE(3, 5) default: break; }
+        switch (a.seg_code[s]) { QC_CASE(2, 4) QC_CASE(3, 4) QC_CASE(3, 5) default: break; }
     } else {
         switch (a.seg_code[s]) { QC_CASE(4, 5) QC_CASE(4, 6) QC_CASE(5, 6) QC_CASE(6, 6) default: break; }
     }

@@ -13,17 +13,14 @@ constexpr int QC_LMAX = 3;              // highest shell angular momentum with k
 constexpr int QC_LPAIR = 2 * QC_LMAX;   // highest pair angular momentum
 constexpr int QC_LTOT = 4 * QC_LMAX;    // highest Hermite order of an ERI
 constexpr int QC_SLOT_ITMAX = 128;
-constexpr int QC_LREG = 4;               // total Hermite orders up to this keep the R table in registers
-constexpr int QC_LHOIST = 4;             // ... and up to this the C lanes of a group evaluate C primitive quartets' tables at once
-constexpr int QC_LHOIST_DPP = 6;         // ... and up to this when the group spans whole 16-lane rows (step 2 by DPP row broadcasts)
-// primitive quartets whose tables one group evaluates per chunk of the hoisted path
-__host__ __device__ constexpr int qc_hoist_chunk(int L, int lgc) { return (L <= QC_LHOIST && lgc < 3) ? (1 << lgc) : 8; }
-__host__ __device__ constexpr bool qc_hoisted(int L, int lgc) { return lgc > 0 && (L <= QC_LHOIST || (lgc >= 4 && L <= QC_LHOIST_DPP)); }
+constexpr int QC_LREG = 4;               // total Hermite orders up to this keep the R table in registers (bra-major kernels; Boys branch)
+constexpr int QC_LHOIST_DPP = 6;         // column kernels: up to this the lanes of a group evaluate several primitive quartets' tables at once
+constexpr int QC_HOIST_CHUNK = 8;        // ... this many per chunk (the parked tables limit the resident waves)
+__host__ __device__ constexpr bool qc_hoisted(int L) { return L <= QC_LHOIST_DPP; }
 // doubles at the head of a lane group's LDS region: the hoisted register tables of one chunk + their (pref, ij/kl)
-// records, or the cooperative R work array (L > QC_LREG)
-__host__ __device__ constexpr int qc_region0(int L, int lgc) {
-    return qc_hoisted(L, lgc) ? qc_hoist_chunk(L, lgc) * ((((L + 1) * (L + 2) * (L + 3) / 6) | 1) + 2)
-                              : (L > QC_LREG ? (L + 1) * (L + 2) * (L + 3) * (L + 4) / 24 : 0);
+// records, or the cooperative R work array
+__host__ __device__ constexpr int qc_region0(int L) {
+    return qc_hoisted(L) ? QC_HOIST_CHUNK * ((((L + 1) * (L + 2) * (L + 3) / 6) | 1) + 2) : (L + 1) * (L + 2) * (L + 3) * (L + 4) / 24;
 }
       // primitive quartets per slot
 constexpr double QC_PRIM_CUTOFF = 1e-17; // primitive pairs whose Hermite expansion block is entirely below this are dropped

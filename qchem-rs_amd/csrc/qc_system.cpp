@@ -287,10 +287,12 @@ void qc_build_model(qc_system *S) {
     qc_build_shards(S);
 }
 
-// Lane-group widths the kernels are instantiated for, per ket Hermite order (gen_step2.py emits the same table).
+// Lane-group widths the kernels are instantiated for, per ket Hermite order (the switch in qc_fock_tier_kernel).  A group is
+// made of whole 16-lane rows - the Hermite contractions broadcast inside rows (DPP) - so the 5..10 columns of a ds / fs ket
+// leave lanes idle; as 8-lane groups with LDS-fed contractions those classes were 20 % slower.
 int qc_lgc_for(int lab, int lcd, int ncd) {
     if (qc_use_mfma(lab, lcd)) return 6;            // matrix-core classes: one slot per wave, always the full wave
-    static const int allowed[QC_LPAIR + 1][4] = {{0, -1, -1, -1}, {2, -1, -1, -1}, {3, 4, -1, -1}, {3, 4, 5, -1}, {5, 6, -1, -1}, {6, -1, -1, -1}, {6, -1, -1, -1}};
+    static const int allowed[QC_LPAIR + 1][4] = {{4, -1, -1, -1}, {4, -1, -1, -1}, {4, -1, -1, -1}, {4, 5, -1, -1}, {5, 6, -1, -1}, {6, -1, -1, -1}, {6, -1, -1, -1}};
     for (int i = 0; i < 4 && allowed[lcd][i] >= 0; ++i)
         if ((1 << allowed[lcd][i]) >= ncd) return allowed[lcd][i];
     return 6;   // wider than a wave: the kernel makes several column passes
@@ -391,10 +393,9 @@ void qc_build_shards(qc_system *S) {
                            2.0 * ca * cb * cc * cd * hcd + 12.0 * na * nb * nc * nd;
             // LDS doubles one lane group needs for this quartet (layout in qc_fock_kernel.h)
             const int ncd = k.na * k.nb, nab = b.na * b.nb;
-            // (the matrix-core classes read the bra block straight from memory: a 48-double Hermite index table instead of
-            // the staged [ab][h] block; groups of whole 16-lane rows read it by row broadcasts and stage nothing)
-            const int w = qc_region0(b.L + k.L, c.LGC) + nab * ncd + nab + ncd + 2 * (b.na * k.na + b.na * k.nb + b.nb * k.na + b.nb * k.nb) +
-                          (qc_use_mfma(c.LAB, c.LCD) ? 48 : (c.LGC >= 4 ? 0 : nab * qc_nherm(b.L)));
+            // (the bra block is read straight from memory; the matrix-core classes keep a 48-double Hermite index table)
+            const int w = qc_region0(b.L + k.L) + nab * ncd + nab + ncd + 2 * (b.na * k.na + b.na * k.nb + b.nb * k.na + b.nb * k.nb) +
+                          (qc_use_mfma(c.LAB, c.LCD) ? 48 : 0);
             words = std::max(words, w);
         }
         c.slot_words = words;
