@@ -385,7 +385,7 @@ int qc_launch_eri_full(qc_system *S, double *d_out) {
             if (rc != QC_OK) return rc;
             continue;
         }
-        qc_make_slots(S, c.tasks, 0, slots);
+        qc_make_slots(S, c.tasks, 0, false, slots);
         if (slots.empty()) continue;
         QcSlot *d = nullptr;
         QC_HIP_CHECK(hipMalloc(&d, slots.size() * sizeof(QcSlot)));

@@ -298,6 +298,7 @@ __device__ __forceinline__ void qc_fock_body(const QcKernelArgs &a, const QcSlot
         for (int o = 32; o > 0; o >>= 1) maxlen = max(maxlen, __shfl_xor(maxlen, o, 64));
         const double *braBase = pd + pb.doff, *ketBase = pd + pk.doff;
         const int npass = (LGC == 6) ? (ncd + 63) / 64 : 1;  // > 1 only for ket pairs with more than 64 function pairs
+        const int cbeg = active ? sl.c0 : 0, cend = active ? sl.c1 : 0;   // ket columns of this slot (all of them unless the host split the class)
 
         if constexpr (MFMA) {
           // ---- high-order kets (LCD >= 4): both Hermite contractions on the matrix cores.  One slot per wave.
@@ -318,9 +319,8 @@ __device__ __forceinline__ void qc_fock_body(const QcKernelArgs &a, const QcSlot
               n1[mt] = t & 255; s1[mt] = (t >> 8) & 255; v1[mt] = t >> 16;
           }
           const double *__restrict__ pdT = a.pairdataT;
-          for (int pass = 0; pass < npass; ++pass) {
-            const int col0 = pass * 64;
-            const int NT = min(4, (ncd - col0 + 15) / 16);
+          for (int col0 = cbeg; col0 < cend; col0 += 64) {       // this slot's ket columns, 64 at a time
+            const int NT = min(4, (cend - col0 + 15) / 16);
             qc_d4 Wacc[MT][4];
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt)
@@ -330,30 +330,53 @@ __device__ __forceinline__ void qc_fock_body(const QcKernelArgs &a, const QcSlot
             auto flush = [&](int ij) {
                 const double *__restrict__ Et = pdT + pb.doff + (size_t)ij * strideB + 4;     // [ab][h]
                 const int MI = (nab + 15) / 16;
-                for (int it = 0; it < MI; ++it) {
+                // A fragments of row tile `it`: Et[ab][h1], shared by the column tiles (clamped loads, masked to zero
+                // outside the block); the next tile's are requested before this tile's MFMAs
+                auto load_e = [&](int it, double (&av)[MT][4]) {
                     const int ab = 16 * it + i16;
-                    double av[MT][4];                            // A fragments of this row tile: Et[ab][h1], shared by the column tiles
+                    const double *row = Et + (size_t)min(ab, nab - 1) * HAB;
 #pragma unroll
                     for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
                         for (int r = 0; r < 4; ++r) {
                             const int h1 = 16 * mt + 4 * r + q4;
-                            av[mt][r] = (ab < nab && h1 < HAB) ? Et[(size_t)ab * HAB + h1] : 0.0;
+                            const double v = row[min(h1, HAB - 1)];
+                            av[mt][r] = (ab < nab && h1 < HAB) ? v : 0.0;
                         }
+                };
+                constexpr bool AHEAD = MT <= 4;               // (six row tiles of W leave no registers for a second fragment set)
+                double avE[MT][4];
+                if constexpr (AHEAD) load_e(0, avE);
+                for (int it = 0; it < MI; ++it) {
+                    double avN[AHEAD ? MT : 1][4];
+                    if constexpr (AHEAD) load_e(min(it + 1, MI - 1), avN);
+                    else load_e(it, avE);
+                    __builtin_amdgcn_sched_barrier(0);
+                    qc_d4 acc[4];
+#pragma unroll
+                    for (int nt = 0; nt < 4; ++nt) acc[nt] = qc_d4{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r)
+#pragma unroll
+                            for (int nt = 0; nt < 4; ++nt)
+                                if (nt < NT) acc[nt] = __builtin_amdgcn_mfma_f64_16x16x4f64(avE[mt][r], Wacc[mt][nt][r], acc[nt], 0, 0, 0);
 #pragma unroll
                     for (int nt = 0; nt < 4; ++nt) {
                         if (nt >= NT) break;
-                        qc_d4 acc = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-                        for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-                            for (int r = 0; r < 4; ++r) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[mt][r], Wacc[mt][nt][r], acc, 0, 0, 0);
                         const int c = col0 + 16 * nt + i16;
 #pragma unroll
                         for (int r = 0; r < 4; ++r) {
                             const int abr = 16 * it + q4 + 4 * r;
-                            if (abr < nab && c < ncd) Iblk[abr * ncd + c] += acc[r];      // this lane alone owns the element
+                            if (abr < nab && c < cend) Iblk[abr * ncd + c] += acc[nt][r];     // this lane alone owns the element
                         }
+                    }
+                    if constexpr (AHEAD) {
+#pragma unroll
+                        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) avE[mt][r] = avN[mt][r];
                     }
                 }
 #pragma unroll
@@ -375,31 +398,49 @@ __device__ __forceinline__ void qc_fock_body(const QcKernelArgs &a, const QcSlot
                 const double X = cb.y - ck.y, Y = cb.z - ck.z, Z = cb.w - ck.w;
                 const double pref = rsqrt(p + q);
                 const double alpha = p * q * (pref * pref);
-                double F[L + 1];
-                qc_boys<L>(alpha * (X * X + Y * Y + Z * Z), a.boys, F);
-                __syncthreads();                  // previous iteration's readers of Rw are done
-                qc_build_r<L>(Rw, lane, 64, alpha, X, Y, Z, F);
+                // Operand fragments of k-step ks.  B = four column tiles of the ket block (plain loads, clamped: rows past
+                // HCD meet a zero A value, columns past ncd are never read back); A = the gathered, signed R values.
+                // Both are requested one k-step ahead of the MFMAs that consume them, the first B before the R table is built.
                 const double *Ecd = ket + 4;
-                for (int ks = 0; ks < KS; ++ks) {
+                auto load_b = [&](int ks, double (&bv)[4]) {
+                    const int h2 = min(4 * ks + q4, HCD - 1);
+#pragma unroll
+                    for (int nt = 0; nt < 4; ++nt) bv[nt] = Ecd[(size_t)h2 * ncd + min(col0 + 16 * nt + i16, ncd - 1)];
+                };
+                auto load_a = [&](int ks, double (&av)[MT]) {
                     const int h2 = 4 * ks + q4;
                     const bool h2ok = h2 < HCD;
                     const int t2 = tab[h2ok ? h2 : 0];
                     const int n2 = t2 & 255, s2 = (t2 >> 8) & 255, v2 = t2 >> 16;
                     const double sg = h2ok ? ((n2 & 1) ? -pref : pref) : 0.0;      // sign of the ket order, scale, validity
-                    double bv[4];
-#pragma unroll
-                    for (int nt = 0; nt < 4; ++nt) {
-                        const int c = col0 + 16 * nt + i16;
-                        bv[nt] = (h2ok && nt < NT && c < ncd) ? Ecd[(size_t)h2 * ncd + c] : 0.0;
-                    }
 #pragma unroll
                     for (int mt = 0; mt < MT; ++mt) {
                         const int N = n1[mt] + n2, ss = s1[mt] + s2;
-                        const double av = (16 * mt + i16 < HAB) ? sg * Rw[N * (N + 1) * (N + 2) / 6 + ss * (ss + 1) / 2 + v1[mt] + v2] : 0.0;
+                        av[mt] = sg * Rw[N * (N + 1) * (N + 2) / 6 + ss * (ss + 1) / 2 + v1[mt] + v2];
+                    }
+                };
+                double bvA[4], avA[MT];
+                load_b(0, bvA);
+                double F[L + 1];
+                qc_boys<L>(alpha * (X * X + Y * Y + Z * Z), a.boys, F);
+                __syncthreads();                  // previous iteration's readers of Rw are done
+                qc_build_r<L>(Rw, lane, 64, alpha, X, Y, Z, F);
+                load_a(0, avA);
+                for (int ks = 0; ks < KS; ++ks) {
+                    double bvB[4], avB[MT];
+                    const int kn = min(ks + 1, KS - 1);
+                    load_b(kn, bvB);
+                    load_a(kn, avB);
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
                         for (int nt = 0; nt < 4; ++nt)
-                            if (nt < NT) Wacc[mt][nt] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv[nt], Wacc[mt][nt], 0, 0, 0);
-                    }
+                            if (nt < NT) Wacc[mt][nt] = __builtin_amdgcn_mfma_f64_16x16x4f64(avA[mt], bvA[nt], Wacc[mt][nt], 0, 0, 0);
+#pragma unroll
+                    for (int nt = 0; nt < 4; ++nt) bvA[nt] = bvB[nt];
+#pragma unroll
+                    for (int mt = 0; mt < MT; ++mt) avA[mt] = avB[mt];
                 }
                 if (++kl == K_cd) { kl = 0; ++ij; }
             }
@@ -584,16 +625,17 @@ __device__ __forceinline__ void qc_fock_body(const QcKernelArgs &a, const QcSlot
                 double *G0 = a.G0 + rep, *G1 = a.G1 + rep;
                 // J blocks: Gt_ab += 2f sum_cd I D_cd ; Gt_cd += 2f sum_ab I D_ab   (final G = Gt + Gt^T)
                 const double fj = 2.0 * f;
+                // (integrals outside [cbeg, cend) are not this slot's: the loops run over its columns only)
                 for (int ab = li; ab < nab; ab += C) {
                     double s = 0.0;
 #pragma unroll 4
-                    for (int cd = 0; cd < ncd; ++cd) s = fma(Iblk[ab * ncd + cd], tDj_cd[cd], s);
+                    for (int cd = cbeg; cd < cend; ++cd) s = fma(Iblk[ab * ncd + cd], tDj_cd[cd], s);
                     const int r = qc_fdiv(ab, inb);
                     const size_t o = (size_t)(pb.offa + r) * n + pb.offb + ab - r * nb;
                     unsafeAtomicAdd(&G0[o], fj * s);
                     if (uhf) unsafeAtomicAdd(&G1[o], fj * s);
                 }
-                for (int cd = li; cd < ncd; cd += C) {
+                for (int cd = cbeg + li; cd < cend; cd += C) {
                     double s = 0.0;
 #pragma unroll 4
                     for (int ab = 0; ab < nab; ++ab) s = fma(Iblk[ab * ncd + cd], tDj_ab[ab], s);
@@ -609,34 +651,38 @@ __device__ __forceinline__ void qc_fock_body(const QcKernelArgs &a, const QcSlot
                     const double *t_ac = tK + s * ktile, *t_ad = t_ac + na * nc, *t_bc = t_ad + na * nd, *t_bd = t_bc + nb * nc;
                     for (int x = li; x < na * nc; x += C) {          // (i,k) <- sum_{j,l} I[ij,kl] D[j,l]
                         const int i = qc_fdiv(x, inc), k = x - i * nc;
+                        const int l0 = max(0, cbeg - k * nd), l1 = min(nd, cend - k * nd);
                         double acc = 0.0;
                         for (int j = 0; j < nb; ++j)
 #pragma unroll 3
-                            for (int l = 0; l < nd; ++l) acc = fma(Iblk[(i * nb + j) * ncd + k * nd + l], t_bd[j * nd + l], acc);
+                            for (int l = l0; l < l1; ++l) acc = fma(Iblk[(i * nb + j) * ncd + k * nd + l], t_bd[j * nd + l], acc);
                         unsafeAtomicAdd(&Gs[(size_t)(pb.offa + i) * n + pk.offa + k], fk * acc);
                     }
                     for (int x = li; x < na * nd; x += C) {          // (i,l) <- sum_{j,k} I[ij,kl] D[j,k]
                         const int i = qc_fdiv(x, ind), l = x - i * nd;
+                        const int k0 = qc_fdiv(max(0, cbeg - l + nd - 1), ind), k1 = min(nc, qc_fdiv(max(0, cend - l + nd - 1), ind));
                         double acc = 0.0;
                         for (int j = 0; j < nb; ++j)
 #pragma unroll 3
-                            for (int k = 0; k < nc; ++k) acc = fma(Iblk[(i * nb + j) * ncd + k * nd + l], t_bc[j * nc + k], acc);
+                            for (int k = k0; k < k1; ++k) acc = fma(Iblk[(i * nb + j) * ncd + k * nd + l], t_bc[j * nc + k], acc);
                         unsafeAtomicAdd(&Gs[(size_t)(pb.offa + i) * n + pk.offb + l], fk * acc);
                     }
                     for (int x = li; x < nb * nc; x += C) {          // (j,k) <- sum_{i,l} I[ij,kl] D[i,l]
                         const int j = qc_fdiv(x, inc), k = x - j * nc;
+                        const int l0 = max(0, cbeg - k * nd), l1 = min(nd, cend - k * nd);
                         double acc = 0.0;
                         for (int i = 0; i < na; ++i)
 #pragma unroll 3
-                            for (int l = 0; l < nd; ++l) acc = fma(Iblk[(i * nb + j) * ncd + k * nd + l], t_ad[i * nd + l], acc);
+                            for (int l = l0; l < l1; ++l) acc = fma(Iblk[(i * nb + j) * ncd + k * nd + l], t_ad[i * nd + l], acc);
                         unsafeAtomicAdd(&Gs[(size_t)(pb.offb + j) * n + pk.offa + k], fk * acc);
                     }
                     for (int x = li; x < nb * nd; x += C) {          // (j,l) <- sum_{i,k} I[ij,kl] D[i,k]
                         const int j = qc_fdiv(x, ind), l = x - j * nd;
+                        const int k0 = qc_fdiv(max(0, cbeg - l + nd - 1), ind), k1 = min(nc, qc_fdiv(max(0, cend - l + nd - 1), ind));
                         double acc = 0.0;
                         for (int i = 0; i < na; ++i)
 #pragma unroll 3
-                            for (int k = 0; k < nc; ++k) acc = fma(Iblk[(i * nb + j) * ncd + k * nd + l], t_ac[i * nc + k], acc);
+                            for (int k = k0; k < k1; ++k) acc = fma(Iblk[(i * nb + j) * ncd + k * nd + l], t_ac[i * nc + k], acc);
                         unsafeAtomicAdd(&Gs[(size_t)(pb.offb + j) * n + pk.offb + l], fk * acc);
                     }
                 }

@@ -64,7 +64,7 @@ struct QcPairDesc {
 };
 
 struct QcTask { int bra, ket; };  // pair indices; (bra|ket) is one unique shell quartet
-struct QcSlot { int bra, ket, lo, hi; };  // a quartet restricted to primitive quartets [lo, hi): the kernels' work unit
+struct QcSlot { int bra, ket, lo, hi, c0, c1; };  // a quartet restricted to primitive quartets [lo, hi) and ket columns [c0, c1): the kernels' work unit
 // Work unit of the bra-major kernels (narrow kets, qc_fock_bm.hip): one wave = one bra pair restricted to the bra
 // primitive pairs [ij_lo, ij_hi), against up to 64 ket pairs (one per lane) ketlist[first .. first + nket).
 struct QcBundle { int bra, ij_lo, ij_hi, first, nket, maxK, pad0, pad1; };
@@ -190,7 +190,7 @@ inline int qc_shard_owner(size_t i, int nranks, size_t ci) {
     const size_t r = (round & 1) ? (nranks - 1 - pos) : pos;
     return (int)((r + ci) % nranks);
 }
-void qc_make_slots(const qc_system *S, const std::vector<QcTask> &tasks, int itmax, std::vector<QcSlot> &out);
+void qc_make_slots(const qc_system *S, const std::vector<QcTask> &tasks, int itmax, bool split_cols, std::vector<QcSlot> &out);
 // group tasks by bra into bundles of <= 64 kets (sorted by primitive count); itmax > 0 also cuts the bra primitive range
 void qc_make_bundles(const qc_system *S, const std::vector<QcTask> &tasks, int itmax, std::vector<QcBundle> &bundles, std::vector<int> &ketlist);
 inline int qc_unit_of(int LAB, int LCD, bool bm) { return bm ? 2 * (QC_LPAIR + 1) + 2 * LCD + (LAB >= 3 ? 1 : 0) : 2 * LAB + (LCD >= 4 ? 1 : 0); }

@@ -299,16 +299,19 @@ int qc_lgc_for(int lab, int lcd, int ncd) {
 }
 
 // Cut quartets into slots of at most `itmax` primitive quartets; longest first so the slots batched into one wave
-// have (nearly) equal trip counts.
-void qc_make_slots(const qc_system *S, const std::vector<QcTask> &tasks, int itmax, std::vector<QcSlot> &out) {
+// have (nearly) equal trip counts.  With `split_cols` (matrix-core classes that cannot fill the chip) a slot is further
+// cut into the 16-column tiles of the ket block: the integrals of different ket columns are independent all the way into
+// the digestion, so a single (ff|ff) quartet is then worked on by four waves (each repeats the R table, none waits).
+void qc_make_slots(const qc_system *S, const std::vector<QcTask> &tasks, int itmax, bool split_cols, std::vector<QcSlot> &out) {
     out.clear();
     for (const auto &t : tasks) {
-        const int npq = S->pairs[t.bra].K * S->pairs[t.ket].K;
+        const int npq = S->pairs[t.bra].K * S->pairs[t.ket].K, ncd = S->pairs[t.ket].na * S->pairs[t.ket].nb;
         const int step = itmax > 0 ? itmax : npq;
         const int nparts = (npq + step - 1) / step;
+        const int ctile = split_cols ? 16 : ncd;
         for (int s = 0; s < nparts; ++s) {   // equal-length parts
             const int lo = (int)((int64_t)npq * s / nparts), hi = (int)((int64_t)npq * (s + 1) / nparts);
-            out.push_back(QcSlot{t.bra, t.ket, lo, hi});
+            for (int c0 = 0; c0 < ncd; c0 += ctile) out.push_back(QcSlot{t.bra, t.ket, lo, hi, c0, std::min(ncd, c0 + ctile)});
         }
     }
     std::stable_sort(out.begin(), out.end(), [](const QcSlot &x, const QcSlot &y) { return x.hi - x.lo > y.hi - y.lo; });
@@ -375,7 +378,11 @@ void qc_build_shards(qc_system *S) {
             for (const auto &t : c.shard) c.bm_rows = std::max(c.bm_rows, S->pairs[t.bra].na + S->pairs[t.bra].nb);
             qc_make_bundles(S, c.shard, itmax, c.bundles, c.ketlist);
         }
-        else qc_make_slots(S, c.shard, itmax, c.slots);
+        else {
+            qc_make_slots(S, c.shard, itmax, false, c.slots);
+            // a matrix-core class (one slot per wave) with fewer slots than the chip has SIMDs: one wave per 16-column tile
+            if (qc_use_mfma(c.LAB, c.LCD) && c.LGC == 6 && c.slots.size() * 4 <= 1024) qc_make_slots(S, c.shard, itmax, true, c.slots);
+        }
         c.prim_quartets = 0; c.bytes_alg = 0; c.flops_alg = 0;
         int words = 0;
         for (const auto &t : c.shard) {
