@@ -172,7 +172,8 @@ int roothaan_enqueue(qc_system *S, ScfWork &W, DeviceDiis &diis, const double *d
             rc = qc_eig_refine_async(st, n, W.Fps[spin].p, W.CpNew[spin].p, W.CpNew[spin].p, dw_out, W.ework.p, W.t1.p, W.t2.p, W.t3.p, W.t4.p,
                                      W.small.p, W.ctl + 4 * spin, 3);
     } else if (W.have_prev[spin])           // first passes, density far from converged: warm-started Jacobi to convergence
-        rc = qc_eig_device_warm(st, n, W.Fps[spin].p, W.CpPrev[spin].p, W.CpNew[spin].p, dw_out, W.ework.p, W.t1.p, W.t2.p);
+        // (the density still moves by O(1) per element here: a sweep that met couplings below 1e-5 leaves 1e-10, far below that)
+        rc = qc_eig_device_warm(st, n, W.Fps[spin].p, W.CpPrev[spin].p, W.CpNew[spin].p, dw_out, W.ework.p, W.t1.p, W.t2.p, 40, 1e-5);
     else rc = device_sorted_eigs(S, W, W.Fps[spin].p, W.CpNew[spin].p, dw_out);          // sorted_eigs (rhf.rs:75), cold
     if (rc != QC_OK) return rc;
     qc_gemm(st, n, n, n, 1.0, W.X.p, n, false, W.CpNew[spin].p, n, false, 0.0, dC, n);   // C = X C'

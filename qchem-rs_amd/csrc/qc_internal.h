@@ -171,9 +171,10 @@ int qc_eig_refine_async(hipStream_t st, int n, double *dA, const double *dV0, do
                         double *t3, double *t4, double *small, int *ctl, int npass);
 void qc_diis_solve(hipStream_t st, int m, int minlen, int maxlen, const int *slots, const double *dots, double *B, double *c, int *flag);
 void qc_lincomb_dev(hipStream_t st, int n, const double *const *Fs, const double *c_dev, int m, double *out);
-int qc_eig_device(hipStream_t st, int n, double *dA /*destroyed*/, double *dV, double *dw, double *d_work, int max_sweeps = 40);
+// done_tol: the sweeps end after one that met no relative coupling above it (the sweep itself leaves ~done_tol^2 behind)
+int qc_eig_device(hipStream_t st, int n, double *dA /*destroyed*/, double *dV, double *dw, double *d_work, int max_sweeps = 40, double done_tol = 1e-9);
 int qc_eig_device_warm(hipStream_t st, int n, double *dA, const double *dV0, double *dV, double *dw, double *d_work, double *t1, double *t2,
-                       int max_sweeps = 40);
+                       int max_sweeps = 40, double done_tol = 1e-9);
 int qc_eig_device_refine(hipStream_t st, int n, double *dA, const double *dV0, double *dV, double *dw, double *d_work, double *t1, double *t2,
                          double *t3, double *t4, double *small);
 void qc_permute_tensor(hipStream_t st, int n, const double *I, double c_direct, double c_exch, double *T);

@@ -95,7 +95,7 @@ __device__ __forceinline__ void qc_rr_pair(int step, int k, int m, int &p, int &
 
 template <bool V_IN_LDS>
 __global__ __launch_bounds__(QC_EIG_THREADS) void qc_jacobi_kernel(int n, const double *__restrict__ Ain, double *__restrict__ Vg,
-                                                                   double *__restrict__ Vout, double *__restrict__ w, int max_sweeps) {
+                                                                   double *__restrict__ Vout, double *__restrict__ w, int max_sweeps, double done_tol) {
     extern __shared__ double sm[];
     const int m = (n + 1) & ~1, half = m / 2, ld = m | 1;
     double *A = sm;                                         // m x ld (padding row/column stay zero => identity rotations)
@@ -172,8 +172,8 @@ __global__ __launch_bounds__(QC_EIG_THREADS) void qc_jacobi_kernel(int n, const 
         double off2 = 0.0;
         for (int k = 0; k < nt / 64; ++k) off2 += red[k];
         __syncthreads();
-        // Jacobi converges quadratically: a sweep that met a relative off-norm <= 1e-9 leaves <= ~1e-18 behind
-        if (2.0 * off2 <= 1e-18 * normF2) break;
+        // Jacobi converges quadratically: a sweep that met a relative off-norm <= done_tol (1e-9) leaves <= ~done_tol^2 behind
+        if (2.0 * off2 <= done_tol * done_tol * normF2) break;
     }
     // ascending order (utils.rs:28): rank sort, then permute columns
     for (int i = tid; i < n; i += nt) {
@@ -220,7 +220,7 @@ __device__ __forceinline__ double qc_hestenes_rotation(double a, double b, doubl
 }
 
 __global__ __launch_bounds__(QC_EIG1_THREADS) void qc_jacobi1_kernel(int n, const double *__restrict__ Ain, double *__restrict__ Vout,
-                                                                    double *__restrict__ w, int max_sweeps) {
+                                                                    double *__restrict__ w, int max_sweeps, double done_tol) {
     extern __shared__ double sm[];
     const int m = (n + 1) & ~1, half = m / 2, ld = n | 1;        // column stride (doubles)
     double *G = sm;                                               // m columns x ld (padding column stays zero)
@@ -278,7 +278,7 @@ __global__ __launch_bounds__(QC_EIG1_THREADS) void qc_jacobi1_kernel(int n, cons
                         const int r = tl + k * QC_EIG1_TEAM;
                         if (r < n) { gp[r] = cs * xp[k] - sn * xq[k]; gq[r] = sn * xp[k] + cs * xq[k]; }
                     }
-                    if (tl == 0 && rel > 1e-9) *flag = 1;         // quadratic convergence: pairs below 1e-9 are done after this rotation
+                    if (tl == 0 && rel > done_tol) *flag = 1;     // quadratic convergence: pairs below done_tol (1e-9) are done after this rotation
                 }
             }
             __syncthreads();
@@ -316,7 +316,7 @@ __global__ __launch_bounds__(QC_EIG1_THREADS) void qc_jacobi1_kernel(int n, cons
 // behind a workgroup barrier per step) but only the cold start and the rare fallback of the refinement use it; the SCF
 // loop's eigensolves are GEMMs (qc_eig_device_refine).  Keeps every shipped basis (benzene/6-311++G**: n = 180) usable.
 __global__ __launch_bounds__(QC_EIG_THREADS) void qc_jacobi1g_kernel(int n, const double *__restrict__ Ain, double *__restrict__ G,
-                                                                     double *__restrict__ Vout, double *__restrict__ w, int max_sweeps) {
+                                                                     double *__restrict__ Vout, double *__restrict__ w, int max_sweeps, double done_tol) {
     extern __shared__ double sm[];
     __shared__ double red[32];
     __shared__ int flag;
@@ -364,7 +364,7 @@ __global__ __launch_bounds__(QC_EIG_THREADS) void qc_jacobi1g_kernel(int n, cons
                     const double t = (zeta >= 0.0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(fma(zeta, zeta, 1.0)));
                     const double cs = 1.0 / sqrt(fma(t, t, 1.0)), sn = cs * t;
                     for (int r = tl; r < n; r += QC_EIG1_TEAM) { const double xp = gp[r], xq = gq[r]; gp[r] = cs * xp - sn * xq; gq[r] = sn * xp + cs * xq; }
-                    if (tl == 0 && rel > 1e-9) flag = 1;
+                    if (tl == 0 && rel > done_tol) flag = 1;
                 }
             }
             __syncthreads();
@@ -396,7 +396,7 @@ __global__ __launch_bounds__(QC_EIG_THREADS) void qc_jacobi1g_kernel(int n, cons
 }
 
 // dA: input (left intact), dV: sorted eigenvectors, dw: eigenvalues, d_work: n*n scratch
-int qc_eig_device(hipStream_t st, int n, double *dA, double *dV, double *dw, double *d_work, int max_sweeps) {
+int qc_eig_device(hipStream_t st, int n, double *dA, double *dV, double *dw, double *d_work, int max_sweeps, double done_tol) {
     const int m = (n + 1) & ~1, ld = m | 1;
     const size_t tail = (2 * (m / 2) + 32) * sizeof(double) + (size_t)m * sizeof(int) + 16;
     const size_t lds2 = 2 * (size_t)m * ld * sizeof(double) + tail, lds1 = (size_t)m * ld * sizeof(double) + tail;
@@ -407,14 +407,14 @@ int qc_eig_device(hipStream_t st, int n, double *dA, double *dV, double *dw, dou
         if (l1 <= 160 * 1024) {
             hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(qc_jacobi1_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)l1);
             if (e != hipSuccess) return QC_ERR_HIP;
-            hipLaunchKernelGGL(qc_jacobi1_kernel, dim3(1), dim3(QC_EIG1_THREADS), l1, st, n, dA, dV, dw, max_sweeps);
+            hipLaunchKernelGGL(qc_jacobi1_kernel, dim3(1), dim3(QC_EIG1_THREADS), l1, st, n, dA, dV, dw, max_sweeps, done_tol);
             return hipGetLastError() == hipSuccess ? QC_OK : QC_ERR_HIP;
         }
     }
     const size_t lds = v_in_lds ? lds2 : lds1;
     if (lds > 160 * 1024 || !v_in_lds) {                // n > 128: the global-memory variant
         if (n > 3000) return QC_ERR_UNSUPPORTED;
-        hipLaunchKernelGGL(qc_jacobi1g_kernel, dim3(1), dim3(QC_EIG_THREADS), (size_t)n * 12 + 16, st, n, dA, d_work, dV, dw, max_sweeps);
+        hipLaunchKernelGGL(qc_jacobi1g_kernel, dim3(1), dim3(QC_EIG_THREADS), (size_t)n * 12 + 16, st, n, dA, d_work, dV, dw, max_sweeps, done_tol);
         return hipGetLastError() == hipSuccess ? QC_OK : QC_ERR_HIP;
     }
     auto kern = v_in_lds ? qc_jacobi_kernel<true> : qc_jacobi_kernel<false>;
@@ -423,7 +423,7 @@ int qc_eig_device(hipStream_t st, int n, double *dA, double *dV, double *dw, dou
         if (e != hipSuccess) return QC_ERR_HIP;
     }
     static const int nthreads = getenv("QC_EIG_THREADS") ? atoi(getenv("QC_EIG_THREADS")) : QC_EIG_THREADS;
-    hipLaunchKernelGGL(kern, dim3(1), dim3(nthreads), lds, st, n, dA, d_work, dV, dw, max_sweeps);
+    hipLaunchKernelGGL(kern, dim3(1), dim3(nthreads), lds, st, n, dA, d_work, dV, dw, max_sweeps, done_tol);
     return hipGetLastError() == hipSuccess ? QC_OK : QC_ERR_HIP;
 }
 
@@ -431,10 +431,10 @@ int qc_eig_device(hipStream_t st, int n, double *dA, double *dV, double *dw, dou
 // B = V0^T A V0 is nearly diagonal, Jacobi needs 1-3 sweeps instead of ~8, and V = V0 Q.  The three products are
 // f64 MFMA GEMMs.  t1/t2: n*n scratch each.
 int qc_eig_device_warm(hipStream_t st, int n, double *dA, const double *dV0, double *dV, double *dw, double *d_work, double *t1, double *t2,
-                       int max_sweeps) {
+                       int max_sweeps, double done_tol) {
     qc_gemm(st, n, n, n, 1.0, dA, n, false, dV0, n, false, 0.0, t1, n);        // A V0
     qc_gemm(st, n, n, n, 1.0, dV0, n, true, t1, n, false, 0.0, t2, n);         // V0^T (A V0)
-    int rc = qc_eig_device(st, n, t2, t1, dw, d_work, max_sweeps);             // Q -> t1
+    int rc = qc_eig_device(st, n, t2, t1, dw, d_work, max_sweeps, done_tol);   // Q -> t1
     if (rc != QC_OK) return rc;
     qc_gemm(st, n, n, n, 1.0, dV0, n, false, t1, n, false, 0.0, dV, n);        // V = V0 Q
     return QC_OK;
