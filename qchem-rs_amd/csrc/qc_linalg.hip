@@ -206,17 +206,22 @@ constexpr int QC_EIG1_TEAM = 8;
 constexpr int QC_EIG1_ROWS = 128 / QC_EIG1_TEAM;       // rows per lane of the LDS variant (n <= 128)
 constexpr int QC_EIG1_THREADS = 64 * QC_EIG1_TEAM;     // 64 teams: one per column pair
 
-// Jacobi rotation (c, s) that orthogonalises two columns with squared norms a, b and inner product g; returns the
-// relative coupling |g| / sqrt(a b).
-__device__ __forceinline__ double qc_hestenes_rotation(double a, double b, double g, double &cs, double &sn) {
-    const double rel = fabs(g) * rsqrt(a * b);
-    const double zeta = (b - a) * (0.5 / g);
+// 1 / x to a few ulp: hardware estimate + two Newton steps (the IEEE division sequence is twice as long, and every lane of a
+// team runs this chain between the barriers of a step)
+__device__ __forceinline__ double qc_fast_rcp(double x) {
+    double r = __builtin_amdgcn_rcp(x);
+    r = fma(fma(-x, r, 1.0), r, r);
+    return fma(fma(-x, r, 1.0), r, r);
+}
+// Jacobi rotation (c, s) that orthogonalises two columns with squared norms a, b and inner product g.  c^2 + s^2 = 1 holds to
+// the accuracy of rsqrt whatever the error of t, so the reciprocal shortcuts cost nothing in orthonormality.
+__device__ __forceinline__ void qc_hestenes_rotation(double a, double b, double g, double &cs, double &sn) {
+    const double zeta = (b - a) * (0.5 * qc_fast_rcp(g));
     const double z2 = fma(zeta, zeta, 1.0);
     const double den = fabs(zeta) + z2 * rsqrt(z2);            // |zeta| + sqrt(zeta^2 + 1)
-    const double t = (zeta >= 0.0 ? 1.0 : -1.0) / den;
+    const double t = (zeta >= 0.0 ? 1.0 : -1.0) * qc_fast_rcp(den);
     cs = rsqrt(fma(t, t, 1.0));
     sn = cs * t;
-    return rel;
 }
 
 __global__ __launch_bounds__(QC_EIG1_THREADS) void qc_jacobi1_kernel(int n, const double *__restrict__ Ain, double *__restrict__ Vout,
@@ -272,13 +277,14 @@ __global__ __launch_bounds__(QC_EIG1_THREADS) void qc_jacobi1_kernel(int n, cons
                 }
                 if (c * c > 1e-32 * (a * b)) {                     // team-uniform: |c| / sqrt(a b) > 1e-16
                     double cs, sn;
-                    const double rel = qc_hestenes_rotation(a, b, c, cs, sn);
+                    qc_hestenes_rotation(a, b, c, cs, sn);
 #pragma unroll
                     for (int k = 0; k < QC_EIG1_ROWS; ++k) {
                         const int r = tl + k * QC_EIG1_TEAM;
                         if (r < n) { gp[r] = cs * xp[k] - sn * xq[k]; gq[r] = sn * xp[k] + cs * xq[k]; }
                     }
-                    if (tl == 0 && rel > done_tol) *flag = 1;     // quadratic convergence: pairs below done_tol (1e-9) are done after this rotation
+                    // quadratic convergence: pairs whose relative coupling |c| / sqrt(a b) is below done_tol (1e-9) are done after this rotation
+                    if (tl == 0 && c * c > done_tol * done_tol * (a * b)) *flag = 1;
                 }
             }
             __syncthreads();
