@@ -98,3 +98,15 @@ def test_invalid_inputs_are_rejected():
     bad_atom = np.array([3], np.int32)
     rc = L.qc_system_create(1, Z, xyz, 1, bad_atom, one, one, npr, e, c, ctypes.byref(h))
     assert rc == q.hf.QC_ERR_INVALID
+
+
+def test_reciprocal_index_division_is_exact_on_the_kernels_range():
+    """qc_fdiv (qc_fock_kernel.h): floor(x / d) as (int)((float(x) + 0.5f) * inv) with inv = v_rcp_f32(d), which may be one ulp
+    off either way.  The staging / digestion loops of the column kernels divide indices below n_ab * n_cd <= 3 600 by function
+    counts <= 100; the identity is checked here, in IEEE float32 arithmetic, on a range sixteen times that."""
+    x = np.arange(0, 65536, dtype=np.int64)
+    xf = x.astype(np.float32) + np.float32(0.5)
+    for d in range(1, 129):
+        inv0 = np.float32(1.0) / np.float32(d)
+        for inv in (inv0, np.nextafter(inv0, np.float32(0)), np.nextafter(inv0, np.float32(2))):
+            assert np.array_equal((xf * inv).astype(np.int64), x // d), d
