@@ -386,3 +386,33 @@ def test_stored_tensor_mode_uhf_triplet():
 def test_not_converged_returns_none():
     q, s, o = _sys("water", "STO-3G")
     assert q.restricted_hartree_fock(s, q.HartreeFockConfig(max_iterations=1, epsilon=1e-14)) is None
+
+
+def test_cli_rhf_and_uhf_end_to_end(capsys):
+    """`qchem-hip`: the reference's command line through the loaders, the C ABI and the kernels; the printed
+    three-decimal values are the oracle's, the opt-in extension (charge / multiplicity) reports <S^2> of triplet O2."""
+    import os
+    import qchem_rs_amd  # noqa: F401
+    from qchem_rs_amd import cli
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    b = lambda n: os.path.join(root, "data", "basis", n + ".json")
+    m = lambda n: os.path.join(root, "data", "mol", n + ".json")
+    q, s, o = _sys("water", "STO-3G")
+    ref = o.rhf(100, 1e-6)
+    s.close()
+    assert cli.main(["rhf", "-b", b("STO-3G"), "-m", m("water")]) == 0
+    lines = capsys.readouterr().out.splitlines()
+    assert lines[0].startswith("hartree fock converged after %d iterations and " % ref["iterations"])
+    assert lines[3] == "hartree fock energy: %.3f" % ref["total_energy"]
+    assert lines[4] == "orbital energies: [" + ", ".join("%.3f" % w for w in ref["orbital_energies"]) + "]"
+    assert cli.main(["uhf", "-b", b("cc-pVDZ"), "-m", m("oxygen"), "-s", "3", "--json"]) == 0
+    lines = capsys.readouterr().out.splitlines()
+    import json
+    doc = json.loads(lines[-1])
+    assert (doc["n_alpha"], doc["n_beta"]) == (9, 7) and 2.0 < doc["spin_square"] < 2.1
+    q, s, o = _sys("oxygen", "cc-pVDZ")
+    ref = o.uhf(100, 1e-6, n_alpha=9, n_beta=7)
+    s.close()
+    assert lines[-2].startswith("<S^2>: 2.0") and abs(doc["total_energy"] - ref["total_energy"]) < 1e-5
+    assert doc["iterations"] == ref["iterations"]
+    assert cli.main(["rhf", "-b", b("STO-3G"), "-m", m("water"), "--max-iterations", "1", "--epsilon", "1e-14"]) == 101
