@@ -246,10 +246,10 @@ __device__ __forceinline__ void qc_fock_body(const QcKernelArgs &a, const QcSlot
     const int n = a.n;
     const bool uhf = a.Dk1 != nullptr;
     constexpr bool HOIST = qc_hoisted(L);
-    constexpr int CH = QC_HOIST_CHUNK;                    // primitive quartets per chunk of the hoisted path
+    constexpr int CH = qc_hoist_chunk(L, LGC);                  // primitive quartets per chunk of the hoisted path
     constexpr int NHP = qc_nherm(L) | 1;                    // padded table length of the hoisted path
     double *const Rw = lds + (size_t)g * slot_words;       // this group's private LDS region
-    double *const Iblk = Rw + qc_region0(L);
+    double *const Iblk = Rw + qc_region0(L, LGC);
     const size_t rep = (size_t)(blk % a.nrep) * a.rep_stride;   // accumulation replica of this workgroup
     constexpr bool MFMA = qc_use_mfma(LAB, LCD) && LGC == 6;   // contractions on the matrix cores (one slot per wave)
     if constexpr (MFMA) {

@@ -15,12 +15,14 @@ constexpr int QC_LTOT = 4 * QC_LMAX;    // highest Hermite order of an ERI
 constexpr int QC_SLOT_ITMAX = 128;
 constexpr int QC_LREG = 4;               // total Hermite orders up to this keep the R table in registers (bra-major kernels; Boys branch)
 constexpr int QC_LHOIST_DPP = 6;         // column kernels: up to this the lanes of a group evaluate several primitive quartets' tables at once
-constexpr int QC_HOIST_CHUNK = 8;        // ... this many per chunk (the parked tables limit the resident waves)
+// ... this many per chunk: the parked tables limit the resident waves, and with four groups per wave (16-lane groups) at L = 5
+// ((pp|dp), the largest such class) four tables beat eight by 13 %; elsewhere eight win by 3 %
+__host__ __device__ constexpr int qc_hoist_chunk(int L, int lgc) { return (L == 5 && lgc == 4) ? 4 : 8; }
 __host__ __device__ constexpr bool qc_hoisted(int L) { return L <= QC_LHOIST_DPP; }
 // doubles at the head of a lane group's LDS region: the hoisted register tables of one chunk + their (pref, ij/kl)
 // records, or the cooperative R work array
-__host__ __device__ constexpr int qc_region0(int L) {
-    return qc_hoisted(L) ? QC_HOIST_CHUNK * ((((L + 1) * (L + 2) * (L + 3) / 6) | 1) + 2) : (L + 1) * (L + 2) * (L + 3) * (L + 4) / 24;
+__host__ __device__ constexpr int qc_region0(int L, int lgc) {
+    return qc_hoisted(L) ? qc_hoist_chunk(L, lgc) * ((((L + 1) * (L + 2) * (L + 3) / 6) | 1) + 2) : (L + 1) * (L + 2) * (L + 3) * (L + 4) / 24;
 }
       // primitive quartets per slot
 constexpr double QC_PRIM_CUTOFF = 1e-17; // primitive pairs whose Hermite expansion block is entirely below this are dropped
