@@ -7,18 +7,22 @@
 // coefficients folded in; Rmat[h1][h2] = (-1)^{|h2|} R_{h1+h2}) and immediately contracted with the density into the
 // six J/K blocks.  f64 throughout.
 //
-// Work unit = "slot": one shell quartet (bra pair | ket pair) restricted to a range of its primitive quartets (deeply
-// contracted quartets are cut into several slots so no lane group runs a long sequential loop; digestion is linear,
-// every slot digests its own partial block).
+// Work unit = "slot": one shell quartet (bra pair | ket pair) restricted to a range of its primitive quartets and,
+// for the small matrix-core classes, to one 16-column tile of its ket block (deeply contracted quartets are cut into
+// several slots so no lane group runs a long sequential loop; digestion is linear, every slot digests its own partial block).
 // Mapping (one wave = one workgroup, grid-stride over batches of G slots of one launch bucket (LAB, LCD, C)):
-//   lanes = G groups x C columns, C = pow2 >= n_cd (ket function pairs), G = 64 / C; group g works on slot g of the
-//   batch, completely independently of the other groups (own LDS region, own descriptors, own digestion).
-//   * a lane owns one ket column cd: its ket expansion column e[HCD] and the half-contracted W[HAB] live in VGPRs;
-//   * for (ss|ss) this is one primitive-quartet stream per lane (64 quartets per wave), for the high-L classes one
-//     quartet per wave with the R table shared by 64 columns;
-//   * R tables are built cooperatively by the C lanes of a group in LDS; step 2 reads each R_s once (gen_step2.py);
+//   lanes = G groups x C columns, C = 16, 32 or 64 >= n_cd (ket function pairs; wider kets take several column passes),
+//   G = 64 / C; group g works on slot g of the batch, completely independently of the other groups (own LDS region, own
+//   descriptors, own digestion).  A group is made of whole 16-lane rows because
+//   * a lane owns one ket column cd and keeps the half-contracted W[HAB] in VGPRs, and both Hermite contractions are
+//     `v_fmac_f64_dpp ... row_newbcast` FMAs: the operand common to the group (an R value in step 2, a bra expansion
+//     coefficient in step 3) sits in one lane of each row and is broadcast by the instruction itself, no LDS traffic;
+//   * R tables: for L <= 6 the lanes of a group evaluate several primitive quartets' tables at once in registers
+//     (generated recursion, gen_step2.py) and park them in LDS; above, one table per primitive quartet is built
+//     cooperatively; classes with an fd / ff ket and a bra of L >= 3 run both contractions as f64 MFMA tiles instead;
 //   * the contracted block I[ab][cd] lives in the group's LDS region, density tiles are staged next to it, and the six
-//     J/K block updates are reduced over LDS and flushed with global_atomic_add_f64 into one of `nrep` replicas.
+//     J/K block updates are flushed with global_atomic_add_f64 into one of `nrep` replicas.
+// (The classes with an ss / ps ket and L <= 4 - one whole quartet per lane - are the bra-major kernels, qc_fock_bm.hip.)
 #pragma once
 #include "qc_internal.h"
 #include <utility>
