@@ -274,9 +274,23 @@ int qc_launch_fock_classes(qc_system *S, const QcFockArgs &fa, float *class_ms, 
     auto launch_concurrent = [&](hipEvent_t *ev, bool per_unit) -> int {
         if (ev) QC_HIP_CHECK(hipEventRecord(ev[0], S->stream));
         QC_HIP_CHECK(hipEventRecord(S->ev_fork, S->stream));
+        // Issue order (the host needs ~8 us per launch, so it matters): inside a stream heaviest first; across streams the
+        // first launch of every stream before any second one, streams in the order of their total load - the chain that
+        // ends the build gets going first and no stream sits empty while another one's queue is being filled.
         std::vector<int> order;
-        for (size_t u = 0; u < units.size(); ++u) if (!units[u].empty()) order.push_back((int)u);
-        std::stable_sort(order.begin(), order.end(), [&](int x, int y) { return S->unit_weight[x] > S->unit_weight[y]; });
+        {
+            std::vector<int> byw;
+            for (size_t u = 0; u < units.size(); ++u) if (!units[u].empty()) byw.push_back((int)u);
+            std::stable_sort(byw.begin(), byw.end(), [&](int x, int y) { return S->unit_weight[x] > S->unit_weight[y]; });
+            std::vector<int> q[QC_NSTREAMS];
+            float load[QC_NSTREAMS] = {};
+            for (int u : byw) { q[S->unit_stream[u]].push_back(u); load[S->unit_stream[u]] += S->unit_weight[u]; }
+            int ks[QC_NSTREAMS];
+            for (int k = 0; k < QC_NSTREAMS; ++k) ks[k] = k;
+            std::stable_sort(ks, ks + QC_NSTREAMS, [&](int x, int y) { return load[x] > load[y]; });
+            for (size_t pos = 0; order.size() < byw.size(); ++pos)
+                for (int k : ks) if (pos < q[k].size()) order.push_back(q[k][pos]);
+        }
         bool used[QC_NSTREAMS] = {};
         for (int u : order) {
             const int k = S->unit_stream[u];
