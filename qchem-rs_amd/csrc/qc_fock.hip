@@ -278,6 +278,7 @@ int qc_launch_fock_classes(qc_system *S, const QcFockArgs &fa, float *class_ms, 
         // first launch of every stream before any second one, streams in the order of their total load - the chain that
         // ends the build gets going first and no stream sits empty while another one's queue is being filled.
         std::vector<int> order;
+        int kmain = 0;
         {
             std::vector<int> byw;
             for (size_t u = 0; u < units.size(); ++u) if (!units[u].empty()) byw.push_back((int)u);
@@ -290,19 +291,21 @@ int qc_launch_fock_classes(qc_system *S, const QcFockArgs &fa, float *class_ms, 
             std::stable_sort(ks, ks + QC_NSTREAMS, [&](int x, int y) { return load[x] > load[y]; });
             for (size_t pos = 0; order.size() < byw.size(); ++pos)
                 for (int k : ks) if (pos < q[k].size()) order.push_back(q[k][pos]);
+            kmain = ks[0];
         }
+        // the most loaded chain runs on the handle's own stream: no fork hop before it, no join after it
         bool used[QC_NSTREAMS] = {};
         for (int u : order) {
             const int k = S->unit_stream[u];
-            hipStream_t st = S->side[k];
-            if (!used[k]) { QC_HIP_CHECK(hipStreamWaitEvent(st, S->ev_fork, 0)); used[k] = true; }
+            hipStream_t st = k == kmain ? S->stream : S->side[k];
+            if (!used[k]) { if (k != kmain) QC_HIP_CHECK(hipStreamWaitEvent(st, S->ev_fork, 0)); used[k] = true; }
             if (ev && per_unit) QC_HIP_CHECK(hipEventRecord(ev[2 + 2 * u], st));
             int rc = launch_segments(S, u, segs_of(units[u]), st, a);
             if (rc != QC_OK) return rc;
             if (ev && per_unit) QC_HIP_CHECK(hipEventRecord(ev[3 + 2 * u], st));
         }
         for (int k = 0; k < QC_NSTREAMS; ++k) {
-            if (!used[k]) continue;
+            if (!used[k] || k == kmain) continue;
             QC_HIP_CHECK(hipEventRecord(S->ev_join[k], S->side[k]));
             QC_HIP_CHECK(hipStreamWaitEvent(S->stream, S->ev_join[k], 0));
         }
