@@ -840,16 +840,26 @@ void qc_count_diff(hipStream_t st, size_t count, const double *a, const double *
 }
 
 // Gt[0][x] += sum_{r>0} Gt[r][x]: folds the accumulation replicas of the Fock build
+// (a small matrix gives only a dozen workgroups, so the kernel is as long as its chain of loads: eight replicas are requested
+// at a time - four independent partial sums, combined in a fixed order)
 __global__ void qc_reduce_replicas_kernel(size_t count, int nrep, size_t stride, double *Gt) {
     for (size_t x = blockIdx.x * (size_t)blockDim.x + threadIdx.x; x < count; x += (size_t)gridDim.x * blockDim.x) {
-        double s = Gt[x];
-        for (int r = 1; r < nrep; ++r) s += Gt[r * stride + x];
-        Gt[x] = s;
+        double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+        int r = 0;
+        for (; r + 8 <= nrep; r += 8) {
+            const double *g = Gt + (size_t)r * stride + x;
+            const double a0 = g[0], a1 = g[stride], a2 = g[2 * stride], a3 = g[3 * stride];
+            const double a4 = g[4 * stride], a5 = g[5 * stride], a6 = g[6 * stride], a7 = g[7 * stride];
+            s0 += a0; s1 += a1; s2 += a2; s3 += a3;
+            s0 += a4; s1 += a5; s2 += a6; s3 += a7;
+        }
+        for (; r < nrep; ++r) s0 += Gt[(size_t)r * stride + x];
+        Gt[x] = (s0 + s1) + (s2 + s3);
     }
 }
 void qc_reduce_replicas(hipStream_t st, size_t count, int nrep, size_t stride, double *Gt) {
     if (nrep <= 1) return;
-    hipLaunchKernelGGL(qc_reduce_replicas_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, st, count, nrep, stride, Gt);
+    hipLaunchKernelGGL(qc_reduce_replicas_kernel, dim3((unsigned)((count + 63) / 64)), dim3(64), 0, st, count, nrep, stride, Gt);
 }
 
 __device__ __forceinline__ double block_sum_256(double v, double *sh) {
