@@ -519,13 +519,14 @@ __global__ __launch_bounds__(1024) void qc_refine_stats_kernel(int n, const doub
     for (int o = 32; o > 0; o >>= 1) { cmax = fmax(cmax, __shfl_down(cmax, o, 64)); emax = fmax(emax, __shfl_down(emax, o, 64)); }
     __syncthreads();
     if ((tid & 63) == 0) { red[tid >> 6] = cmax; red[16 + (tid >> 6)] = emax; }
+    // a strong pair must be mutual (i's only strong partner is j and vice versa); one index per thread (partner[] was written by
+    // this workgroup before the barrier above) - as a loop of thread 0 these dependent loads were half of the kernel's 18 us
+    for (int i = tid; i < n; i += 1024) { const int pj = partner[i]; if (pj >= 0 && partner[pj] != i) sh_multi = 1; }
     __syncthreads();
     if (tid == 0) {
         double a = 0.0, b = 0.0;
         for (int k = 0; k < 16; ++k) { a = fmax(a, red[k]); b = fmax(b, red[16 + k]); }
-        // a strong pair must be mutual (i's only strong partner is j and vice versa)
-        int multi = sh_multi;
-        for (int i = 0; i < n && !multi; ++i) if (partner[i] >= 0 && partner[partner[i]] != i) multi = 1;
+        const int multi = sh_multi;
         stats[3] = 0.5 * sh_nstrong; stats[4] = a; stats[5] = b; stats[6] = multi;
         if (ctl) {   // the decisions qc_eig_device_refine takes on the host, for the sync-free variant
             const double orth = stats[1], scl = fmax(stats[2], 1e-300);
