@@ -987,24 +987,30 @@ void qc_dots(hipStream_t st, int n, const double *x, const double *const *ys, in
 // out2[0] = 0.5 tr(Dnew (2H + G)),  out2[1] = sum_i (Dnew - Dold)_ii^2      (rhf.rs:84-88)
 // `out2` may be pinned host memory (the SCF pass reads its scalars without a copy); with `ctl` the control words are
 // copied next to them (ctl_out) and cleared for the next pass.
-__global__ __launch_bounds__(256) void qc_energy_rms_kernel(int n, const double *Dn, const double *Do, const double *H, const double *G,
-                                                            double *out2, int *ctl, int *ctl_out) {
-    __shared__ double sh[4];
+// (one workgroup: the kernel is as long as a thread's chain of loads, hence 1024 threads and a separate pass over the diagonal)
+__global__ __launch_bounds__(1024) void qc_energy_rms_kernel(int n, const double *Dn, const double *Do, const double *H, const double *G,
+                                                             double *out2, int *ctl, int *ctl_out) {
+    __shared__ double sh[2][16];
     double e = 0.0, r = 0.0;
-    for (int x = threadIdx.x; x < n * n; x += 256) {
+    for (int x = threadIdx.x; x < n * n; x += 1024) {
         const int i = x / n, j = x - i * n;
         e = fma(Dn[x], 2.0 * H[j * n + i] + G[j * n + i], e);
-        if (i == j) { const double d = Dn[x] - Do[x]; r = fma(d, d, r); }
     }
-    e = block_sum_256(e, sh);
-    r = block_sum_256(r, sh);
-    if (threadIdx.x == 0) { out2[0] = 0.5 * e; out2[1] = r; }
+    for (int i = threadIdx.x; i < n; i += 1024) { const double d = Dn[(size_t)i * n + i] - Do[(size_t)i * n + i]; r = fma(d, d, r); }
+    for (int o = 32; o > 0; o >>= 1) { e += __shfl_down(e, o, 64); r += __shfl_down(r, o, 64); }
+    if ((threadIdx.x & 63) == 0) { sh[0][threadIdx.x >> 6] = e; sh[1][threadIdx.x >> 6] = r; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        e = 0.0; r = 0.0;
+        for (int k = 0; k < 16; ++k) { e += sh[0][k]; r += sh[1][k]; }
+        out2[0] = 0.5 * e; out2[1] = r;
+    }
     if (ctl && threadIdx.x < 16) { ctl_out[threadIdx.x] = ctl[threadIdx.x]; ctl[threadIdx.x] = 0; }
     __threadfence_system();
 }
 void qc_energy_rms(hipStream_t st, int n, const double *Dnew, const double *Dold, const double *H, const double *G, double *out2, int *ctl,
                    int *ctl_out) {
-    hipLaunchKernelGGL(qc_energy_rms_kernel, dim3(1), dim3(256), 0, st, n, Dnew, Dold, H, G, out2, ctl, ctl_out);
+    hipLaunchKernelGGL(qc_energy_rms_kernel, dim3(1), dim3(1024), 0, st, n, Dnew, Dold, H, G, out2, ctl, ctl_out);
 }
 
 // out = sum_i c[i] * Fs[i]   (diis.rs:52-58)
