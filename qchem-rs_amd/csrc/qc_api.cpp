@@ -148,12 +148,11 @@ int huckel_density(qc_system *S, ScfWork &W, const std::vector<double> &h_eht, i
 // One spin's Roothaan step, enqueued without any host synchronisation: F = H + G; e = FDS - SDF; DIIS; F' = X^T F X;
 // eigenvectors; C = X C'   (rhf.rs:70-76).  The eigensolve is warm-started from this spin's previous vectors once they
 // exist (qc_eig_refine_async: outcome in ctl[4 spin]); new vectors go to CpNew[spin], C to dC.
-int roothaan_enqueue(qc_system *S, ScfWork &W, DeviceDiis &diis, const double *dG, const double *dD, double *dw_out, double *dC, int spin) {
+int roothaan_enqueue(qc_system *S, ScfWork &W, DeviceDiis &diis, const double *dG, const double *dD, double *dw_out, double *dC, int spin,
+                     double *dE, double *dF, bool have_F) {
     const int n = S->nbasis;
     hipStream_t st = S->stream;
-    double *dE, *dF;
-    diis.next_sample(&dE, &dF);
-    qc_axpby(st, n, 1.0, W.H.p, 1.0, dG, dF);                                            // F
+    if (!have_F) qc_axpby(st, n, 1.0, W.H.p, 1.0, dG, dF);                               // F (else written by the build's closing kernel)
     qc_gemm(st, n, n, n, 1.0, dF, n, false, dD, n, false, 0.0, W.t2.p, n);               // F D
     qc_gemm(st, n, n, n, 1.0, W.t2.p, n, false, W.S.p, n, false, 0.0, W.Fp.p, n);        // F D S
     qc_sub_transpose(st, n, W.Fp.p, dE);                                                 // e = FDS - (FDS)^T = FDS - SDF
@@ -288,7 +287,8 @@ int qc_eri_full(qc_system *S, double *out) {
 
 }  // extern "C"
 
-int qc_fock_build_device(qc_system *S, const double *dDa, const double *dDb, double *dGa, double *dGb, bool uhf, int *twin_cache) {
+int qc_fock_build_device(qc_system *S, const double *dDa, const double *dDb, double *dGa, double *dGb, bool uhf, int *twin_cache,
+                         const double *dH, double *dFa, double *dFb, bool *f_done) {
     const int n = S->nbasis;
     const size_t nn = (size_t)n * n;
     hipStream_t st = S->stream;
@@ -358,9 +358,10 @@ int qc_fock_build_device(qc_system *S, const double *dDa, const double *dDb, dou
     if (S->comm) {   // partial Fock matrices -> full, one all-reduce per build ([Ga|Gb] concatenated for UHF)
         if (ncclAllReduce(S->d_Gtmp, S->d_Gtmp, nspin * nn, ncclDouble, ncclSum, (ncclComm_t)S->comm, st) != ncclSuccess) return QC_ERR_RCCL;
     }
-    qc_symmetrize_add(st, n, S->d_Gtmp, dGa);
-    if (two) qc_symmetrize_add(st, n, S->d_Gtmp + nn, dGb);
+    qc_symmetrize_add(st, n, S->d_Gtmp, dGa, dH, dH ? dFa : nullptr);
+    if (two) qc_symmetrize_add(st, n, S->d_Gtmp + nn, dGb, dH, dH ? dFb : nullptr);
     else if (uhf) QC_HIP_CHECK(hipMemcpyAsync(dGb, dGa, nn * sizeof(double), hipMemcpyDeviceToDevice, st));
+    if (f_done) *f_done = dH != nullptr && dFa != nullptr && (!uhf || (two && dFb != nullptr));
     return QC_OK;
 }
 
@@ -528,6 +529,9 @@ static int scf_iterate(qc_scf_state *st, double *energy, double *rms_out) {
     const int nspin = st->uhf ? 2 : 1;
     int rc;
     QC_HIP_CHECK(hipEventRecord(st->ev0, sm));
+    double *dE[2] = {nullptr, nullptr}, *dF[2] = {nullptr, nullptr};       // this pass's DIIS sample buffers (error, Fock matrix) per spin
+    for (int s = 0; s < nspin; ++s) st->diis[s]->next_sample(&dE[s], &dF[s]);
+    bool have_F = false;
     // G of every spin from the *old* densities
     if (st->stored) {
         if (st->uhf) {   // uhf.rs:216-226: G_s = <I, D_s + D_s'> - <I^x, D_s>
@@ -540,13 +544,13 @@ static int scf_iterate(qc_scf_state *st, double *energy, double *rms_out) {
             qc_tensor_gemv(sm, n, st->T4.p, st->D[0].p, nullptr, nullptr, st->G.p);   // rhf.rs:152-167
         }
     } else if ((rc = qc_fock_build_device(S, st->D[0].p, st->uhf ? st->D[1].p : nullptr, st->G.p, st->uhf ? st->G.p + nn : nullptr, st->uhf,
-                                          &st->twin)) != QC_OK) return rc;
+                                          &st->twin, W.H.p, dF[0], dF[1], &have_F)) != QC_OK) return rc;
     // (Enqueueing the *next* pass's build here, ahead of the wait below, was tried: its side-stream launches then sit
     // behind unsignalled barriers while the main queue still works, and with 8 hardware queues on 4 pipes the blocked
     // queues stall their pipe neighbours - 1.6 ms per pass instead of 0.6.)
     QC_HIP_CHECK(hipEventRecord(st->ev1, sm));
     for (int s = 0; s < nspin; ++s)                                       // (the control words were cleared by the previous pass)
-        if ((rc = roothaan_enqueue(S, W, *st->diis[s], st->G.p + s * nn, st->D[s].p, st->ws.p + s * n, st->Cs.p + s * nn, s)) != QC_OK) return rc;
+        if ((rc = roothaan_enqueue(S, W, *st->diis[s], st->G.p + s * nn, st->D[s].p, st->ws.p + s * n, st->Cs.p + s * nn, s, dE[s], dF[s], have_F)) != QC_OK) return rc;
     int *h_ctl = reinterpret_cast<int *>(W.h_scal + 4);
     auto density_and_scalars = [&](int s) -> int {
         if (st->nocc[s] > 0) qc_gemm(sm, n, n, st->nocc[s], st->uhf ? 1.0 : 2.0, st->Cs.p + s * nn, n, false, st->Cs.p + s * nn, n, true, 0.0, st->Dn[s].p, n);

@@ -164,7 +164,9 @@ int qc_launch_eri_full(qc_system *S, double *d_out);
 int qc_one_electron_device(qc_system *S, int which /* 0 S, 1 T, 2 V */, double *d_out);
 void qc_drop_graphs(qc_system *S);
 int qc_launch_fock_classes(qc_system *S, const QcFockArgs &a, float *class_ms /*nullable*/, float *unit_ms = nullptr /*nullable, 14*/);
-int qc_fock_build_device(qc_system *S, const double *dDa, const double *dDb, double *dGa, double *dGb, bool uhf, int *twin_cache = nullptr);
+// (dH with dFa / dFb: the Fock matrices H + G are written by the closing kernel as well; *f_done tells whether both were)
+int qc_fock_build_device(qc_system *S, const double *dDa, const double *dDb, double *dGa, double *dGb, bool uhf, int *twin_cache = nullptr,
+                         const double *dH = nullptr, double *dFa = nullptr, double *dFb = nullptr, bool *f_done = nullptr);
 
 // dense linear algebra on the handle's stream (all row-major n x n, device pointers)
 void qc_gemm(hipStream_t st, int m, int n, int k, double alpha, const double *A, int lda, bool ta, const double *B,
@@ -183,7 +185,7 @@ void qc_permute_tensor(hipStream_t st, int n, const double *I, double c_direct, 
 void qc_tensor_gemv(hipStream_t st, int n, const double *T1, const double *D1, const double *T2, const double *D2, double *G);
 void qc_axpby(hipStream_t st, int n, double a, const double *x, double b, const double *y, double *out);
 void qc_sub_transpose(hipStream_t st, int n, const double *M, double *out);              // out = M - M^T
-void qc_symmetrize_add(hipStream_t st, int n, const double *Gt, double *G);              // G = Gt + Gt^T
+void qc_symmetrize_add(hipStream_t st, int n, const double *Gt, double *G, const double *H = nullptr, double *F = nullptr);   // G = Gt + Gt^T (and F = H + G)
 void qc_reduce_replicas(hipStream_t st, size_t count, int nrep, size_t stride, double *Gt);  // Gt[0] += sum_r>0 Gt[r]
 void qc_count_diff(hipStream_t st, size_t count, const double *a, const double *b, int *flag);
 int qc_lgc_for(int lab, int lcd, int ncd);

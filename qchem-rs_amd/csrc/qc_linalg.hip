@@ -819,14 +819,17 @@ void qc_sub_transpose(hipStream_t st, int n, const double *M, double *out) {
 }
 
 // G = Gt + Gt^T: closes the unique-quartet digestion (fock_finalize)
-__global__ void qc_symmetrize_add_kernel(int n, const double *Gt, double *G) {
+// (with H and F given, F = H + G - the Fock matrix of rhf.rs:68 - leaves in the same launch)
+__global__ void qc_symmetrize_add_kernel(int n, const double *Gt, double *G, const double *H, double *F) {
     for (int x = blockIdx.x * blockDim.x + threadIdx.x; x < n * n; x += gridDim.x * blockDim.x) {
         const int i = x / n, j = x - i * n;
-        G[x] = Gt[x] + Gt[j * n + i];
+        const double g = Gt[x] + Gt[j * n + i];
+        G[x] = g;
+        if (F) F[x] = 1.0 * H[x] + 1.0 * g;              // the arithmetic of qc_axpby(1, H, 1, G)
     }
 }
-void qc_symmetrize_add(hipStream_t st, int n, const double *Gt, double *G) {
-    hipLaunchKernelGGL(qc_symmetrize_add_kernel, dim3((n * n + 255) / 256), dim3(256), 0, st, n, Gt, G);
+void qc_symmetrize_add(hipStream_t st, int n, const double *Gt, double *G, const double *H, double *F) {
+    hipLaunchKernelGGL(qc_symmetrize_add_kernel, dim3((n * n + 255) / 256), dim3(256), 0, st, n, Gt, G, H, F);
 }
 
 // flag[0] = number of positions where a and b differ bitwise (spin-symmetry test of the UHF build)
