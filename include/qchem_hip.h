@@ -33,6 +33,8 @@ enum {
     QC_OK = 0,
     QC_NOT_CONVERGED = 1,   /* rhf.rs:106-107 / uhf.rs:165-166 return None */
     QC_DIIS_SINGULAR = 2,   /* rhf.rs:73 expect("DIIS failed") / uhf.rs:95-97 panic */
+    QC_EIG_NOT_CONVERGED = 3, /* the Jacobi sweeps of an eigensolve ran out (no counterpart: nalgebra's SymmetricEigen, utils.rs:16,
+                               * iterates until it converges; reported instead of continuing on unconverged vectors) */
     QC_ERR_INVALID = -1,
     QC_ERR_NO_DEVICE = -2,
     QC_ERR_HIP = -3,
@@ -129,6 +131,9 @@ int qc_scf_begin_uhf(qc_system *sys, int n_alpha, int n_beta, qc_scf_state **out
 int qc_scf_iterate(qc_scf_state *st, double *electronic_energy, double *density_rms);
 int qc_scf_orbital_energies(qc_scf_state *st, int spin, double *out_n);
 int qc_scf_density(qc_scf_state *st, int spin, double *out_nxn);
+/* Set-up matrices of the state, n*n doubles to the host: which = 0 overlap S (rhf.rs:41), 1 core Hamiltonian H = T + V
+ * (rhf.rs:48), 2 transformation matrix X = S^-1/2 (compute_transformation_matrix, rhf.rs:124-131). */
+int qc_scf_matrix(qc_scf_state *st, int which, double *out_nxn);
 /* <S^2> of the current UHF determinant: Sz (Sz + 1) + N_beta - tr(D_alpha S D_beta S), Sz = (N_alpha - N_beta) / 2.
  * The reference leaves open shells as a TODO (uhf.rs:42, main.rs:111); this is the diagnostic that goes with the
  * n_alpha / n_beta extension.  RHF states return 0. */
@@ -142,6 +147,20 @@ void qc_scf_end(qc_scf_state *st);
  * during set-up (QC_ERR_UNSUPPORTED if the device cannot hold them); single-GPU only. */
 int qc_set_fock_mode(qc_system *sys, int mode);
 double qc_scf_tensor_ms(qc_scf_state *st);   /* wall time of the tensor build of a stored-mode state */
+
+/* ---- accumulation of the direct Fock build.  1 (default): every contribution to G is rounded once to a multiple of
+ * 2^-S Eh and added as a 64-bit integer - the sum does not depend on the order the GPU serves the adds in, so a build is
+ * reproducible bit for bit (run to run, stream assignment, number of ranks) and both spins of a UHF build see identical
+ * arithmetic, as in the reference (uhf.rs:80-108, 210-227).  S follows the density of the build (a bound on |G| keeps every
+ * sum inside 64 bits): 2^-49 Eh = 1.8e-15 for benzene/cc-pVDZ.  0: f64 atomics (last-bit noise from the accumulation
+ * order; kept for A/B measurements). */
+int qc_set_accumulation(qc_system *sys, int fixed_point);
+
+/* ---- Schwarz screening (the reference's TODO at uhf.rs:49-50: "if we could skip some of them ...").  Once per geometry the
+ * GPU evaluates the (ab|ab) quartet of every shell pair; unique quartets with sqrt((ab|ab) (cd|cd)) < tau are left out of
+ * the work lists (|(ab|cd)| <= that product).  Default 1e-12; 0 switches it off.  Throughput figures keep counting the
+ * enumerated quartets (qc_nquartets). */
+int qc_set_schwarz(qc_system *sys, double tau);
 
 /* ---- multi-GPU (not in the reference, which is single-threaded; BASELINE.json north_star).  One process per GPU.
  * Rank 0 calls qc_comm_unique_id, the host distributes the 128 bytes, every rank calls qc_comm_init, which creates
@@ -165,6 +184,9 @@ typedef struct {
     double bytes_alg;          /* pair data + 6 D blocks read + 6 F blocks read/write, bytes */
     double flops_alg;          /* Boys + R table + Hermite contraction + digestion, flops */
     int32_t nclasses;          /* kernel launches per build */
+    int64_t quartets_enumerated;   /* all unique quartets of the molecule (what the reference visits; all ranks) */
+    int64_t quartets_screened_out; /* of those, dropped by the Schwarz bound (all ranks); 0 before the device pass has run */
+    double schwarz_tau;            /* threshold in force (0: none) */
 } qc_work_stats;
 int qc_work_stats_get(qc_system *sys, qc_work_stats *out);
 /* Time `reps` Fock builds (RHF digestion of dD) per kernel class with hipEvents on the handle's stream.

@@ -23,6 +23,13 @@ double now_ms() {
     return duration<double, std::milli>(steady_clock::now().time_since_epoch()).count();
 }
 
+// hipEvent that is destroyed on every path out of its scope
+struct Event {
+    hipEvent_t e = nullptr;
+    int create() { return hipEventCreate(&e) == hipSuccess ? QC_OK : QC_ERR_HIP; }
+    ~Event() { if (e) (void)hipEventDestroy(e); }
+};
+
 struct DevBuf {
     double *p = nullptr;
     int alloc(size_t count) { return hipMalloc(&p, count * sizeof(double)) == hipSuccess ? QC_OK : QC_ERR_HIP; }
@@ -215,6 +222,7 @@ int qc_system_create(int natoms, const int32_t *Z, const double *xyz, int nshell
         po += sh.nprim;
         S->shells.push_back(std::move(sh));
     }
+    if (const char *e = getenv("QC_ACCUM")) S->accum_fx = std::strcmp(e, "f64") == 0 ? 0 : 1;     // A/B switch: QC_ACCUM=f64
     qc_build_model(S);
     if (!S->last_error.empty()) { fprintf(stderr, "qchem_hip: %s\n", S->last_error.c_str()); delete S; return QC_ERR_UNSUPPORTED; }
     *out = S;
@@ -292,74 +300,53 @@ int qc_fock_build_device(qc_system *S, const double *dDa, const double *dDb, dou
     const int n = S->nbasis;
     const size_t nn = (size_t)n * n;
     hipStream_t st = S->stream;
+    const bool fx = S->accum_fx != 0;
+    const double *fxs = fx ? S->d_fxs : nullptr;
     // Spin symmetry: the reference evaluates both spins with identical arithmetic (uhf.rs:210-227), so bitwise-equal
-    // densities give bitwise-equal G (its closed-shell UHF never breaks symmetry).  Atomic accumulation
-    // order would not preserve that, so equal spins are detected and digested once.
-    // Inside an SCF run the answer cannot change (equal spins stay equal under identical arithmetic, different ones stay
-    // different), so the drivers pass a cache and only their first build pays the host round trip.
+    // densities give bitwise-equal G (its closed-shell UHF never breaks symmetry).  The fixed-point
+    // accumulation keeps that property by construction: every contribution is the same sequence of operations for either
+    // spin and integer sums do not depend on their order.  Only the f64-atomic mode (kept for A/B measurements) needs help:
+    // there equal spins are detected and digested once.  Inside an SCF run the answer cannot change, so the drivers pass a
+    // cache and only their first build pays the host round trip.
     bool twin = false;
-    if (uhf && twin_cache && *twin_cache >= 0) twin = *twin_cache != 0;
-    else if (uhf) {
-        int diff = 1;
-        QC_HIP_CHECK(hipMemsetAsync(S->d_flag, 0, sizeof(int), st));
-        qc_count_diff(st, nn, dDa, dDb, S->d_flag);
-        QC_HIP_CHECK(hipMemcpyAsync(&diff, S->d_flag, sizeof(int), hipMemcpyDeviceToHost, st));
-        QC_HIP_CHECK(hipStreamSynchronize(st));
-        twin = (diff == 0);
-        if (twin_cache) *twin_cache = twin ? 1 : 0;
+    if (uhf && !fx) {
+        if (twin_cache && *twin_cache >= 0) twin = *twin_cache != 0;
+        else {
+            int diff = 1;
+            QC_HIP_CHECK(hipMemsetAsync(S->d_flag, 0, sizeof(int), st));
+            qc_count_diff(st, nn, dDa, dDb, S->d_flag);
+            QC_HIP_CHECK(hipMemcpyAsync(&diff, S->d_flag, sizeof(int), hipMemcpyDeviceToHost, st));
+            QC_HIP_CHECK(hipStreamSynchronize(st));
+            twin = (diff == 0);
+            if (twin_cache) *twin_cache = twin ? 1 : 0;
+        }
     }
     const bool two = uhf && !twin;
     const int nspin = two ? 2 : 1;
-    // The accumulation phase (memset, density sum, every class kernel on the side streams, replica fold) is captured
-    // into a hipGraph the first time it runs with a given set of operand pointers and replayed afterwards: the eager
-    // form costs ~10 us of host time per launch, which for the ~35 small class kernels of a build is most of its time.
-    auto enqueue = [&]() -> int {
-        QC_HIP_CHECK(hipMemsetAsync(S->d_Gtmp, 0, (size_t)QC_NREP * nspin * nn * sizeof(double), st));
-        QcFockArgs a{};
-        a.nrep = QC_NREP; a.rep_stride = nspin * nn;
-        if (uhf) {
-            qc_axpby(st, n, 1.0, dDa, 1.0, dDb, S->d_Dj);
-            a.Dj = S->d_Dj; a.Dk0 = dDa; a.Dk1 = two ? dDb : nullptr; a.cK = 1.0;
-        } else {
-            a.Dj = dDa; a.Dk0 = dDa; a.Dk1 = nullptr; a.cK = 0.5;
-        }
-        a.G0 = S->d_Gtmp; a.G1 = S->d_Gtmp + nn;
-        int rc_ = qc_launch_fock_classes(S, a, nullptr);
-        if (rc_ != QC_OK) return rc_;
-        qc_reduce_replicas(st, nspin * nn, QC_NREP, nspin * nn, S->d_Gtmp);
-        return QC_OK;
-    };
-    const int mode = uhf ? (two ? 2 : 1) : 0;
-    hipGraphExec_t exec = nullptr;
-    if (S->use_graphs) {
-        for (auto &g : S->graphs) if (g.Da == dDa && g.Db == dDb && g.mode == mode) exec = g.exec;
-        if (!exec) {
-            hipGraph_t graph = nullptr;
-            bool ok = hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal) == hipSuccess;
-            int rc_cap = ok ? enqueue() : QC_ERR_HIP;
-            if (ok && hipStreamEndCapture(st, &graph) != hipSuccess) ok = false;
-            if (ok && rc_cap == QC_OK && graph && hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0) == hipSuccess) {
-                if (S->graphs.size() >= 6) qc_drop_graphs(S);
-                S->graphs.push_back({dDa, dDb, mode, exec});
-            } else {
-                exec = nullptr;
-                S->use_graphs = false;                 // capture unsupported here: stay on eager launches
-                (void)hipGetLastError();
-            }
-            if (graph) (void)hipGraphDestroy(graph);
-        }
-    }
-    if (exec) {
-        QC_HIP_CHECK(hipGraphLaunch(exec, st));
+    // accumulation phase: zero the replicas, density sum, every class kernel on the side streams, replica fold
+    const size_t plane = (size_t)QC_NREP * nspin * nn;          // one accumulator plane: [replica][spin][n*n]
+    QC_HIP_CHECK(hipMemsetAsync(S->d_Gtmp, 0, (fx ? 2 : 1) * plane * sizeof(double), st));
+    QcFockArgs a{};
+    a.nrep = QC_NREP; a.rep_stride = nspin * nn; a.fxs = fxs; a.fx_lo = plane;
+    if (fx) qc_fx_scale(st, n, dDa, uhf ? dDb : nullptr, S->imax, S->d_fxs);      // this build's fixed-point unit, from its densities
+    if (uhf) {
+        qc_axpby(st, n, 1.0, dDa, 1.0, dDb, S->d_Dj);
+        a.Dj = S->d_Dj; a.Dk0 = dDa; a.Dk1 = two ? dDb : nullptr; a.cK = 1.0;
     } else {
-        int rc = enqueue();
-        if (rc != QC_OK) return rc;
+        a.Dj = dDa; a.Dk0 = dDa; a.Dk1 = nullptr; a.cK = 0.5;
     }
-    if (S->comm) {   // partial Fock matrices -> full, one all-reduce per build ([Ga|Gb] concatenated for UHF)
-        if (ncclAllReduce(S->d_Gtmp, S->d_Gtmp, nspin * nn, ncclDouble, ncclSum, (ncclComm_t)S->comm, st) != ncclSuccess) return QC_ERR_RCCL;
+    a.G0 = S->d_Gtmp; a.G1 = S->d_Gtmp + nn;
+    int rc = qc_launch_fock_classes(S, a, nullptr);
+    if (rc != QC_OK) return rc;
+    qc_reduce_replicas(st, nspin * nn, QC_NREP, nspin * nn, S->d_Gtmp, S->d_Gred, fx, plane);
+    if (S->comm) {
+        // partial Fock matrices -> full, one all-reduce per build ([Ga|Gb] concatenated for UHF; hi and lo planes back to
+        // back).  Fixed-point partials are summed as integers: the result is bit-identical on every rank and to the
+        // single-GPU build, whatever the ring order.
+        if (ncclAllReduce(S->d_Gred, S->d_Gred, (fx ? 2 : 1) * nspin * nn, fx ? ncclInt64 : ncclDouble, ncclSum, (ncclComm_t)S->comm, st) != ncclSuccess) return QC_ERR_RCCL;
     }
-    qc_symmetrize_add(st, n, S->d_Gtmp, dGa, dH, dH ? dFa : nullptr);
-    if (two) qc_symmetrize_add(st, n, S->d_Gtmp + nn, dGb, dH, dH ? dFb : nullptr);
+    qc_symmetrize_add(st, n, S->d_Gred, nspin * nn, dGa, dH, dH ? dFa : nullptr, fxs);
+    if (two) qc_symmetrize_add(st, n, S->d_Gred + nn, nspin * nn, dGb, dH, dH ? dFb : nullptr, fxs);
     else if (uhf) QC_HIP_CHECK(hipMemcpyAsync(dGb, dGa, nn * sizeof(double), hipMemcpyDeviceToDevice, st));
     if (f_done) *f_done = dH != nullptr && dFa != nullptr && (!uhf || (two && dFb != nullptr));
     return QC_OK;
@@ -652,6 +639,13 @@ int qc_scf_density(qc_scf_state *st, int spin, double *out) {
     QC_HIP_CHECK(hipMemcpy(out, st->D[spin].p, nn * sizeof(double), hipMemcpyDeviceToHost));
     return QC_OK;
 }
+int qc_scf_matrix(qc_scf_state *st, int which, double *out) {
+    if (!st || !out || which < 0 || which > 2) return QC_ERR_INVALID;
+    const size_t nn = (size_t)st->S->nbasis * st->S->nbasis;
+    const double *src = which == 0 ? st->W.S.p : which == 1 ? st->W.H.p : st->W.X.p;
+    QC_HIP_CHECK(hipMemcpy(out, src, nn * sizeof(double), hipMemcpyDeviceToHost));
+    return QC_OK;
+}
 int qc_scf_spin_square(qc_scf_state *st, double *s2) {
     if (!st || !s2) return QC_ERR_INVALID;
     *s2 = 0.0;
@@ -673,6 +667,18 @@ int qc_scf_spin_square(qc_scf_state *st, double *s2) {
     const double sz = 0.5 * (st->nocc[0] - st->nocc[1]);
     *s2 = sz * (sz + 1.0) + st->nocc[1] - tr;
     return QC_OK;
+}
+
+int qc_set_accumulation(qc_system *S, int fixed_point) {
+    if (!S || (fixed_point != 0 && fixed_point != 1)) return QC_ERR_INVALID;
+    S->accum_fx = fixed_point;
+    return QC_OK;
+}
+
+int qc_set_schwarz(qc_system *S, double tau) {
+    if (!S || !(tau >= 0.0)) return QC_ERR_INVALID;
+    S->schwarz_tau = tau;
+    return qc_device_reshard(S);
 }
 
 int qc_set_fock_mode(qc_system *S, int mode) {
@@ -787,6 +793,9 @@ int qc_work_stats_get(qc_system *S, qc_work_stats *out) {
         out->quartets += (int64_t)c.shard.size(); out->prim_quartets += c.prim_quartets;
         out->bytes_alg += c.bytes_alg; out->flops_alg += c.flops_alg; out->nclasses += 1;
     }
+    out->quartets_enumerated = S->nquartets;
+    out->quartets_screened_out = S->nscreened;
+    out->schwarz_tau = S->pairQ.empty() ? 0.0 : S->schwarz_tau;
     return QC_OK;
 }
 
@@ -799,12 +808,14 @@ int qc_fock_profile(qc_system *S, const double *dD, double *dG, int reps, float 
     const size_t nn = (size_t)n * n;
     std::vector<float> acc(S->classes.size(), 0.f), one(S->classes.size(), 0.f);
     float tot = 0.f;
-    hipEvent_t e0, e1;
-    QC_HIP_CHECK(hipEventCreate(&e0)); QC_HIP_CHECK(hipEventCreate(&e1));
+    if (S->accum_fx) qc_fx_scale(S->stream, n, dD, nullptr, S->imax, S->d_fxs);
+    Event ev0, ev1;
+    if (ev0.create() != QC_OK || ev1.create() != QC_OK) return QC_ERR_HIP;
+    hipEvent_t e0 = ev0.e, e1 = ev1.e;
     for (int r = 0; r < reps; ++r) {
-        QC_HIP_CHECK(hipMemsetAsync(S->d_Gtmp, 0, (size_t)QC_NREP * nn * sizeof(double), S->stream));
+        QC_HIP_CHECK(hipMemsetAsync(S->d_Gtmp, 0, (size_t)2 * QC_NREP * nn * sizeof(double), S->stream));
         QcFockArgs a{};
-        a.nrep = QC_NREP; a.rep_stride = nn;
+        a.nrep = QC_NREP; a.rep_stride = nn; a.fxs = S->accum_fx ? S->d_fxs : nullptr; a.fx_lo = (size_t)QC_NREP * nn;
         a.Dj = dD; a.Dk0 = dD; a.Dk1 = nullptr; a.cK = 0.5; a.G0 = S->d_Gtmp; a.G1 = S->d_Gtmp + nn;
         if ((rc = qc_launch_fock_classes(S, a, one.data())) != QC_OK) return rc;
         for (size_t i = 0; i < acc.size(); ++i) acc[i] += one[i];
@@ -815,7 +826,6 @@ int qc_fock_profile(qc_system *S, const double *dD, double *dG, int reps, float 
         QC_HIP_CHECK(hipEventSynchronize(e1));
         float ms; (void)hipEventElapsedTime(&ms, e0, e1); tot += ms;
     }
-    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
     int k = 0;
     for (size_t i = 0; i < S->classes.size(); ++i) {
         const QcClass &c = S->classes[i];
@@ -842,12 +852,14 @@ int qc_fock_profile_tiers(qc_system *S, const double *dD, double *dG, int reps, 
     const int NU = QC_NUNITS;
     std::vector<float> acc(NU, 0.f), one(NU, 0.f);
     float tot = 0.f;
-    hipEvent_t e0, e1;
-    QC_HIP_CHECK(hipEventCreate(&e0)); QC_HIP_CHECK(hipEventCreate(&e1));
+    if (S->accum_fx) qc_fx_scale(S->stream, S->nbasis, dD, nullptr, S->imax, S->d_fxs);
+    Event ev0, ev1;
+    if (ev0.create() != QC_OK || ev1.create() != QC_OK) return QC_ERR_HIP;
+    hipEvent_t e0 = ev0.e, e1 = ev1.e;
     for (int r = 0; r < reps; ++r) {
-        QC_HIP_CHECK(hipMemsetAsync(S->d_Gtmp, 0, (size_t)QC_NREP * nn * sizeof(double), S->stream));
+        QC_HIP_CHECK(hipMemsetAsync(S->d_Gtmp, 0, (size_t)2 * QC_NREP * nn * sizeof(double), S->stream));
         QcFockArgs a{};
-        a.nrep = QC_NREP; a.rep_stride = nn;
+        a.nrep = QC_NREP; a.rep_stride = nn; a.fxs = S->accum_fx ? S->d_fxs : nullptr; a.fx_lo = (size_t)QC_NREP * nn;
         a.Dj = dD; a.Dk0 = dD; a.Dk1 = nullptr; a.cK = 0.5; a.G0 = S->d_Gtmp; a.G1 = S->d_Gtmp + nn;
         if ((rc = qc_launch_fock_classes(S, a, nullptr, one.data())) != QC_OK) return rc;
         for (int i = 0; i < NU; ++i) acc[i] += one[i];
@@ -857,7 +869,6 @@ int qc_fock_profile_tiers(qc_system *S, const double *dD, double *dG, int reps, 
         QC_HIP_CHECK(hipEventSynchronize(e1));
         float ms; (void)hipEventElapsedTime(&ms, e0, e1); tot += ms;
     }
-    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
     for (int u = 0; u < NU; ++u) {
         unit_ms[u] = acc[u] / reps;
         if (unit_quartets) unit_quartets[u] = 0;

@@ -15,6 +15,17 @@ int qc_launch_tier_lab4(int, int, size_t, hipStream_t, const QcTierArgs &);
 int qc_launch_tier_lab5(int, int, size_t, hipStream_t, const QcTierArgs &);
 int qc_launch_tier_lab6(int, int, size_t, hipStream_t, const QcTierArgs &);
 
+// timing events that are destroyed on every path out of their scope
+struct EventList {
+    std::vector<hipEvent_t> ev;
+    int create(size_t count) {
+        ev.assign(count, nullptr);
+        for (auto &e : ev) if (hipEventCreate(&e) != hipSuccess) return QC_ERR_HIP;
+        return QC_OK;
+    }
+    ~EventList() { for (auto e : ev) if (e) (void)hipEventDestroy(e); }
+};
+
 static int launch_tier(int lab, int tier, int grid, size_t lds, hipStream_t st, const QcTierArgs &a) {
     switch (lab) {
         case 0: return qc_launch_tier_lab0(tier, grid, lds, st, a);
@@ -53,13 +64,7 @@ static int upload_slots(qc_system *S) {
     return QC_OK;
 }
 
-void qc_drop_graphs(qc_system *S) {
-    for (auto &g : S->graphs) if (g.exec) (void)hipGraphExecDestroy(g.exec);
-    S->graphs.clear();
-}
-
 int qc_device_reshard(qc_system *S) {
-    qc_drop_graphs(S);
     S->unit_ms.clear(); S->unit_stream.clear();
     qc_build_shards(S);
     if (!S->device_ready) return QC_OK;
@@ -105,26 +110,30 @@ int qc_device_init(qc_system *S) {
     QC_HIP_CHECK(hipMemcpy(S->d_boys, tab.data(), tab.size() * sizeof(double), hipMemcpyHostToDevice));
     QC_HIP_CHECK(hipMalloc(&S->d_D, 2 * nn * sizeof(double)));
     QC_HIP_CHECK(hipMalloc(&S->d_G, 2 * nn * sizeof(double)));
-    QC_HIP_CHECK(hipMalloc(&S->d_Gtmp, (size_t)QC_NREP * 2 * nn * sizeof(double)));
+    QC_HIP_CHECK(hipMalloc(&S->d_Gtmp, (size_t)2 * QC_NREP * 2 * nn * sizeof(double)));
+    QC_HIP_CHECK(hipMalloc(&S->d_Gred, (size_t)2 * 2 * nn * sizeof(double)));
     QC_HIP_CHECK(hipMalloc(&S->d_Dj, nn * sizeof(double)));
     QC_HIP_CHECK(hipMalloc(&S->d_flag, 4 * sizeof(int)));
-    int rc = upload_slots(S);
+    QC_HIP_CHECK(hipMalloc(&S->d_fxs, 2 * sizeof(double)));
+    // Schwarz factors of the pairs (once per geometry), then the screened work lists
+    int rc = qc_schwarz_device(S);
     if (rc != QC_OK) return rc;
+    qc_build_shards(S);
+    if ((rc = upload_slots(S)) != QC_OK) return rc;
     S->device_ready = true;
     return QC_OK;
 }
 
 void qc_device_free(qc_system *S) {
-    qc_drop_graphs(S);
     for (auto &c : S->classes) {
         if (c.d_slots) { (void)hipFree(c.d_slots); c.d_slots = nullptr; }
         if (c.d_bundles) { (void)hipFree(c.d_bundles); c.d_bundles = nullptr; }
         if (c.d_ketlist) { (void)hipFree(c.d_ketlist); c.d_ketlist = nullptr; }
     }
-    void *ptrs[] = {S->d_shells, S->d_pairdata, S->d_pairdataT, S->d_pspack, S->d_pairs, S->d_boys, S->d_D, S->d_G, S->d_Gtmp, S->d_Dj, S->d_flag};
-    S->d_flag = nullptr;
+    void *ptrs[] = {S->d_shells, S->d_pairdata, S->d_pairdataT, S->d_pspack, S->d_pairs, S->d_boys, S->d_D, S->d_G, S->d_Gtmp, S->d_Gred, S->d_Dj, S->d_flag, S->d_fxs};
+    S->d_flag = nullptr; S->d_fxs = nullptr;
     for (void *p : ptrs) if (p) (void)hipFree(p);
-    S->d_shells = nullptr; S->d_pairdata = S->d_pairdataT = S->d_pspack = nullptr; S->d_pairs = nullptr; S->d_boys = S->d_D = S->d_G = S->d_Gtmp = S->d_Dj = nullptr;
+    S->d_shells = nullptr; S->d_pairdata = S->d_pairdataT = S->d_pspack = nullptr; S->d_pairs = nullptr; S->d_boys = S->d_D = S->d_G = S->d_Gtmp = S->d_Gred = S->d_Dj = nullptr;
     for (int i = 0; i < QC_NSTREAMS; ++i) {
         if (S->side[i]) (void)hipStreamDestroy(S->side[i]);
         if (S->ev_join[i]) (void)hipEventDestroy(S->ev_join[i]);
@@ -141,7 +150,7 @@ static QcKernelArgs base_args(qc_system *S, const QcFockArgs &fa) {
     QcKernelArgs a{};
     a.pairs = S->d_pairs; a.pairdata = S->d_pairdata; a.pairdataT = S->d_pairdataT; a.boys = S->d_boys; a.n = S->nbasis;
     a.Dj = fa.Dj; a.Dk0 = fa.Dk0; a.Dk1 = fa.Dk1; a.G0 = fa.G0; a.G1 = fa.G1; a.cK = fa.cK; a.eri_out = fa.eri_out;
-    a.nrep = fa.nrep > 0 ? fa.nrep : 1; a.rep_stride = fa.rep_stride;
+    a.nrep = fa.nrep > 0 ? fa.nrep : 1; a.rep_stride = fa.rep_stride; a.fxs = fa.fxs; a.fx_lo = fa.fx_lo; a.schwarz_out = fa.schwarz_out;
     return a;
 }
 
@@ -164,7 +173,7 @@ static int launch_segments(qc_system *S, int unit, const std::vector<Seg> &segs,
         // exchange rows of a wave's current bra in LDS: (na + nb) rows x n columns per spin
         const int rowbytes = (base.Dk1 ? 2 : 1) * rows * S->nbasis * 8;
         // (QC_BM_NO_ROWBUF forces the large-n fallback - direct global atomics per bundle - so that tests can reach it)
-        t.use_rowbuf = (base.eri_out == nullptr && QC_BM_LDS_TABLE + 2 * (iblock + rowbytes) <= lds_max && !getenv("QC_BM_NO_ROWBUF")) ? 1 : 0;
+        t.use_rowbuf = (base.eri_out == nullptr && base.schwarz_out == nullptr && QC_BM_LDS_TABLE + 2 * (iblock + rowbytes) <= lds_max && !getenv("QC_BM_NO_ROWBUF")) ? 1 : 0;
         const int wbytes = iblock + (t.use_rowbuf ? rowbytes : 0);
         while (nw > 1 && QC_BM_LDS_TABLE + nw * wbytes > lds_max) nw /= 2;          // Cartesian d / f bras: 36+ rows of I per wave
         int grid = 0, k = 0;
@@ -228,8 +237,9 @@ int qc_launch_fock_classes(qc_system *S, const QcFockArgs &fa, float *class_ms, 
     };
     if (class_ms || unit_ms) {
         const size_t nev = (class_ms ? S->classes.size() : units.size()) + 1;
-        std::vector<hipEvent_t> ev(nev);
-        for (auto &e : ev) QC_HIP_CHECK(hipEventCreate(&e));
+        EventList evl;
+        if (evl.create(nev) != QC_OK) return QC_ERR_HIP;
+        std::vector<hipEvent_t> &ev = evl.ev;
         QC_HIP_CHECK(hipEventRecord(ev[0], S->stream));
         if (class_ms) {
             for (size_t ci = 0; ci < S->classes.size(); ++ci) {
@@ -249,7 +259,6 @@ int qc_launch_fock_classes(qc_system *S, const QcFockArgs &fa, float *class_ms, 
         QC_HIP_CHECK(hipEventSynchronize(ev.back()));
         float *out = class_ms ? class_ms : unit_ms;
         for (size_t i = 0; i + 1 < nev; ++i) QC_HIP_CHECK(hipEventElapsedTime(&out[i], ev[i], ev[i + 1]));
-        for (auto &e : ev) (void)hipEventDestroy(e);
         return QC_OK;
     }
     // Launch units are independent; they go to QC_NSTREAMS side streams (one hardware queue each next to the main
@@ -319,13 +328,14 @@ int qc_launch_fock_classes(qc_system *S, const QcFockArgs &fa, float *class_ms, 
         // each proposes the next assignment (longest-first on the durations seen *inside* the build, over 4 to 7 streams - fewer
         // concurrent kernels disturb each other less), the fastest is kept.
         S->unit_ms.assign(units.size(), 0.f);
-        const size_t gbytes = (size_t)a.nrep * a.rep_stride * sizeof(double);
+        const size_t gbytes = (fa.fxs ? 2 : 1) * (size_t)a.nrep * a.rep_stride * sizeof(double);   // (hi and lo planes are contiguous)
         int rc = qc_launch_fock_classes(S, fa, nullptr, S->unit_ms.data());     // warm-up: first launches pay code upload
         if (rc == QC_OK) rc = qc_launch_fock_classes(S, fa, nullptr, S->unit_ms.data());   // serial, timed
         if (rc != QC_OK) return rc;
         lpt(S->unit_ms, QC_NSTREAMS);
-        std::vector<hipEvent_t> ev(2 + 2 * units.size());
-        for (auto &e : ev) QC_HIP_CHECK(hipEventCreate(&e));
+        EventList evl;
+        if (evl.create(2 + 2 * units.size()) != QC_OK) return QC_ERR_HIP;
+        std::vector<hipEvent_t> &ev = evl.ev;
         std::vector<std::vector<int>> cand;
         std::vector<std::vector<float>> weight;
         std::vector<float> total;
@@ -372,10 +382,58 @@ int qc_launch_fock_classes(qc_system *S, const QcFockArgs &fa, float *class_ms, 
             if (tmin < best_t) { best_t = tmin; best = rank[r]; }
         }
         S->unit_stream = cand[best]; S->unit_weight = weight[best];
-        for (auto &e : ev) (void)hipEventDestroy(e);
         if (fa.G0) QC_HIP_CHECK(hipMemsetAsync(fa.G0, 0, gbytes, S->stream));
     }
     return launch_concurrent(nullptr, false);
+}
+
+// Schwarz pass (the reference's own TODO at uhf.rs:49-50): the (P|P) quartet of every stored pair through the
+// class kernels in their `schwarz_out` mode - unsplit slots / one-ket bundles, serial launches, once per geometry.
+int qc_schwarz_device(qc_system *S) {
+    const size_t np = S->pairs.size();
+    double *d_q = nullptr;
+    QC_HIP_CHECK(hipMalloc(&d_q, np * sizeof(double)));
+    struct Free { double *p; ~Free() { (void)hipFree(p); } } guard{d_q};
+    QC_HIP_CHECK(hipMemsetAsync(d_q, 0, np * sizeof(double), S->stream));
+    QcFockArgs fa{};
+    fa.schwarz_out = d_q;
+    const QcKernelArgs a = base_args(S, fa);
+    std::vector<QcSlot> slots;
+    std::vector<QcBundle> bundles; std::vector<int> ketlist;
+    std::vector<QcTask> diag;
+    for (const auto &c : S->classes) {
+        diag.clear();
+        for (const auto &t : c.tasks) if (t.bra == t.ket) diag.push_back(t);
+        if (diag.empty()) continue;
+        if (c.bm) {
+            qc_make_bundles(S, diag, 0, bundles, ketlist);
+            QcBundle *db = nullptr; int *dk = nullptr;
+            QC_HIP_CHECK(hipMalloc(&db, bundles.size() * sizeof(QcBundle)));
+            QC_HIP_CHECK(hipMalloc(&dk, ketlist.size() * sizeof(int)));
+            QC_HIP_CHECK(hipMemcpyAsync(db, bundles.data(), bundles.size() * sizeof(QcBundle), hipMemcpyHostToDevice, S->stream));
+            QC_HIP_CHECK(hipMemcpyAsync(dk, ketlist.data(), ketlist.size() * sizeof(int), hipMemcpyHostToDevice, S->stream));
+            int mx = 0;
+            for (const auto &t : diag) mx = std::max(mx, S->pairs[t.bra].na * S->pairs[t.bra].nb * S->pairs[t.ket].na * S->pairs[t.ket].nb);
+            int rc = launch_segments(S, qc_unit_of(c.LAB, c.LCD, true), {Seg{&c, nullptr, (int)bundles.size(), db, dk, mx * 65 * 8}}, S->stream, a);
+            QC_HIP_CHECK(hipStreamSynchronize(S->stream));
+            (void)hipFree(db); (void)hipFree(dk);
+            if (rc != QC_OK) return rc;
+            continue;
+        }
+        qc_make_slots(S, diag, 0, false, slots);
+        QcSlot *d = nullptr;
+        QC_HIP_CHECK(hipMalloc(&d, slots.size() * sizeof(QcSlot)));
+        QC_HIP_CHECK(hipMemcpyAsync(d, slots.data(), slots.size() * sizeof(QcSlot), hipMemcpyHostToDevice, S->stream));
+        int rc = launch_segments(S, qc_unit_of(c.LAB, c.LCD, false), {Seg{&c, d, (int)slots.size()}}, S->stream, a);
+        QC_HIP_CHECK(hipStreamSynchronize(S->stream));
+        (void)hipFree(d);
+        if (rc != QC_OK) return rc;
+    }
+    S->pairQ.assign(np, 0.0);
+    QC_HIP_CHECK(hipMemcpy(S->pairQ.data(), d_q, np * sizeof(double), hipMemcpyDeviceToHost));
+    S->imax = 0.0;
+    for (double q : S->pairQ) S->imax = std::max(S->imax, q * q);
+    return QC_OK;
 }
 
 // molint::eri replacement for tests/plumbing: unsplit slots (every quartet complete in one slot) + plain stores

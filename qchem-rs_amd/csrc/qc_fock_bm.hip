@@ -24,6 +24,8 @@
 // wave-cycles waiting to issue).  Same evaluation as qc_boys<L>.
 // f64 add into LDS through the DS unit (a generic pointer would make it a flat atomic)
 typedef __attribute__((address_space(3))) double qc_lds_double;
+// (the row buffer belongs to one wave and every add to it is an instruction of that wave: the DS unit serves the lanes of an
+// instruction in a fixed order, so these sums do not depend on timing - f64 is fine here in the fixed-point mode too)
 __device__ __forceinline__ void qc_lds_add(double *p, double v) { (void)__builtin_amdgcn_ds_atomic_fadd_f64((qc_lds_double *)p, v); }
 
 constexpr int QC_BM_TROW = 9;
@@ -176,6 +178,7 @@ __device__ __forceinline__ void qc_bm_body(const QcKernelArgs &a, const double *
     const double *__restrict__ pd = a.pairdata;
     const int n = a.n;
     const bool uhf = a.Dk1 != nullptr;
+    const double fxscale = a.fxs ? a.fxs[0] : 0.0;           // 0: f64 atomics
 
     const QcBundle bd = bundles[blk];
     const int bra = __builtin_amdgcn_readfirstlane(bd.bra);
@@ -205,6 +208,15 @@ __device__ __forceinline__ void qc_bm_body(const QcKernelArgs &a, const double *
 
     const int nd = pk.nb;                                     // (nc, nd) = (1,1), (3,1) or (1,3)
     const int c0 = pk.offa, d0 = pk.offb;
+    if (a.schwarz_out != nullptr) {
+        // Schwarz factors: the bundles are (P|P) quartets, one ket per bundle; the largest element of the block is on its diagonal
+        if (active) {
+            double m = 0.0;
+            for (int x = 0; x < nab * NC; ++x) m = fmax(m, fabs(I[x * LS]));
+            a.schwarz_out[ket] = sqrt(m);
+        }
+        return;
+    }
     if (a.eri_out != nullptr) {
         // materialise (ij|kl) with its 8 symmetry images (tests / stored-tensor mode; bundles are not cut along ij there)
         if (active) {
@@ -243,7 +255,7 @@ __device__ __forceinline__ void qc_bm_body(const QcKernelArgs &a, const double *
     // touched element after the bundle; without one they go to global memory directly.
     auto kadd = [&](int sp, int r, int grow, int col, double v) {
         if (rowbuf) qc_lds_add(&rowbuf[((size_t)sp * rowcap + r) * n + col], v);
-        else unsafeAtomicAdd(&(sp ? G1 : G0)[(size_t)grow * n + col], v);
+        else qc_gadd(&(sp ? G1 : G0)[(size_t)grow * n + col], v, fxscale, a.fx_lo);
     };
     auto kadd3 = [&](int sp, int r, int grow, const double (&accK)[NC], const double (&accL)[NC]) {
         if constexpr (NC == 1) {
@@ -318,8 +330,7 @@ __device__ __forceinline__ void qc_bm_body(const QcKernelArgs &a, const double *
 #pragma unroll
         for (int c = 0; c < NC; ++c) {
             const size_t o = (size_t)(c0 + kc[c]) * n + d0 + lc[c];
-            unsafeAtomicAdd(&G0[o], fj * jcd[c]);
-            if (uhf) unsafeAtomicAdd(&G1[o], fj * jcd[c]);
+            qc_gadd2(&G0[o], &G1[o], uhf, fj * jcd[c], fxscale, a.fx_lo);
         }
     }
     // same-wave LDS hand-off (DS operations of a wave execute in order): lane ab sums row ab over the 64 columns
@@ -332,8 +343,7 @@ __device__ __forceinline__ void qc_bm_body(const QcKernelArgs &a, const double *
 #pragma unroll 8
         for (int j = 0; j < 64; j += 2) { s0 += row[j]; s1 += row[j + 1]; }
         const size_t o = (size_t)(offa + ab / nb) * n + offb + ab % nb;
-        unsafeAtomicAdd(&G0[o], s0 + s1);
-        if (uhf) unsafeAtomicAdd(&G1[o], s0 + s1);
+        qc_gadd2(&G0[o], &G1[o], uhf, s0 + s1, fxscale, a.fx_lo);
     }
 }
 
@@ -374,6 +384,7 @@ __device__ __forceinline__ void qc_bm_segment(const QcBmArgs &a, const int s, co
     const QcBundle *__restrict__ bundles = a.seg_bundles[s];
     // the rows a wave has accumulated for the bundle of bra pair `bra` leave as one global atomic per touched element:
     // the 64 kets of a bundle share most of their functions, so the lanes' contributions combine 2-5x in LDS first
+    const double fxscale = a.base.fxs ? a.base.fxs[0] : 0.0;
     auto flush_rows = [&](int bra) {
         const QcPairDesc pb = a.base.pairs[bra];
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
@@ -385,7 +396,7 @@ __device__ __forceinline__ void qc_bm_segment(const QcBmArgs &a, const int s, co
                 double *row = rowbuf + ((size_t)sp * rowcap + r) * n;
                 for (int col = lane; col < n; col += 64) {
                     const double v = row[col];
-                    if (v != 0.0) { unsafeAtomicAdd(&G[(size_t)grow * n + col], v); row[col] = 0.0; }
+                    if (v != 0.0) { qc_gadd(&G[(size_t)grow * n + col], v, fxscale, a.base.fx_lo); row[col] = 0.0; }
                 }
             }
         }
@@ -416,11 +427,11 @@ __global__ __launch_bounds__(qc_bm_waves(LCD, HI) * 64) void qc_fock_bm_kernel(c
 template <int LCD, int HI>
 static int launch_bm(int grid, int nwaves, size_t lds, hipStream_t st, const QcBmArgs &a) {
     auto kern = qc_fock_bm_kernel<LCD, HI>;
-    static size_t lds_allowed = 48 * 1024;
-    if (lds > lds_allowed) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    static std::atomic<bool> raised{false};       // once per instantiation, to the device maximum (see qc_launch_tier)
+    if (lds > 48 * 1024 && !raised.load(std::memory_order_acquire)) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, QC_LDS_MAX);
         if (e != hipSuccess) return QC_ERR_HIP;
-        lds_allowed = lds;
+        raised.store(true, std::memory_order_release);
     }
     hipLaunchKernelGGL(kern, dim3(grid), dim3(nwaves * 64), lds, st, a);
     return hipGetLastError() == hipSuccess ? QC_OK : QC_ERR_HIP;

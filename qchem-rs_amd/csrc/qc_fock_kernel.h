@@ -25,6 +25,7 @@
 // (The classes with an ss / ps ket and L <= 4 - one whole quartet per lane - are the bra-major kernels, qc_fock_bm.hip.)
 #pragma once
 #include "qc_internal.h"
+#include <atomic>
 #include <utility>
 
 struct QcKernelArgs {
@@ -39,7 +40,56 @@ struct QcKernelArgs {
     int nrep;                 // accumulation replicas (spreads global-atomic contention)
     double cK;
     double *eri_out;
+    const double *fxs;        // accumulation mode of G0 / G1: non-null = two-limb 64-bit fixed point (order-independent, exact) with
+                              // the scale 2^S of this build at fxs[0] (qc_fx_scale_kernel); null = f64 atomics
+    size_t fx_lo;             // doubles from an element of the hi plane to the same element of the lo plane
+    double *schwarz_out;      // if non-null: no digestion - the slots are (P|P) quartets and sqrt(max |(ab|cd)|) goes to [P]
 };
+
+// ---- order-independent, exact accumulation.  The digestion adds ~10^3 contributions from different waves into every
+// element of Gt; with f64 atomics the sum depends on the order the memory system happens to serve them in, so two builds
+// from the same density differ in the last bits - and the reference, which evaluates both spins (and every build) with one
+// fixed sequence of operations (uhf.rs:80-108, 210-227), never sees such noise.  In fixed-point mode a contribution v is
+// split into two 64-bit integers, hi = rint(v 2^S) and lo = rint((v 2^S - hi) 2^32), which are added to two accumulator
+// planes with integer atomics (global_atomic_add_x2).  Integer addition is associative: the result is the same whatever the
+// order, the replica, the stream assignment or the number of ranks (the all-reduce adds integers too).  S comes from a
+// rigorous bound on |Gt| (qc_fx_scale, qc_linalg.hip), so the hi plane cannot leave 62 bits; the lo plane carries 32 more
+// bits, unit 2^-(S+32) Eh - 3e-23 for benzene - so the sum is exact to far below the rounding of a single contribution:
+// more accurate than f64 accumulation, not less, also when a near-singular overlap matrix blows the density up to 1e6.
+__device__ __forceinline__ void qc_fx2(double v, double scale, unsigned long long &hi, unsigned long long &lo) {
+    const double t = v * scale;                                             // exact (power of two)
+    const double th = __builtin_rint(t);                                    // integer-valued, |th| < 2^62
+    const double tl = __builtin_rint((t - th) * 0x1p32);                    // t - th exact, |tl| <= 2^31
+    const double h1 = __builtin_floor(th * 0x1p-32);
+    const double h0 = __builtin_fma(h1, -0x1p32, th);                       // exact, 0 <= h0 < 2^32
+    hi = ((unsigned long long)(unsigned)(int)h1 << 32) | (unsigned long long)(unsigned)h0;
+    lo = (unsigned long long)(long long)(int)tl;                            // (+2^31 saturates one unit of 2^-(S+32) short: harmless)
+}
+// p: element of the hi plane; the lo plane lies lo_off doubles behind it
+__device__ __forceinline__ void qc_gadd(double *p, double v, double fxscale, size_t lo_off) {
+    if (fxscale != 0.0) {
+        unsigned long long hi, lo;
+        qc_fx2(v, fxscale, hi, lo);
+        atomicAdd(reinterpret_cast<unsigned long long *>(p), hi);
+        atomicAdd(reinterpret_cast<unsigned long long *>(p + lo_off), lo);
+    } else unsafeAtomicAdd(p, v);
+}
+// the same value into the two spins' matrices (Coulomb terms): one conversion
+__device__ __forceinline__ void qc_gadd2(double *p0, double *p1, bool two, double v, double fxscale, size_t lo_off) {
+    if (fxscale != 0.0) {
+        unsigned long long hi, lo;
+        qc_fx2(v, fxscale, hi, lo);
+        atomicAdd(reinterpret_cast<unsigned long long *>(p0), hi);
+        atomicAdd(reinterpret_cast<unsigned long long *>(p0 + lo_off), lo);
+        if (two) {
+            atomicAdd(reinterpret_cast<unsigned long long *>(p1), hi);
+            atomicAdd(reinterpret_cast<unsigned long long *>(p1 + lo_off), lo);
+        }
+    } else {
+        unsafeAtomicAdd(p0, v);
+        if (two) unsafeAtomicAdd(p1, v);
+    }
+}
 
 template <int L>
 __device__ __forceinline__ void qc_rtab(double alpha, double X, double Y, double Z, const double (&F)[L + 1], double (&R)[qc_nherm(L)]);
@@ -249,6 +299,8 @@ __device__ __forceinline__ void qc_fock_body(const QcKernelArgs &a, const QcSlot
     const double *__restrict__ pd = a.pairdata;
     const int n = a.n;
     const bool uhf = a.Dk1 != nullptr;
+    const double fxscale = a.fxs ? a.fxs[0] : 0.0;          // 0: f64 atomics
+    const bool digest = a.eri_out == nullptr && a.schwarz_out == nullptr;
     constexpr bool HOIST = qc_hoisted(L);
     constexpr int CH = qc_hoist_chunk(L, LGC);                  // primitive quartets per chunk of the hoisted path
     constexpr int NHP = qc_nherm(L) | 1;                    // padded table length of the hoisted path
@@ -282,7 +334,7 @@ __device__ __forceinline__ void qc_fock_body(const QcKernelArgs &a, const QcSlot
 
         if (active) {
             for (int i = li; i < nab * ncd; i += C) Iblk[i] = 0.0;
-            if (a.eri_out == nullptr) {   // stage the density tiles this quartet touches
+            if (digest) {   // stage the density tiles this quartet touches
                 for (int i = li; i < nab; i += C) { const int r = qc_fdiv(i, inb); tDj_ab[i] = a.Dj[(size_t)(pb.offa + r) * n + pb.offb + i - r * nb]; }
                 for (int i = li; i < ncd; i += C) { const int r = qc_fdiv(i, ind); tDj_cd[i] = a.Dj[(size_t)(pk.offa + r) * n + pk.offb + i - r * nd]; }
                 for (int s = 0; s < (uhf ? 2 : 1); ++s) {
@@ -611,7 +663,15 @@ __device__ __forceinline__ void qc_fock_body(const QcKernelArgs &a, const QcSlot
 
         if (active) {
             const double f = (pb.shA_eq_shB ? 0.5 : 1.0) * (pk.shA_eq_shB ? 0.5 : 1.0) * (sl.bra == sl.ket ? 0.5 : 1.0);
-            if (a.eri_out != nullptr) {
+            if (a.schwarz_out != nullptr) {
+                // Schwarz factor of pair P from the complete (P|P) block (unsplit slot): by the Schwarz inequality the largest
+                // |(ab|cd)| of the block sits on its diagonal, so no index matching is needed
+                double m = 0.0;
+                for (int x = li; x < nab * ncd; x += C) m = fmax(m, fabs(Iblk[x]));
+#pragma unroll
+                for (int o = C / 2; o > 0; o >>= 1) m = fmax(m, __shfl_xor(m, o, C));
+                if (li == 0) a.schwarz_out[sl.bra] = sqrt(m);
+            } else if (a.eri_out != nullptr) {
                 // materialise (ij|kl) with its 8 symmetry images: the tensor molint::eri returns (tests / plumbing only;
                 // the host hands this mode unsplit slots, so plain stores are complete values)
                 const size_t n1 = n, n2 = n1 * n1, n3 = n2 * n1;
@@ -636,8 +696,7 @@ __device__ __forceinline__ void qc_fock_body(const QcKernelArgs &a, const QcSlot
                     for (int cd = cbeg; cd < cend; ++cd) s = fma(Iblk[ab * ncd + cd], tDj_cd[cd], s);
                     const int r = qc_fdiv(ab, inb);
                     const size_t o = (size_t)(pb.offa + r) * n + pb.offb + ab - r * nb;
-                    unsafeAtomicAdd(&G0[o], fj * s);
-                    if (uhf) unsafeAtomicAdd(&G1[o], fj * s);
+                    qc_gadd2(&G0[o], &G1[o], uhf, fj * s, fxscale, a.fx_lo);
                 }
                 for (int cd = cbeg + li; cd < cend; cd += C) {
                     double s = 0.0;
@@ -645,8 +704,7 @@ __device__ __forceinline__ void qc_fock_body(const QcKernelArgs &a, const QcSlot
                     for (int ab = 0; ab < nab; ++ab) s = fma(Iblk[ab * ncd + cd], tDj_ab[ab], s);
                     const int r = qc_fdiv(cd, ind);
                     const size_t o = (size_t)(pk.offa + r) * n + pk.offb + cd - r * nd;
-                    unsafeAtomicAdd(&G0[o], fj * s);
-                    if (uhf) unsafeAtomicAdd(&G1[o], fj * s);
+                    qc_gadd2(&G0[o], &G1[o], uhf, fj * s, fxscale, a.fx_lo);
                 }
                 // K blocks: Gt_ac -= cK f sum_bd I D_bd, and the ad / bc / bd images
                 const double fk = -a.cK * f;
@@ -660,7 +718,7 @@ __device__ __forceinline__ void qc_fock_body(const QcKernelArgs &a, const QcSlot
                         for (int j = 0; j < nb; ++j)
 #pragma unroll 3
                             for (int l = l0; l < l1; ++l) acc = fma(Iblk[(i * nb + j) * ncd + k * nd + l], t_bd[j * nd + l], acc);
-                        unsafeAtomicAdd(&Gs[(size_t)(pb.offa + i) * n + pk.offa + k], fk * acc);
+                        qc_gadd(&Gs[(size_t)(pb.offa + i) * n + pk.offa + k], fk * acc, fxscale, a.fx_lo);
                     }
                     for (int x = li; x < na * nd; x += C) {          // (i,l) <- sum_{j,k} I[ij,kl] D[j,k]
                         const int i = qc_fdiv(x, ind), l = x - i * nd;
@@ -669,7 +727,7 @@ __device__ __forceinline__ void qc_fock_body(const QcKernelArgs &a, const QcSlot
                         for (int j = 0; j < nb; ++j)
 #pragma unroll 3
                             for (int k = k0; k < k1; ++k) acc = fma(Iblk[(i * nb + j) * ncd + k * nd + l], t_bc[j * nc + k], acc);
-                        unsafeAtomicAdd(&Gs[(size_t)(pb.offa + i) * n + pk.offb + l], fk * acc);
+                        qc_gadd(&Gs[(size_t)(pb.offa + i) * n + pk.offb + l], fk * acc, fxscale, a.fx_lo);
                     }
                     for (int x = li; x < nb * nc; x += C) {          // (j,k) <- sum_{i,l} I[ij,kl] D[i,l]
                         const int j = qc_fdiv(x, inc), k = x - j * nc;
@@ -678,7 +736,7 @@ __device__ __forceinline__ void qc_fock_body(const QcKernelArgs &a, const QcSlot
                         for (int i = 0; i < na; ++i)
 #pragma unroll 3
                             for (int l = l0; l < l1; ++l) acc = fma(Iblk[(i * nb + j) * ncd + k * nd + l], t_ad[i * nd + l], acc);
-                        unsafeAtomicAdd(&Gs[(size_t)(pb.offb + j) * n + pk.offa + k], fk * acc);
+                        qc_gadd(&Gs[(size_t)(pb.offb + j) * n + pk.offa + k], fk * acc, fxscale, a.fx_lo);
                     }
                     for (int x = li; x < nb * nd; x += C) {          // (j,l) <- sum_{i,k} I[ij,kl] D[i,k]
                         const int j = qc_fdiv(x, ind), l = x - j * nd;
@@ -687,7 +745,7 @@ __device__ __forceinline__ void qc_fock_body(const QcKernelArgs &a, const QcSlot
                         for (int i = 0; i < na; ++i)
 #pragma unroll 3
                             for (int k = k0; k < k1; ++k) acc = fma(Iblk[(i * nb + j) * ncd + k * nd + l], t_ac[i * nc + k], acc);
-                        unsafeAtomicAdd(&Gs[(size_t)(pb.offb + j) * n + pk.offb + l], fk * acc);
+                        qc_gadd(&Gs[(size_t)(pb.offb + j) * n + pk.offb + l], fk * acc, fxscale, a.fx_lo);
                     }
                 }
             }
@@ -735,11 +793,13 @@ void qc_fock_tier_kernel(const QcTierArgs a) {
 template <int LAB, int TIER>
 int qc_launch_tier(int grid, size_t lds, hipStream_t st, const QcTierArgs &a) {
     auto kern = qc_fock_tier_kernel<LAB, TIER>;
-    static size_t lds_allowed = 48 * 1024;      // raise the dynamic-LDS cap once per instantiation, not per launch
-    if (lds > lds_allowed) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    // the dynamic-LDS cap of this instantiation is raised once, to the device maximum (the attribute is process-wide, so a
+    // per-handle high-water mark would let one handle lower another's cap; the flag only saves the repeated call)
+    static std::atomic<bool> raised{false};
+    if (lds > 48 * 1024 && !raised.load(std::memory_order_acquire)) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, QC_LDS_MAX);
         if (e != hipSuccess) return QC_ERR_HIP;
-        lds_allowed = lds;
+        raised.store(true, std::memory_order_release);
     }
     hipLaunchKernelGGL(kern, dim3(grid), dim3(64), lds, st, a);
     return hipGetLastError() == hipSuccess ? QC_OK : QC_ERR_HIP;

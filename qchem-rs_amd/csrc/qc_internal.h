@@ -27,6 +27,9 @@ __host__ __device__ constexpr int qc_region0(int L, int lgc) {
       // primitive quartets per slot
 constexpr double QC_PRIM_CUTOFF = 1e-17; // primitive pairs whose Hermite expansion block is entirely below this are dropped
 constexpr int QC_NREP = 32;             // replicas of the Fock accumulation buffer
+constexpr int QC_FX_MAXBITS = 52;       // fixed-point accumulation: finest unit 2^-52 Eh; the scale of a build follows its density (qc_fx_scale)
+constexpr double QC_SCHWARZ_TAU = 1e-12; // quartets with sqrt((ab|ab) (cd|cd)) below this are not evaluated (default)
+constexpr int QC_LDS_MAX = 160 * 1024;  // LDS of a gfx950 CU, the cap the kernels with dynamic LDS are allowed
 constexpr int QC_TUNE_ROUNDS = 6;        // concurrent builds measured before the stream assignment is frozen
 constexpr int QC_NSTREAMS = 7;          // class kernels of one build run concurrently on this many streams
 constexpr int QC_NUNITS = 2 * (QC_LPAIR + 1) + 4;   // launch units of one build: (LAB, tier) of the column kernels + 4 bra-major launches
@@ -103,6 +106,10 @@ struct qc_system {
     std::vector<double> pspack;                 // ps pairs, 8 doubles per primitive: [q, Q(3), E_0[x,y,z], E_1] (see qc_fock_bm.hip)
     std::vector<double> pairdataT;              // same blocks with the expansion stored [ab][h] (bra side of the bra-major kernels)
     std::vector<QcClass> classes;
+    std::vector<double> pairQ;                  // Schwarz factor sqrt(max_ab (ab|ab)) of each stored pair (empty until the device pass has run)
+    double imax = 0.0;                          // max pairQ^2: bound on every |(ij|kl)|
+    double schwarz_tau = QC_SCHWARZ_TAU;        // 0: no screening
+    int64_t nscreened = 0;                      // quartets (of the whole list, all ranks) dropped by the Schwarz bound
     int64_t nquartets = 0;
     int rank = 0, nranks = 1;
     // device
@@ -118,18 +125,17 @@ struct qc_system {
     QcPairDesc *d_pairs = nullptr;
     double *d_boys = nullptr;
     double *d_D = nullptr, *d_G = nullptr;   // 2 * n*n each (alpha/beta or Dj/Dk)
-    double *d_Gtmp = nullptr;                // 2 * n*n accumulation target
+    double *d_Gtmp = nullptr;                // accumulation target: [plane (hi, lo)][replica][spin][n*n]
+    double *d_Gred = nullptr;                // replicas folded: [plane][spin][n*n]
     double *d_Dj = nullptr;
+    double *d_fxs = nullptr;                 // [2^S, 2^-S]: fixed-point scale of the current build
     int *d_flag = nullptr;
     void *comm = nullptr;                    // ncclComm_t
-    // captured Fock builds (memset + class kernels on the side streams + replica fold), keyed by operand pointers
-    struct FockGraph { const double *Da, *Db; int mode; hipGraphExec_t exec; };
-    std::vector<FockGraph> graphs;
     std::vector<float> unit_ms;              // measured serial time of each launch unit (autotuned once per shard)
     std::vector<int> unit_stream;            // side stream of each launch unit (longest-processing-time assignment)
     std::vector<float> unit_weight;          // durations that order the launches (measured inside concurrent builds)
     int fock_mode = 0;                       // 0 direct (default), 1 stored tensor (the reference's own algorithm)
-    bool use_graphs = false;                 // hipGraph replay of the build measured slower than eager multi-stream launches on ROCm 7.2
+    int accum_fx = 1;                        // 1 (default): fixed-point, order-independent accumulation of G; 0: f64 atomics
     std::string last_error;
 };
 
@@ -159,10 +165,15 @@ struct QcFockArgs {
     double *eri_out;      // if non-null: store the integrals into the n^4 tensor instead of digesting
     int nrep;             // accumulation replicas behind G0/G1
     size_t rep_stride;    // doubles between replicas
+    const double *fxs;    // non-null: G0 / G1 accumulate 64-bit fixed-point integers (hi plane), scale 2^S at fxs[0], 2^-S at fxs[1] (device)
+    size_t fx_lo;         // doubles from the hi plane to the lo plane
+    double *schwarz_out;  // non-null: Schwarz pass over the (P|P) quartets, sqrt(max |(ab|cd)|) per pair (device), no digestion
 };
 int qc_launch_eri_full(qc_system *S, double *d_out);
+int qc_schwarz_device(qc_system *S);     // fills pairQ / imax from the (P|P) quartets, then screens the work lists
+// fixed-point scale of a build from its densities: out[0] = 2^S, out[1] = 2^-S, S = min(QC_FX_MAXBITS, 60 - ceil(log2(4 imax sum|D|)))
+void qc_fx_scale(hipStream_t st, int n, const double *Da, const double *Db /*nullable*/, double imax, double *out);
 int qc_one_electron_device(qc_system *S, int which /* 0 S, 1 T, 2 V */, double *d_out);
-void qc_drop_graphs(qc_system *S);
 int qc_launch_fock_classes(qc_system *S, const QcFockArgs &a, float *class_ms /*nullable*/, float *unit_ms = nullptr /*nullable, 14*/);
 // (dH with dFa / dFb: the Fock matrices H + G are written by the closing kernel as well; *f_done tells whether both were)
 int qc_fock_build_device(qc_system *S, const double *dDa, const double *dDb, double *dGa, double *dGb, bool uhf, int *twin_cache = nullptr,
@@ -185,8 +196,10 @@ void qc_permute_tensor(hipStream_t st, int n, const double *I, double c_direct, 
 void qc_tensor_gemv(hipStream_t st, int n, const double *T1, const double *D1, const double *T2, const double *D2, double *G);
 void qc_axpby(hipStream_t st, int n, double a, const double *x, double b, const double *y, double *out);
 void qc_sub_transpose(hipStream_t st, int n, const double *M, double *out);              // out = M - M^T
-void qc_symmetrize_add(hipStream_t st, int n, const double *Gt, double *G, const double *H = nullptr, double *F = nullptr);   // G = Gt + Gt^T (and F = H + G)
-void qc_reduce_replicas(hipStream_t st, size_t count, int nrep, size_t stride, double *Gt);  // Gt[0] += sum_r>0 Gt[r]
+// (fxs non-null: Gt = [hi | lo] planes of 64-bit fixed-point integers, lo_off doubles apart, units fxs[1] = 2^-S and 2^-(S+32))
+void qc_symmetrize_add(hipStream_t st, int n, const double *Gt, size_t lo_off, double *G, const double *H, double *F, const double *fxs);   // G = Gt + Gt^T (and F = H + G)
+// out[p * count + x] = sum_r Gt[p * plane_stride + r * stride + x], p < (fx ? 2 : 1)
+void qc_reduce_replicas(hipStream_t st, size_t count, int nrep, size_t stride, const double *Gt, double *out, bool fx, size_t plane_stride);
 void qc_count_diff(hipStream_t st, size_t count, const double *a, const double *b, int *flag);
 int qc_lgc_for(int lab, int lcd, int ncd);
 // owner of the i-th (cost-sorted) quartet of launch class `ci`: boustrophedon deal, start rank rotated per class

@@ -820,16 +820,53 @@ void qc_sub_transpose(hipStream_t st, int n, const double *M, double *out) {
 
 // G = Gt + Gt^T: closes the unique-quartet digestion (fock_finalize)
 // (with H and F given, F = H + G - the Fock matrix of rhf.rs:68 - leaves in the same launch)
-__global__ void qc_symmetrize_add_kernel(int n, const double *Gt, double *G, const double *H, double *F) {
+// FX: Gt = [hi plane | lo plane] of 64-bit fixed-point integers, units fxs[1] = 2^-S and 2^-(S+32) (qc_fock_kernel.h): the two
+// halves are added as integers, the planes meet in one fma when the sum becomes a double - G is symmetric bit for bit
+template <bool FX>
+__global__ void qc_symmetrize_add_kernel(int n, const double *Gt, size_t lo_off, double *G, const double *H, double *F, const double *fxs) {
+    const double u1 = FX ? fxs[1] : 1.0, u2 = u1 * 0x1p-32;
     for (int x = blockIdx.x * blockDim.x + threadIdx.x; x < n * n; x += gridDim.x * blockDim.x) {
         const int i = x / n, j = x - i * n;
-        const double g = Gt[x] + Gt[j * n + i];
+        double g;
+        if constexpr (FX) {
+            const long long *Gh = reinterpret_cast<const long long *>(Gt), *Gl = Gh + lo_off;
+            g = fma((double)(Gl[x] + Gl[j * n + i]), u2, (double)(Gh[x] + Gh[j * n + i]) * u1);
+        } else g = Gt[x] + Gt[j * n + i];
         G[x] = g;
         if (F) F[x] = 1.0 * H[x] + 1.0 * g;              // the arithmetic of qc_axpby(1, H, 1, G)
     }
 }
-void qc_symmetrize_add(hipStream_t st, int n, const double *Gt, double *G, const double *H, double *F) {
-    hipLaunchKernelGGL(qc_symmetrize_add_kernel, dim3((n * n + 255) / 256), dim3(256), 0, st, n, Gt, G, H, F);
+void qc_symmetrize_add(hipStream_t st, int n, const double *Gt, size_t lo_off, double *G, const double *H, double *F, const double *fxs) {
+    if (fxs) hipLaunchKernelGGL(qc_symmetrize_add_kernel<true>, dim3((n * n + 255) / 256), dim3(256), 0, st, n, Gt, lo_off, G, H, F, fxs);
+    else hipLaunchKernelGGL(qc_symmetrize_add_kernel<false>, dim3((n * n + 255) / 256), dim3(256), 0, st, n, Gt, lo_off, G, H, F, fxs);
+}
+
+// Fixed-point scale of one Fock build.  Every |(ij|kl)| <= imax (Schwarz) and every element of Gt is a sum of terms
+// f (ij|kl) D_kl with |f| <= 2 in which each D_kl occurs at most once per kind (J, K), so |Gt_ij| <= 3 imax sum|D| and
+// 2^S (4 imax sum|D|) <= 2^60 keeps every partial and final sum inside 62 bits - wrap-around cannot happen.  One workgroup,
+// fixed reduction order: the same densities give the same scale on every rank.
+__global__ __launch_bounds__(1024) void qc_fx_scale_kernel(int nn, const double *__restrict__ Da, const double *__restrict__ Db, double imax,
+                                                           double *__restrict__ out) {
+    __shared__ double sh[16];
+    double s = 0.0;
+    for (int x = threadIdx.x; x < nn; x += 1024) s += fabs(Da[x]) + (Db ? fabs(Db[x]) : 0.0);
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o, 64);
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double t = 0.0;
+        for (int k = 0; k < 16; ++k) t += sh[k];
+        const double bound = 4.0 * imax * t;
+        int e = 0;
+        if (bound > 0.0 && bound < 1e300) { (void)frexp(bound, &e); }      // bound < 2^e
+        else if (!(bound < 1e300)) e = 1100;                              // inf / nan densities: coarsest scale
+        int S = 60 - e;
+        S = S > QC_FX_MAXBITS ? QC_FX_MAXBITS : (S < -900 ? -900 : S);
+        out[0] = ldexp(1.0, S); out[1] = ldexp(1.0, -S);
+    }
+}
+void qc_fx_scale(hipStream_t st, int n, const double *Da, const double *Db, double imax, double *out) {
+    hipLaunchKernelGGL(qc_fx_scale_kernel, dim3(1), dim3(1024), 0, st, n * n, Da, Db, imax, out);
 }
 
 // flag[0] = number of positions where a and b differ bitwise (spin-symmetry test of the UHF build)
@@ -843,27 +880,34 @@ void qc_count_diff(hipStream_t st, size_t count, const double *a, const double *
     hipLaunchKernelGGL(qc_count_diff_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, st, count, a, b, flag);
 }
 
-// Gt[0][x] += sum_{r>0} Gt[r][x]: folds the accumulation replicas of the Fock build
+// out[p][x] = sum_r Gt[p][r][x]: folds the accumulation replicas of the Fock build, plane by plane (f64: one plane; fixed
+// point: hi and lo planes, `plane_stride` doubles apart, summed as integers); the sums of the planes land back to back in `out`
 // (a small matrix gives only a dozen workgroups, so the kernel is as long as its chain of loads: eight replicas are requested
 // at a time - four independent partial sums, combined in a fixed order)
-__global__ void qc_reduce_replicas_kernel(size_t count, int nrep, size_t stride, double *Gt) {
-    for (size_t x = blockIdx.x * (size_t)blockDim.x + threadIdx.x; x < count; x += (size_t)gridDim.x * blockDim.x) {
-        double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+template <typename T>
+__global__ void qc_reduce_replicas_kernel(size_t count, int nrep, size_t stride, int nplanes, size_t plane_stride, const T *Gt, T *out) {
+    for (size_t y = blockIdx.x * (size_t)blockDim.x + threadIdx.x; y < count * nplanes; y += (size_t)gridDim.x * blockDim.x) {
+        const size_t p = y / count, x = y - p * count;
+        const T *base = Gt + p * plane_stride + x;
+        T s0 = 0, s1 = 0, s2 = 0, s3 = 0;
         int r = 0;
         for (; r + 8 <= nrep; r += 8) {
-            const double *g = Gt + (size_t)r * stride + x;
-            const double a0 = g[0], a1 = g[stride], a2 = g[2 * stride], a3 = g[3 * stride];
-            const double a4 = g[4 * stride], a5 = g[5 * stride], a6 = g[6 * stride], a7 = g[7 * stride];
+            const T *g = base + (size_t)r * stride;
+            const T a0 = g[0], a1 = g[stride], a2 = g[2 * stride], a3 = g[3 * stride];
+            const T a4 = g[4 * stride], a5 = g[5 * stride], a6 = g[6 * stride], a7 = g[7 * stride];
             s0 += a0; s1 += a1; s2 += a2; s3 += a3;
             s0 += a4; s1 += a5; s2 += a6; s3 += a7;
         }
-        for (; r < nrep; ++r) s0 += Gt[(size_t)r * stride + x];
-        Gt[x] = (s0 + s1) + (s2 + s3);
+        for (; r < nrep; ++r) s0 += base[(size_t)r * stride];
+        out[y] = (s0 + s1) + (s2 + s3);
     }
 }
-void qc_reduce_replicas(hipStream_t st, size_t count, int nrep, size_t stride, double *Gt) {
-    if (nrep <= 1) return;
-    hipLaunchKernelGGL(qc_reduce_replicas_kernel, dim3((unsigned)((count + 63) / 64)), dim3(64), 0, st, count, nrep, stride, Gt);
+void qc_reduce_replicas(hipStream_t st, size_t count, int nrep, size_t stride, const double *Gt, double *out, bool fx, size_t plane_stride) {
+    const int nplanes = fx ? 2 : 1;
+    const unsigned grid = (unsigned)((count * nplanes + 63) / 64);
+    if (fx) hipLaunchKernelGGL(qc_reduce_replicas_kernel<long long>, dim3(grid), dim3(64), 0, st, count, nrep, stride, nplanes, plane_stride,
+                               reinterpret_cast<const long long *>(Gt), reinterpret_cast<long long *>(out));
+    else hipLaunchKernelGGL(qc_reduce_replicas_kernel<double>, dim3(grid), dim3(64), 0, st, count, nrep, stride, nplanes, plane_stride, Gt, out);
 }
 
 __device__ __forceinline__ double block_sum_256(double v, double *sh) {

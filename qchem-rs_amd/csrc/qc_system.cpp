@@ -349,23 +349,33 @@ void qc_make_bundles(const qc_system *S, const std::vector<QcTask> &tasks, int i
 // (0..N-1, N-1..0, ...; start rank rotated per class), so each rank holds the same mix of classes and nearly the same
 // modelled cost.  Data-only; no communication.
 void qc_build_shards(qc_system *S) {
+    // Schwarz screening (once the factors exist - they come from a device pass): |(ab|cd)| <= Q_ab Q_cd, quartets below
+    // schwarz_tau are not evaluated.  Density-independent, so the work lists stay static; the reference visits every quartet
+    // (its own TODO, uhf.rs:49-50), throughput figures keep counting the enumerated ones.
+    const bool screen = !S->pairQ.empty() && S->schwarz_tau > 0.0;
+    S->nscreened = 0;
+    std::vector<QcTask> kept;
     for (size_t ci = 0; ci < S->classes.size(); ++ci) {
         auto &c = S->classes[ci];
         // heaviest first: the primitive-quartet count is the dominant cost inside a class
         std::stable_sort(c.tasks.begin(), c.tasks.end(), [&](const QcTask &x, const QcTask &y) {
             return (int64_t)S->pairs[x.bra].K * S->pairs[x.ket].K > (int64_t)S->pairs[y.bra].K * S->pairs[y.ket].K;
         });
+        kept.clear();
+        for (const auto &t : c.tasks)
+            if (!screen || S->pairQ[t.bra] * S->pairQ[t.ket] >= S->schwarz_tau) kept.push_back(t);
+        S->nscreened += (int64_t)(c.tasks.size() - kept.size());
         c.shard.clear();
         std::vector<QcBundle> pb; std::vector<int> kl;
-        if (c.bm && S->nranks > 1) qc_make_bundles(S, c.tasks, 0, pb, kl);
+        if (c.bm && S->nranks > 1) qc_make_bundles(S, kept, 0, pb, kl);
         if (pb.size() >= (size_t)8 * S->nranks) {
             // enough of them: deal whole 64-ket bundles, not single quartets, so a rank's waves stay full
             for (size_t i = 0; i < pb.size(); ++i)
                 if (qc_shard_owner(i, S->nranks, ci) == S->rank)
                     for (int k = 0; k < pb[i].nket; ++k) c.shard.push_back(QcTask{pb[i].bra, kl[pb[i].first + k]});
         } else {
-            for (size_t i = 0; i < c.tasks.size(); ++i)
-                if (qc_shard_owner(i, S->nranks, ci) == S->rank) c.shard.push_back(c.tasks[i]);
+            for (size_t i = 0; i < kept.size(); ++i)
+                if (qc_shard_owner(i, S->nranks, ci) == S->rank) c.shard.push_back(kept[i]);
         }
         // slot length: long enough to amortise the per-slot digestion, short enough that the class still fills the chip
         int64_t tot_pq = 0;

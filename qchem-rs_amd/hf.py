@@ -41,7 +41,7 @@ EXPORTS = ["qc_system_create", "qc_system_destroy", "qc_nbasis", "qc_nelectrons"
            "qc_fock_rhf_device", "qc_fock_uhf_device", "qc_sym_eig", "qc_scf_rhf", "qc_scf_uhf", "qc_comm_unique_id",
            "qc_comm_init", "qc_set_shard", "qc_plan_shard", "qc_set_stream", "qc_device_ready", "qc_work_stats_get",
            "qc_fock_profile", "qc_plan_shard_quartets", "qc_scf_begin_rhf", "qc_scf_begin_uhf", "qc_scf_iterate",
-           "qc_scf_orbital_energies", "qc_scf_density", "qc_scf_spin_square", "qc_scf_timings", "qc_scf_end", "qc_fock_profile_tiers", "qc_sym_eig_warm", "qc_set_fock_mode", "qc_scf_tensor_ms"]
+           "qc_scf_orbital_energies", "qc_scf_density", "qc_scf_spin_square", "qc_scf_timings", "qc_scf_end", "qc_fock_profile_tiers", "qc_sym_eig_warm", "qc_set_fock_mode", "qc_scf_tensor_ms", "qc_set_accumulation", "qc_set_schwarz", "qc_scf_matrix"]
 
 
 class QcError(RuntimeError):
@@ -62,7 +62,8 @@ class _Output(C.Structure):
 
 class WorkStats(C.Structure):
     _fields_ = [("quartets", C.c_int64), ("prim_quartets", C.c_int64), ("bytes_alg", C.c_double),
-                ("flops_alg", C.c_double), ("nclasses", C.c_int32)]
+                ("flops_alg", C.c_double), ("nclasses", C.c_int32), ("quartets_enumerated", C.c_int64),
+                ("quartets_screened_out", C.c_int64), ("schwarz_tau", C.c_double)]
 
 
 _lib = None
@@ -116,12 +117,15 @@ def lib():
         L.qc_fock_profile.argtypes = [vp, vp, vp, C.c_int, vp, vp, vp, vp, vp, vp]
         L.qc_fock_profile_tiers.argtypes = [vp, vp, vp, C.c_int, vp, vp, vp, vp, vp]
         L.qc_set_fock_mode.argtypes = [vp, C.c_int]
+        L.qc_set_accumulation.argtypes = [vp, C.c_int]
+        L.qc_set_schwarz.argtypes = [vp, C.c_double]
         L.qc_scf_tensor_ms.argtypes = [vp]; L.qc_scf_tensor_ms.restype = C.c_double
         L.qc_scf_begin_rhf.argtypes = [vp, C.POINTER(vp)]
         L.qc_scf_begin_uhf.argtypes = [vp, C.c_int, C.c_int, C.POINTER(vp)]
         L.qc_scf_iterate.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_double)]
         L.qc_scf_orbital_energies.argtypes = [vp, C.c_int, _dp]
         L.qc_scf_density.argtypes = [vp, C.c_int, _dp]
+        L.qc_scf_matrix.argtypes = [vp, C.c_int, _dp]
         L.qc_scf_spin_square.argtypes = [vp, C.POINTER(C.c_double)]
         L.qc_scf_timings.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double)]
         L.qc_scf_end.argtypes = [vp]; L.qc_scf_end.restype = None
@@ -207,6 +211,14 @@ class System:
         """'direct' (default) or 'stored' (the reference's conventional algorithm, tensor resident in HBM)."""
         _check(lib().qc_set_fock_mode(self._h, {"direct": 0, "stored": 1}[mode]), "qc_set_fock_mode")
 
+    def set_accumulation(self, mode: str):
+        """'fixed' (default: order-independent 64-bit fixed-point sums, bitwise reproducible) or 'f64' (atomics)."""
+        _check(lib().qc_set_accumulation(self._h, {"fixed": 1, "f64": 0}[mode]), "qc_set_accumulation")
+
+    def set_schwarz(self, tau: float):
+        """Schwarz threshold of the work lists (default 1e-12; 0 = every quartet, like the reference)."""
+        _check(lib().qc_set_schwarz(self._h, float(tau)), "qc_set_schwarz")
+
     def set_shard(self, rank, nranks): _check(lib().qc_set_shard(self._h, rank, nranks), "qc_set_shard")
 
     def plan_shard(self, rank, nranks):
@@ -286,6 +298,11 @@ class ScfStepper:
 
     def density(self, spin=0):
         D = np.zeros((self.system.n, self.system.n)); _check(lib().qc_scf_density(self._st, spin, D), "qc_scf_density"); return D
+
+    def matrix(self, which: str):
+        """Set-up matrix of the state: 'S' (overlap), 'H' (core Hamiltonian) or 'X' (S^-1/2, rhf.rs:124-131)."""
+        M = np.zeros((self.system.n, self.system.n))
+        _check(lib().qc_scf_matrix(self._st, {"S": 0, "H": 1, "X": 2}[which], M), "qc_scf_matrix"); return M
 
     def spin_square(self) -> float:
         """<S^2> of the current UHF determinant (0 for RHF)."""

@@ -34,8 +34,9 @@ def test_library_is_native_and_device_ready():
 
 
 @pytest.mark.parametrize("mol,basis", [("hydrogen", "STO-3G"), ("water", "STO-3G"), ("water", "6-31G_st_st"),
-                                       ("water", "cc-pVDZ"), ("ethylene", "STO-3G")])
+                                       ("water", "cc-pVDZ"), ("ethylene", "STO-3G"), ("ethylene", "cc-pVDZ")])
 def test_eri_tensor_matches_oracle(mol, basis):
+    # (ethylene/cc-pVDZ: C spherical d against H p - the shell classes of benzene/cc-pVDZ, BASELINE config 5)
     q, s, o = _sys(mol, basis)
     I_gpu, I_cpu = s.eri(), o.eri()
     assert np.abs(I_gpu - I_cpu).max() < TOL_INT
@@ -315,46 +316,156 @@ def test_uhf_reference_rule_matches_oracle(mol, basis):
 
 
 def test_uhf_triplet_oxygen_extension():
-    """BASELINE config 4: O2 triplet (n_alpha = 9, n_beta = 7) - an extension, checked against the oracle's same extension."""
+    """BASELINE config 4: O2 triplet (n_alpha = 9, n_beta = 7) - an extension, checked against the oracle's same extension.
+
+    The symmetric determinant the reference algorithm settles on is a saddle of the UHF functional (a symmetry-broken one
+    lies 0.024 Eh lower) and the never-reset DIIS(2,8) of uhf.rs:76-78 crawls on it at a density rms of 1e-9..1e-10.  The
+    iteration stays there as long as nothing seeds the unstable direction: the reference's fixed sequence of operations
+    does not, and neither does the fixed-point accumulation of the GPU build (f64 atomics did, in one run of five).  One
+    outcome, asserted three ways."""
     q, s, o = _sys("oxygen", "cc-pVDZ")
-    # This SCF crawls: with the never-reset DIIS(2,8) of uhf.rs:76-78 on a spectrum with exactly degenerate pi shells the
-    # density rms wanders around 1e-9..1e-10 for dozens of passes (the oracle needs 95 to dip below 1e-10; run-to-run
-    # rounding of the atomic accumulation moves the GPU between ~50 and ~200), and the reported stale-G energy
-    # (SURVEY fact 7) is first-order in that residual: at epsilon = 1e-10 the two reported energies agree to a few 1e-9 Eh,
-    # occasionally 1e-8, depending on where each side happens to stop.  The parity statement that does not depend on
-    # the stopping point is the variational energy of the converged densities.
     ref = o.uhf(2000, 1e-10, n_alpha=9, n_beta=7)
     assert ref["status"] == 0
-    st = q.ScfStepper(s, uhf=True, n_alpha=9, n_beta=7)
-    e = rms = None
-    for _ in range(20001):
-        e, rms = st.iterate()
-        if rms / 2.0 < 1e-10:                                  # uhf.rs:139
-            break
+
+    def run():
+        st = q.ScfStepper(s, uhf=True, n_alpha=9, n_beta=7)
+        trace = []
+        for _ in range(2001):
+            e, rms = st.iterate()
+            trace.append((e, rms))
+            if rms / 2.0 < 1e-10:                              # uhf.rs:139
+                break
+        Da, Db = st.density(0), st.density(1)
+        st.close()
+        return trace, Da, Db
+
+    trace, Da, Db = run()
+    e, rms = trace[-1]
     assert rms / 2.0 < 1e-10
-    Da, Db = st.density(0), st.density(1)
-    st.close()
-    # (1) the variational energy of the converged densities - second order in the residual, hence free of the stopping
-    # noise - evaluated by the oracle for both sides
-    I, H, S = o.eri(), o.kinetic() + o.nuclear(), o.overlap()
+    # (1) the variational energy of the converged densities, evaluated by the oracle for both sides
+    I, H = o.eri(), o.kinetic() + o.nuclear()
     evar = lambda A, B: 0.5 * np.sum(A * (2 * H + o.g_uhf(A, B, I))) + 0.5 * np.sum(B * (2 * H + o.g_uhf(B, A, I)))
-    dE = evar(Da, Db) - evar(ref["density_alpha"], ref["density_beta"])
-    if abs(dE) < 1e-9:
-        # (2) the energy as the reference reports it (stale G): first order in the distance to the fixed point on both
-        # sides, and while the iteration crawls that distance is many times the step the stopping rule looks at (a
-        # contraction factor of 0.99 puts a 1e-10 step 1e-8 away), so this is a plausibility bound - (1) is the parity statement
-        assert abs(e + s.nuclear_repulsion() - ref["total_energy"]) < 50 * TOL_E
-        return
-    # The crawl has a cause: the symmetric determinant the reference algorithm settles on (-177.2467 Eh) is a saddle of
-    # the UHF functional - a symmetry-broken determinant lies 0.024 Eh lower - and the iteration sits on it only as long
-    # as nothing seeds the unstable direction.  The oracle's arithmetic keeps the symmetry exactly; the order of the GPU's
-    # atomic accumulation does not (1e-16 relative), the seed grows a few percent per pass, and about one run in five
-    # reaches the lower determinant before the stopping rule fires.  That outcome is accepted only for what it is: a
-    # genuine stationary point (commutator of the oracle's Fock matrices with the densities) of lower energy.
-    assert dE < -1e-3
-    for A, B in ((Da, Db), (Db, Da)):
-        F = H + o.g_uhf(A, B, I)
-        assert np.abs(F @ A @ S - S @ A @ F).max() < 1e-6
+    assert abs(evar(Da, Db) - evar(ref["density_alpha"], ref["density_beta"])) < 1e-9
+    # (2) the energy as the reference reports it (stale G, uhf.rs:145-153) within the north-star bar
+    assert abs(e + s.nuclear_repulsion() - ref["total_energy"]) < TOL_E
+    # (3) a second run repeats the first bit for bit - every pass's energy and rms
+    trace2, Da2, Db2 = run()
+    assert trace2 == trace and np.array_equal(Da2, Da) and np.array_equal(Db2, Db)
+
+
+def test_fock_build_is_bitwise_reproducible():
+    """Fixed-point accumulation (default): a build does not depend on the order the GPU serves its atomic adds in - same
+    bits from repeated builds, from a fresh handle (its own stream tuning) and for the two spins of a closed-shell UHF
+    build (the reference's identical per-spin arithmetic, uhf.rs:80-108, 210-227).  The f64-atomic mode agrees to rounding."""
+    q, s, o = _sys("water", "cc-pVTZ")
+    D = _rand_sym(s.n, 41)
+    G0 = s.fock_rhf(D)
+    assert np.array_equal(G0, G0.T)
+    for _ in range(3):
+        assert np.array_equal(s.fock_rhf(D), G0)
+    s2 = q.System(load_system("water", "cc-pVTZ"))
+    assert np.array_equal(s2.fock_rhf(D), G0)
+    Ga, Gb = s.fock_uhf(D, D)
+    assert np.array_equal(Ga, Gb)
+    I = o.eri()
+    assert np.abs(Ga - o.g_uhf(D, D, I)).max() < TOL_INT * max(1.0, np.abs(Ga).max())
+    # partial matrices of a sharded build are integers too: their sum is the full matrix
+    acc = np.zeros_like(G0)
+    for r in range(4):
+        s2.set_shard(r, 4)
+        acc += s2.fock_rhf(D)
+    assert np.abs(acc - G0).max() < 1e-13 * np.abs(G0).max()
+    s2.set_accumulation("f64")
+    s2.set_shard(0, 1)
+    assert np.abs(s2.fock_rhf(D) - G0).max() < 1e-12 * np.abs(G0).max()
+    s2.close()
+
+
+def test_scf_runs_are_bitwise_reproducible():
+    q, s, o = _sys("water", "cc-pVDZ")
+    outs = [q.restricted_hartree_fock(s, q.HartreeFockConfig(100, 1e-10)) for _ in range(2)]
+    assert outs[0].iterations == outs[1].iterations and outs[0].electronic_energy == outs[1].electronic_energy
+    assert outs[0].orbital_energies == outs[1].orbital_energies
+
+
+def test_schwarz_factors_and_screening():
+    """Schwarz pass: the screened build (default tau = 1e-12) against the unscreened one and the oracle; the count of
+    surviving quartets is reported, never more than enumerated; tau = 0 restores every quartet."""
+    q, s, o = _sys("ethylene", "6-31G_st_st")
+    D = _rand_sym(s.n, 51)
+    G = s.fock_rhf(D)                                   # device pass has run: lists are screened
+    ws = s.work_stats()
+    assert ws.schwarz_tau == 1e-12 and ws.quartets_enumerated == s.n_quartets()
+    assert 0 <= ws.quartets_screened_out < ws.quartets_enumerated and ws.quartets + ws.quartets_screened_out <= ws.quartets_enumerated
+    G_ref = o.g_rhf(D, o.eri())
+    assert np.abs(G - G_ref).max() < TOL_INT * max(1.0, np.abs(G_ref).max())
+    s.set_schwarz(0.0)
+    ws0 = s.work_stats()
+    assert ws0.quartets_screened_out == 0 and ws0.quartets >= ws.quartets
+    G_all = s.fock_rhf(D)
+    assert np.abs(G_all - G).max() < TOL_INT * max(1.0, np.abs(G_ref).max())
+
+
+def test_benzene_ccpvdz_fock_against_the_oracle_on_a_shard():
+    """BASELINE config 5 at full size against the oracle: one shard of eight of the product's own work plan (~135 k shell
+    quartets over every class of benzene/cc-pVDZ) digested by the GPU and by the oracle's quartet-list contraction
+    (orc_g_rhf_quartets: the reference's (ij|kl) D_kl - 1/2 (ik|jl) D_kl sums, rhf.rs:58-62,152-167, restricted to the list)."""
+    q, s, o = _sys("benzene", "cc-pVDZ")
+    D = _rand_sym(s.n, 61)
+    G_full = s.fock_rhf(D)                              # (initialises the device: Schwarz factors, screened lists)
+    s.set_shard(3, 8)
+    abcd = s.plan_shard_quartets(3, 8)
+    assert 100_000 < len(abcd) < 160_000
+    G = s.fock_rhf(D)
+    G_ref = o.g_rhf_quartets(D, abcd)
+    scale = max(1.0, np.abs(G_full).max())
+    assert np.abs(G - G_ref).max() < TOL_INT * scale
+    # the screened-out quartets are below the parity bar as a whole: unscreened full build == screened full build
+    s.set_shard(0, 1)
+    s.set_schwarz(0.0)
+    assert np.abs(s.fock_rhf(D) - G_full).max() < TOL_INT * scale
+
+
+def test_benzene_ccpvdz_energy_matches_oracle():
+    """BASELINE config 5, converged energy.  Both sides stall at a density rms of ~3e-9 (near-degenerate orbitals, never-reset
+    DIIS), so the comparison is made at an epsilon both reach."""
+    q, s, o = _sys("benzene", "cc-pVDZ")
+    out = q.restricted_hartree_fock(s, q.HartreeFockConfig(100, 1e-8))
+    ref = o.rhf(100, 1e-8)
+    assert out is not None and ref["status"] == 0
+    assert abs(out.total_energy() - ref["total_energy"]) < TOL_E
+
+
+@pytest.mark.parametrize("mol,basis", [("water", "cc-pVDZ"), ("ethylene", "6-31G_st_st"), ("oxygen", "cc-pVDZ")])
+def test_startup_stages_match_oracle(mol, basis):
+    """X = S^-1/2 with the diagonal-of-the-product quirk (rhf.rs:124-131), H = T + V and the Hueckel density with the
+    1.75-scaled diagonal (rhf.rs:133-150) - stage by stage against the oracle's orc_core_guess."""
+    q, s, o = _sys(mol, basis)
+    S_ref, H_ref, X_ref, D_ref = o.core_guess()
+    st = q.ScfStepper(s)
+    assert np.abs(st.matrix("S") - S_ref).max() < 1e-11
+    assert np.abs(st.matrix("H") - H_ref).max() < 1e-10 * max(1.0, np.abs(H_ref).max())
+    assert np.abs(st.matrix("X") - X_ref).max() < 1e-9 * max(1.0, np.abs(X_ref).max())
+    D0 = st.density(0)
+    st.close()
+    if mol != "oxygen":          # homonuclear: degenerate Hueckel orbitals on the occupation boundary make D0 eigensolver-dependent (SURVEY a8)
+        assert np.abs(D0 - D_ref).max() < 1e-8 * max(1.0, np.abs(D_ref).max())
+    assert abs(np.sum(D0 * S_ref) - 2 * (s.n_electrons() // 2)) < 1e-9          # tr(D S) = N
+
+
+@pytest.mark.parametrize("mol,basis", [("water", "cc-pVDZ"), ("ethylene", "STO-3G")])
+def test_rhf_passes_match_oracle_one_by_one(mol, basis):
+    """Every pass of the loop body (rhf.rs:67-88) against the oracle's trace: energy and density rms of pass k agree, so guess,
+    DIIS window growth (passthrough below 4 samples, extrapolation from the 4th on, diis.rs:28-59), eigensolve and density
+    update are each pinned - not only the converged end point."""
+    q, s, o = _sys(mol, basis)
+    ref = o.rhf(100, 1e-10, trace=True)
+    st = q.ScfStepper(s)
+    for k in range(len(ref["trace_energy"])):
+        e, rms = st.iterate()
+        assert abs(e - ref["trace_energy"][k]) < 1e-9 * max(1.0, abs(e)), k
+        assert abs(rms - ref["trace_rms"][k]) < 1e-9 + 1e-5 * ref["trace_rms"][k], k
+    st.close()
 
 
 @pytest.mark.parametrize("mol,basis", [("water", "STO-3G"), ("water", "cc-pVTZ"), ("ethylene", "6-31G_st_st")])
