@@ -1,26 +1,33 @@
 #!/usr/bin/env python3
 """bench.py - SCF-iteration time and ERI shell-quartet throughput of the MI355X Hartree-Fock path.
 
-    python bench.py --gpus N --steps K --warmup W            (N > 1: launched by torch.distributed.run, one rank per GPU)
+    python bench.py --gpus N --steps K --warmup W
 
-A *step* is one pass of the SCF loop body (rhf.rs:67-88): direct-SCF Fock build over every unique shell quartet
-(ERI evaluation + J/K digestion), F = H + G, commutator, DIIS, F' = X^T F X, eigensolve, new density, energy, rms -
-through the step-wise C ABI (`qc_scf_iterate`), all operands resident in HBM before the timed region starts.
+N = 1 runs in this process.  N > 1: either launched by `python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...`
+(one rank per GPU; RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* from the environment), or started plainly - then this process,
+before it touches any GPU, starts that launcher itself as a child, relays rank 0's JSON line and exits with the child's code.
+
+A *step* is one pass of the SCF loop body (rhf.rs:67-88): direct-SCF Fock build over every unique shell quartet (ERI evaluation
++ J/K digestion), F = H + G, commutator, DIIS, F' = X^T F X, eigensolve, new density, energy, rms - through the step-wise C ABI
+(`qc_scf_iterate`), all operands resident in HBM before the timed region starts.  The timed passes are the passes of REAL SCF
+runs from the Hueckel guess: pass 0, 1, ... until the reference's stopping rule fires at epsilon = 1e-10, then the next run
+starts again at pass 0 (the runs' set-up - one-electron integrals, S^-1/2, guess - happens before the clock starts).
 
 Workloads (BASELINE.json configs; inputs are the fixture files under data/, nothing is random):
   N = 1  -> H2O / cc-pVTZ RHF (configs[2], the configuration the metric is quoted on; 58 bf, 32 131 unique quartets)
-  N > 1  -> C6H6 / cc-pVDZ RHF (configs[4]): the class-sorted quartet list is dealt across the ranks, every rank digests
-            its shard and the partial Fock matrices are summed by one RCCL all-reduce per build (strong scaling).
-            The N = 1 line carries the same workload's single-GPU numbers under "scaling_reference".
-`value` = unique shell quartets enumerated per step x K / elapsed (max over ranks), whole job.
-`ms_per_step` = SCF-iteration time.
+  N > 1  -> C6H6 / cc-pVDZ RHF (configs[4]): the class-sorted quartet list is dealt across the ranks, every rank digests its
+            shard and the partial Fock matrices are summed by one RCCL all-reduce per build (strong scaling).  The N = 1 line
+            carries the same workload's single-GPU numbers under "scaling_reference".
+`value` = unique shell quartets enumerated per step x K / elapsed (max over ranks), whole job.  `ms_per_step` = SCF-iteration time.
 
-Extra objects on the JSON line: "roofline" (dominant ERI class kernel, hipEvent-timed on the library's stream) and
-"cpu_baseline" (the oracle - a CPU restatement of the reference algorithm - timed on this host's cores).
+Extra objects on the JSON line: "roofline" (the Fock build: hipEvent-timed inside the timed passes on the library's stream,
+binding roof first) and "cpu_baseline" (the oracle - a CPU restatement of the reference algorithm - on this host's cores).
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -34,7 +41,9 @@ WORKLOADS = {
     "c6h6_631gss": ("benzene", "6-31G_st_st", "C6H6/6-31G** RHF"),
 }
 HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.3 TB/s achievable)
-FP64_VALU_PEAK_TF = 78.6    # MI355X FP64 vector peak (datasheet)
+FP64_PEAK_TF = 78.6         # MI355X FP64 vector peak = FP64 matrix (MFMA) peak (MI355X_MICROARCH.md)
+EPS = 1e-10                 # stopping rule of the timed SCF runs (the parity tests' epsilon)
+PROFILE_ROUND = "r02"
 
 
 def load(q, key):
@@ -43,92 +52,244 @@ def load(q, key):
     return q.MolecularSystem.load(os.path.join(ROOT, "data", "mol", mol + ".json"), b)
 
 
-def timed_steps(torch, dist, stepper, steps, warmup, world):
-    for _ in range(warmup):
-        stepper.iterate()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    tm0 = stepper.timings()
+class Host:
+    """Host-side rendezvous of the ranks (barrier, max of the elapsed times, unique-id broadcast) over gloo: the GPUs' only
+    collective is the library's RCCL all-reduce of the partial Fock matrix."""
+
+    def __init__(self, world, torch, dist):
+        self.world, self.torch, self.dist = world, torch, dist
+
+    def barrier(self):
+        if self.world > 1:
+            self.dist.barrier()
+
+    def max(self, x):
+        if self.world == 1:
+            return x
+        t = self.torch.tensor([x], dtype=self.torch.float64)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+        return float(t.item())
+
+
+def timed_scf_passes(q, sysh, host, sync, steps, warmup):
+    """`steps` timed passes of real SCF runs (see the module docstring); returns elapsed seconds and what the passes were."""
+    # warm-up: one whole SCF run (code upload, stream tuning, Schwarz pass), at least `warmup` passes; it also tells how many
+    # runs the timed region needs
+    st = q.ScfStepper(sysh)
+    kconv = None
+    for k in range(max(warmup, 200)):
+        _, rms = st.iterate()
+        if kconv is None and rms < EPS:
+            kconv = k
+        if kconv is not None and k + 1 >= warmup:
+            break
+    st.close()
+    per_run = (kconv + 1) if kconv is not None else steps
+    runs = [q.ScfStepper(sysh) for _ in range((steps + per_run - 1) // per_run)]          # set-up outside the timed region
+    host.barrier(); sync()
     t0 = time.perf_counter()
-    for _ in range(steps):
-        stepper.iterate()          # synchronises the library's stream at the end of every pass
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
-    tm1 = stepper.timings()
-    stepper.timed = {k: (tm1[k] - tm0[k]) / steps for k in ("fock", "linalg")}   # hipEvent ms per timed step
-    return dt
+    done, cur, passes, restarts = 0, 0, [], 0
+    k_in_run = 0
+    while done < steps:
+        _, rms = runs[cur].iterate()            # synchronises the library's stream at the end of every pass
+        passes.append(k_in_run)
+        done += 1; k_in_run += 1
+        if rms < EPS and done < steps and cur + 1 < len(runs):
+            cur += 1; k_in_run = 0; restarts += 1
+    sync(); host.barrier()
+    dt = host.max(time.perf_counter() - t0)
+    fock = sum(r.timings()["fock"] for r in runs) / steps          # hipEvent ms inside the passes
+    linalg = sum(r.timings()["linalg"] for r in runs) / steps
+    D = runs[0].density(0)
+    for r in runs:
+        r.close()
+    info = {"passes_timed": "SCF passes %s of %d run(s) from the Hueckel guess, stopping rule rms < %g (converges at pass %s)"
+            % ("0..%d" % max(passes), restarts + 1, EPS, kconv), "converges_at_pass": kconv}
+    return dt, fock, linalg, D, info
 
 
-def roofline(torch, sysh, D_host, reps):
-    """hipEvent timing (on the library's stream) of the kernels a Fock build launches.
+def roofline_of(ws, fock_ms, n_launches):
+    """Both roofs of the Fock build: t_roof = max(bytes_alg / BW_HBM, flops_alg / P_FP64); the binding one on top."""
+    t = fock_ms * 1e-3
+    gbs, tfs = ws.bytes_alg / t / 1e9, ws.flops_alg / t / 1e12
+    t_hbm, t_fp = ws.bytes_alg / (HBM_PEAK_GBS * 1e9), ws.flops_alg / (FP64_PEAK_TF * 1e12)
+    hbm = {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS}
+    fp = {"bound": "fp64", "achieved": tfs, "peak": FP64_PEAK_TF, "unit": "TFLOP/s", "frac": tfs / FP64_PEAK_TF}
+    top, other = (fp, hbm) if t_fp >= t_hbm else (hbm, fp)
+    out = dict(top)
+    out.update({
+        "traffic": None,
+        "other_roof": other,
+        "t_roof_us": {"fp64": t_fp * 1e6, "hbm": t_hbm * 1e6},
+        "kernel": "qc_fock_tier_kernel<LAB, TIER> + qc_fock_bm_kernel<LCD, HI>: %d concurrent launches = one Fock build" % n_launches,
+        "kernel_ms": fock_ms,
+        "kernel_ms_source": "hipEvents on the library's stream around the build of every timed pass (mean)",
+        "kernel_quartets": int(ws.quartets), "kernel_alg_bytes": float(ws.bytes_alg), "kernel_alg_flops": float(ws.flops_alg),
+        "note": "f64 gather-compute-scatter on the FP64 ridge; FP64 vector peak = FP64 MFMA peak = 78.6 TFLOP/s on this chip",
+    })
+    return out
 
-    A build = at most 18 launches: `qc_fock_tier_kernel<LAB, TIER>` (all class buckets of bra class LAB with LCD <= 3 /
-    LCD >= 4) and `qc_fock_bm_kernel<LCD, HI>` (bra-major kernels for ss / ps kets), concurrent on side streams.  The roofline entry is the tier kernel that takes the longest when
-    each is launched alone; `fock_build` gives the same ratios for the whole (overlapped) build, `classes` the per-bucket
-    view.  Algorithmic bytes/flops: SURVEY.md 8(d) per-quartet model summed over the quartets a launch processes."""
-    import qchem_rs_amd as q
+
+def unit_profile(torch, q, sysh, D_host, reps):
+    """Every launch of a build timed alone (hipEvents, serial) next to the concurrent build."""
     dD = torch.from_numpy(D_host).cuda()
     dG = torch.zeros_like(dD)
     torch.cuda.synchronize()
     tp = sysh.fock_profile_tiers(dD.data_ptr(), dG.data_ptr(), reps)
-    prof = sysh.fock_profile(dD.data_ptr(), dG.data_ptr(), max(1, reps // 2))
-    k = int(tp["unit_ms"].argmax())
-    ws = sysh.work_stats()
-    cname = lambda c: ("bm<%d, %d>" % ((int(c) >> 8) & 15, (int(c) >> 4) & 15)) if int(c) >> 12 else "<%d, %d, %d>" % (int(c) >> 8, (int(c) >> 4) & 15, int(c) & 15)
-    order = prof["class_ms"].argsort()[::-1][:10]
-    top = [{"class": cname(prof["class_id"][i]), "ms": float(prof["class_ms"][i]),
-            "quartets": int(prof["quartets"][i]), "GF": float(prof["flops"][i]) / 1e9} for i in order]
-    tiers = [{"kernel": q.hf.unit_name(u), "ms_alone": float(tp["unit_ms"][u]), "quartets": int(tp["quartets"][u]),
+    units = [{"kernel": q.hf.unit_name(u), "ms_alone": float(tp["unit_ms"][u]), "quartets": int(tp["quartets"][u]),
               "alg_MB": float(tp["bytes"][u]) / 1e6, "alg_GF": float(tp["flops"][u]) / 1e9,
-              "GBs_alone": float(tp["bytes"][u]) / (float(tp["unit_ms"][u]) * 1e-3) / 1e9,
-              "TFLOPs_alone": float(tp["flops"][u]) / (float(tp["unit_ms"][u]) * 1e-3) / 1e12} for u in range(len(tp["unit_ms"])) if tp["quartets"][u] > 0]
-    tot_ms = float(tp["total_ms"])
-    gbs = float(ws.bytes_alg) / (tot_ms * 1e-3) / 1e9
-    tfs = float(ws.flops_alg) / (tot_ms * 1e-3) / 1e12
-    # The dominant operation is the Fock build: one kernel template (qc_fock_tier_kernel<LAB, TIER>), launched once per
-    # non-empty (bra class, tier) - the launches overlap on side streams, so no single instantiation "owns" the time.
-    # The roofline entry therefore prices the whole build: algorithmic bytes/flops of all unique quartets / build time
-    # (hipEvents on the library's stream around the concurrent launches).  `tiers_alone` lists every instantiation timed
-    # by itself; profiles/ holds the rocprofv3 --stats summary with the same kernels.
-    return {
-        "bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS, "traffic": None,
-        "kernel": "qc_fock_tier_kernel<LAB, TIER> + qc_fock_bm_kernel<LCD, HI>: %d concurrent launches = one Fock build" % len(tiers), "kernel_ms": tot_ms,
-        "kernel_quartets": int(ws.quartets), "kernel_alg_bytes": float(ws.bytes_alg), "kernel_alg_flops": float(ws.flops_alg),
-        "note": "f64 gather-compute-scatter on the FP64 ridge (SURVEY 8d): both roofs are given; the binding one is fp64_valu",
-        "fp64_valu": {"achieved": tfs, "peak": FP64_VALU_PEAK_TF, "unit": "TFLOP/s", "frac": tfs / FP64_VALU_PEAK_TF},
-        "fock_build": {"ms": tot_ms, "sum_tier_kernels_serial_ms": float(tp["unit_ms"].sum()), "launches": len(tiers),
-                       "quartets_per_s": float(ws.quartets) / (tot_ms * 1e-3),
-                       "slowest_tier_alone": q.hf.unit_name(k),
-                       "tiers_alone": tiers, "top_classes_serial": top},
-    }
+              "TFLOPs_alone": float(tp["flops"][u]) / (float(tp["unit_ms"][u]) * 1e-3) / 1e12}
+             for u in range(len(tp["unit_ms"])) if tp["quartets"][u] > 0]
+    return {"build_ms_standalone": float(tp["total_ms"]), "sum_units_serial_ms": float(tp["unit_ms"].sum()), "units_alone": units}
 
 
-def cpu_baseline(mol, budget_s=20.0):
-    """The oracle (CPU restatement of the reference's conventional SCF) on this host, one thread like the reference."""
+def committed_counters(key):
+    """HBM traffic of the build and MFMA utilisation of the eigensolve from the rocprofv3 --pmc passes committed under profiles/
+    (tools/run_pmc.sh + tools/make_pmc_summary.py; separate passes, corrected as MI355X_MICROARCH.md prescribes)."""
+    f = os.path.join(ROOT, "profiles", "%s_pmc_%s.json" % (PROFILE_ROUND, key))
+    if not os.path.exists(f):
+        return None
+    try:
+        return json.load(open(f))
+    except Exception:
+        return None
+
+
+def accumulation_ab(q, mol, passes=12):
+    """Cost of the exact fixed-point accumulation next to plain f64 atomics: build time (hipEvents) over the same SCF passes."""
+    out = {}
+    for mode in ("fixed", "f64"):
+        s = q.System(mol); s.set_accumulation(mode)
+        st = q.ScfStepper(s)
+        for _ in range(4):
+            st.iterate()
+        t0 = st.timings()["fock"]
+        for _ in range(passes):
+            st.iterate()
+        out[mode] = (st.timings()["fock"] - t0) / passes
+        st.close(); s.close()
+    return {"default": "fixed point (2 x 64-bit integer atomics per contribution: exact, order-independent, bitwise reproducible)",
+            "fock_build_ms_fixed_point": out["fixed"], "fock_build_ms_f64_atomics": out["f64"],
+            "cost_of_determinism": out["fixed"] / out["f64"] - 1.0}
+
+
+def cpu_baseline(mol, budget_s=12.0):
+    """The oracle (CPU restatement of the reference's conventional SCF) on this host: all cores (OpenMP over shell quartets) and
+    one thread - the reference itself is single-threaded."""
     from oracle.oracle import Oracle
     o = Oracle(mol)
     nq = o.n_unique_quartets()
-    # probe ~1/50 of the quartets to size the sample
-    t0 = time.perf_counter(); _, c = o.eri_strided(0, 50); probe = time.perf_counter() - t0
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    cores = min(cores, 16)                 # a one-GPU lease of the pool owns 16 of the host's cores
+    t0 = time.perf_counter(); _, c = o.eri_strided_mt(0, 50, 1, store=False); probe = time.perf_counter() - t0
     est_full = probe * nq / max(c, 1)
-    stride = max(1, int(est_full / budget_s + 0.999))
-    t0 = time.perf_counter(); I, c = o.eri_strided(0, stride); dt = time.perf_counter() - t0
-    out = {"value": c / dt, "unit": "shell-quartets/s", "cores": 1, "kind": "port",
-           "sample": "every %d-th of the %d unique shell quartets of the same workload (%d quartets, %.2f s), "
-                     "oracle/qc_oracle.c orc_eri_full_strided" % (stride, nq, c, dt)}
-    if stride == 1 and o.n <= 64:
+    stride1 = max(1, int(est_full / budget_s + 0.999))
+    t0 = time.perf_counter(); _, c1 = o.eri_strided_mt(0, stride1, 1, store=False); dt1 = time.perf_counter() - t0
+    stride_mt = max(1, int(est_full / cores / budget_s * 1.5 + 0.999))
+    o.eri_strided_mt(0, max(stride_mt * 50, 50), cores, store=False)             # thread start-up outside the timing
+    t0 = time.perf_counter(); _, cm = o.eri_strided_mt(0, stride_mt, cores, store=False); dtm = time.perf_counter() - t0
+    out = {"value": cm / dtm, "unit": "shell-quartets/s", "cores": cores, "kind": "port",
+           "sample": "every %d-th of the %d unique shell quartets of the same workload (%d quartets, %.2f s) on %d threads, "
+                     "oracle/qc_oracle.c orc_eri_full_strided_mt" % (stride_mt, nq, cm, dtm, cores),
+           "one_thread": {"value": c1 / dt1, "cores": 1, "sample": "every %d-th quartet (%d quartets, %.2f s)" % (stride1, c1, dt1),
+                          "note": "the reference is single-threaded: this is its configuration"}}
+    if stride1 == 1 and o.n <= 64:
         # whole reference-style SCF on the CPU: n^4 contraction per iteration (rhf.rs:152-167) on the stored tensor
-        t0 = time.perf_counter(); r = o.rhf(100, 1e-10, eri=I); dt2 = time.perf_counter() - t0
+        I = o.eri()
+        t0 = time.perf_counter(); r = o.rhf(100, EPS, eri=I); dt2 = time.perf_counter() - t0
         out["scf_iter_ms"] = dt2 * 1e3 / (r["iterations"] + 1)
-        out["scf_note"] = "conventional SCF iteration (dense n^4 contraction + Jacobi eigensolve), tensor precomputed"
+        out["scf_note"] = "conventional SCF iteration (dense n^4 contraction + Jacobi eigensolve), one thread, tensor precomputed"
     return out
+
+
+def measure(torch, q, host, key, steps, warmup, world, rank, uid=None, with_units=True):
+    mol = load(q, key)
+    sysh = q.System(mol)
+    if world > 1:
+        sysh.comm_init(uid, rank, world)        # shard the quartet list, RCCL communicator for the partial-Fock all-reduce
+    nq_total = sysh.n_quartets()
+    dt, fock_ms, linalg_ms, D, info = timed_scf_passes(q, sysh, host, torch.cuda.synchronize, steps, warmup)
+    ws = sysh.work_stats()
+    res = {
+        "value": nq_total * steps / dt, "ms_per_step": dt * 1e3 / steps, "steps": steps,
+        "n_basis": sysh.n, "unique_quartets": int(nq_total),
+        "quartets_enumerated": int(ws.quartets_enumerated),
+        "quartets_after_schwarz": int(ws.quartets_enumerated - ws.quartets_screened_out), "schwarz_tau": ws.schwarz_tau,
+        "iter_breakdown_ms": {"fock_build": fock_ms, "diis_eig_density": linalg_ms},
+        "timed": info,
+    }
+    res["roofline"] = roofline_of(ws, fock_ms, 0)
+    if with_units:
+        up = unit_profile(torch, q, sysh, D, reps=3)      # collective when sharded: every rank calls it
+        res["roofline"]["kernel"] = "qc_fock_tier_kernel<LAB, TIER> + qc_fock_bm_kernel<LCD, HI>: %d concurrent launches = one Fock build" % len(up["units_alone"])
+        res["roofline"]["fock_build"] = up
+    else:
+        res["roofline"]["kernel"] = "qc_fock_tier_kernel<LAB, TIER> + qc_fock_bm_kernel<LCD, HI>: the concurrent launches of one Fock build"
+    res["roofline"]["shard"] = "rank 0's shard of %d" % world if world > 1 else "all quartets"
+    pmc = committed_counters(key)
+    if pmc and world == 1:
+        res["roofline"]["traffic"] = pmc.get("fock_build_hbm_bytes")
+        res["roofline"]["traffic_detail"] = pmc.get("fock_build")
+        if "eigensolve" in pmc:
+            res["eigensolve_counters"] = pmc["eigensolve"]
+    sysh.close()
+    return res, mol
+
+
+def self_launch(args):
+    """`python bench.py --gpus N` started plainly: become the launcher's parent (no GPU call has happened in this process)."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=%d" % args.gpus,
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    p = subprocess.run(cmd, stdout=subprocess.PIPE, text=True, env=env)
+    line = None
+    for ln in p.stdout.splitlines():
+        try:
+            d = json.loads(ln)
+            if isinstance(d, dict) and "metric" in d:
+                line = ln
+                continue
+        except ValueError:
+            pass
+        print(ln, file=sys.stderr)
+    if line is not None:
+        print(line, flush=True)
+    sys.exit(p.returncode if p.returncode else (0 if line is not None else 1))
+
+
+def dry_run(args, world, rank):
+    """Harness test without a GPU (tests/test_bench_launch.py): same launch, rendezvous, timing and JSON path; a step is the
+    product's host-side shard planner instead of the kernels.  Not a measurement."""
+    import torch
+    import torch.distributed as dist
+    import qchem_rs_amd as q
+    if world > 1:
+        dist.init_process_group("gloo")
+    host = Host(world, torch, dist)
+    sysh = q.System(load(q, "h2o_sto3g"))
+    for _ in range(args.warmup):
+        sysh.plan_shard(rank, world)
+    host.barrier()
+    t0 = time.perf_counter()
+    mine = 0
+    for _ in range(args.steps):
+        mine = sysh.plan_shard(rank, world)[0]
+    host.barrier()
+    dt = host.max(time.perf_counter() - t0)
+    tot = torch.tensor([mine], dtype=torch.int64)
+    if world > 1:
+        dist.all_reduce(tot)
+    if rank == 0:
+        print(json.dumps({"metric": "DRY RUN (no GPU): bench.py launch/rendezvous harness test, not a measurement", "value": 0.0,
+                          "unit": "shell-quartets/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                          "ms_per_step": dt * 1e3 / args.steps, "dry_run": True, "quartets_over_all_ranks": int(tot.item()),
+                          "quartets_expected": int(sysh.n_quartets())}), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
 
 
 def main():
@@ -139,86 +300,83 @@ def main():
     ap.add_argument("--workload", default="auto", choices=["auto"] + sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-scaling-reference", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="only the headline measurement (profiling runs)")
+    ap.add_argument("--dry-run", action="store_true", help="harness test without a GPU (not a measurement)")
     args = ap.parse_args()
-
-    import numpy as np
-    import torch
-    import torch.distributed as dist
-    import qchem_rs_amd as q
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus > 1 and world != args.gpus:
-        raise SystemExit("bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d" % (args.gpus, args.gpus))
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        self_launch(args)                                  # never returns
+    if args.gpus != world:
+        raise SystemExit("bench.py --gpus %d inside a launcher with WORLD_SIZE=%d" % (args.gpus, world))
+    if args.dry_run:
+        return dry_run(args, world, rank)
+
+    import torch
+    import torch.distributed as dist
+    import qchem_rs_amd as q
+
     if not torch.cuda.is_available() or not q.device_ready():
         raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
     torch.cuda.set_device(local_rank)
+    uid = None
     if world > 1:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        dist.init_process_group("gloo")                    # host-side rendezvous only
+        box = [q.comm_unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(box, src=0)
+        uid = box[0]
+    host = Host(world, torch, dist)
 
     key = args.workload if args.workload != "auto" else ("h2o_ccpvtz" if world == 1 else "c6h6_ccpvdz")
-    mol = load(q, key)
-    sysh = q.System(mol)
-    nq_total = sysh.n_quartets()
-    if world > 1:
-        uid = [q.comm_unique_id() if rank == 0 else None]
-        dist.broadcast_object_list(uid, src=0)
-        sysh.comm_init(uid[0], rank, world)        # shard the quartet list, RCCL communicator for the partial-Fock all-reduce
-
-    stepper = q.ScfStepper(sysh)
-    dt = timed_steps(torch, dist, stepper, args.steps, args.warmup, world)
-    D = stepper.density(0)
-    tm = stepper.timed
+    res, mol = measure(torch, q, host, key, args.steps, args.warmup, world, rank, uid, with_units=not args.no_extras)
     line = {
         "metric": "ERI shell-quartets/sec through one SCF iteration (ms_per_step = SCF iter time), RHF",
-        "value": nq_total * args.steps / dt, "unit": "shell-quartets/s", "n_gpus": world, "steps": args.steps,
-        "warmup": args.warmup, "ms_per_step": dt * 1e3 / args.steps, "higher_is_better": True,
+        "value": res["value"], "unit": "shell-quartets/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": res["ms_per_step"], "higher_is_better": True,
         "scaling": "strong" if world > 1 else "weak", "vs_baseline": None, "dtype": "f64",
-        "data": "fixture molecule + basis files under data/ (no randomness); densities are the SCF's own iterates",
-        "config": {"workload": WORKLOADS[key][2] + " direct-SCF iteration", "n_basis": sysh.n, "unique_quartets": int(nq_total),
+        "data": "fixture molecule + basis files under data/ (no randomness); densities are the SCF's own iterates from the Hueckel guess",
+        "config": {"workload": WORKLOADS[key][2] + " direct-SCF iteration", "n_basis": res["n_basis"], "unique_quartets": res["unique_quartets"],
+                   "quartets_after_schwarz": res["quartets_after_schwarz"], "schwarz_tau": res["schwarz_tau"],
+                   "passes": res["timed"]["passes_timed"],
                    "parallelism": "1 GPU" if world == 1 else "quartet shards over %d GPUs + 1 RCCL all-reduce of G per build" % world},
-        "iter_breakdown_ms": {"fock_build": tm["fock"], "diis_eig_density": tm["linalg"]},
+        "iter_breakdown_ms": res["iter_breakdown_ms"],
+        "roofline": res["roofline"],
     }
-    rf = roofline(torch, sysh, D, reps=5)      # collective when sharded: every rank calls it
-    stepper.close()
-    if rank == 0:
-        line["roofline"] = rf
-        pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-        if os.path.exists(pmc) and key == "h2o_ccpvtz":   # HBM bytes per build from committed rocprofv3 --pmc passes (same workload)
-            try:
-                recs = [v for k2, v in json.load(open(pmc)).items() if k2.startswith("qc_fock_")]
-                line["roofline"]["traffic"] = {
-                    "hbm_bytes": sum(r["hbm_bytes"] for r in recs), "fetch_bytes_x2": sum(r["fetch_bytes_x2"] for r in recs),
-                    "write_bytes": sum(r["write_bytes"] or 0 for r in recs), "atomic_requests": sum(r["atomic_requests"] or 0 for r in recs),
-                    "source": "profiles/pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, summed over the build's launches)"}
-            except Exception:
-                pass
-    if world == 1 and rank == 0:
+    if "eigensolve_counters" in res:
+        line["eigensolve_counters"] = res["eigensolve_counters"]
+    if world > 1 and rank == 0:
+        line["rccl"] = q.rccl_info()
+    if world == 1 and not args.no_extras:
+        line["accumulation"] = accumulation_ab(q, mol)
         if not args.no_scaling_reference and key == "h2o_ccpvtz":
-            m2 = load(q, "c6h6_ccpvdz")
-            s2 = q.System(m2)
-            st2 = q.ScfStepper(s2)
-            k2 = max(3, min(args.steps, 5))
-            dt2 = timed_steps(torch, dist, st2, k2, 1, 1)
-            tm2 = st2.timed
-            st2.close()
+            k2 = max(8, min(args.steps, 24))
+            r2, m2 = measure(torch, q, host, "c6h6_ccpvdz", k2, 2, 1, 0, None, with_units=True)
             line["scaling_reference"] = {"workload": WORKLOADS["c6h6_ccpvdz"][2] + " direct-SCF iteration", "n_gpus": 1,
-                                         "value": s2.n_quartets() * k2 / dt2, "ms_per_step": dt2 * 1e3 / k2, "steps": k2,
-                                         "fock_build_ms": tm2["fock"], "unique_quartets": int(s2.n_quartets())}
-            if not args.no_cpu_baseline:      # the oracle on a bounded sample of the same 1.1 M quartets (~10 s of one host core)
-                line["scaling_reference"]["cpu_baseline"] = cpu_baseline(m2, budget_s=10.0)
-            s2.close()
+                                         "value": r2["value"], "ms_per_step": r2["ms_per_step"], "steps": k2,
+                                         "passes": r2["timed"]["passes_timed"],
+                                         "iter_breakdown_ms": r2["iter_breakdown_ms"], "unique_quartets": r2["unique_quartets"],
+                                         "quartets_after_schwarz": r2["quartets_after_schwarz"], "roofline": r2["roofline"],
+                                         "accumulation": accumulation_ab(q, m2, passes=8)}
+            if "eigensolve_counters" in r2:
+                line["scaling_reference"]["eigensolve_counters"] = r2["eigensolve_counters"]
+            if not args.no_cpu_baseline:      # the oracle on a bounded sample of the same 1.1 M quartets
+                line["scaling_reference"]["cpu_baseline"] = cpu_baseline(m2, budget_s=6.0)
         if key in ("h2o_ccpvtz", "h2o_sto3g", "c6h6_ccpvdz"):
             # the reference's own (conventional) algorithm on the same GPU: tensor resident in HBM, one streaming GEMV per pass
             s3 = q.System(mol); s3.set_fock_mode("stored")
             st3 = q.ScfStepper(s3)
-            dt3 = timed_steps(torch, dist, st3, args.steps, args.warmup, 1)
-            tm3 = st3.timed; n3 = s3.n
+            for _ in range(3):
+                st3.iterate()
+            t0 = st3.timings(); w0 = time.perf_counter()
+            for _ in range(args.steps):
+                st3.iterate()
+            dt3 = time.perf_counter() - w0
+            t1 = st3.timings(); n3 = s3.n
             gemv_bytes = 8.0 * (n3 * (n3 + 1) // 2) * n3 * n3
-            fock_ms3 = tm3["fock"]
+            fock_ms3 = (t1["fock"] - t0["fock"]) / args.steps
             line["stored_mode"] = {"ms_per_step": dt3 * 1e3 / args.steps, "tensor_build_ms": st3.tensor_ms(),
-                                   "tensor_build_quartets_per_s": nq_total / (st3.tensor_ms() * 1e-3),
                                    "gemv_ms": fock_ms3, "gemv_alg_bytes": gemv_bytes,
                                    "gemv_GBs": gemv_bytes / (fock_ms3 * 1e-3) / 1e9, "gemv_frac_of_8TBs": gemv_bytes / (fock_ms3 * 1e-3) / 1e9 / HBM_PEAK_GBS,
                                    "note": "rhf.rs:45,58-62,152-167 as written: molint::eri once, electron_terms, dense n^4 contraction per pass; "
@@ -228,7 +386,6 @@ def main():
             line["cpu_baseline"] = cpu_baseline(mol)
     if rank == 0:
         print(json.dumps(line), flush=True)
-    sysh.close()                                    # releases the RCCL communicator before torch tears its own down
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

@@ -165,6 +165,10 @@ int qc_set_schwarz(qc_system *sys, double tau);
 /* ---- multi-GPU (not in the reference, which is single-threaded; BASELINE.json north_star).  One process per GPU.
  * Rank 0 calls qc_comm_unique_id, the host distributes the 128 bytes, every rank calls qc_comm_init, which creates
  * an RCCL communicator on the current device and restricts this handle's Fock builds to shard `rank` of `nranks`. */
+/* RCCL is bound at run time (dlopen): $QC_RCCL_LIB, else the librccl.so.1 already mapped into the process (torch's bundled
+ * copy in a torch process - one RCCL per process), else librccl.so.1 from the loader's search path (/opt/rocm/lib).
+ * qc_rccl_info writes "<path> version <code>" of the copy in use. */
+int qc_rccl_info(char *buf, size_t len);
 int qc_comm_unique_id(uint8_t id[128]);
 int qc_comm_init(qc_system *sys, const uint8_t id[128], int rank, int nranks);
 /* Shard without a communicator (tests / external reduction): Fock builds then return the PARTIAL matrix. */

@@ -42,6 +42,7 @@ def lib():
         for f in ("orc_overlap", "orc_kinetic", "orc_nuclear", "orc_eri_full"):
             getattr(L, f).argtypes = [C.c_void_p, _dp]; getattr(L, f).restype = None
         L.orc_eri_full_strided.argtypes = [C.c_void_p, _dp, C.c_long, C.c_long]; L.orc_eri_full_strided.restype = C.c_long
+        L.orc_eri_full_strided_mt.argtypes = [C.c_void_p, C.c_void_p, C.c_long, C.c_long, C.c_int]; L.orc_eri_full_strided_mt.restype = C.c_long
         L.orc_n_unique_quartets.argtypes = [C.c_void_p]; L.orc_n_unique_quartets.restype = C.c_long
         L.orc_eri_shell_quartet.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, _dp]
         L.orc_nuclear_repulsion.argtypes = [C.c_void_p]; L.orc_nuclear_repulsion.restype = C.c_double
@@ -96,6 +97,12 @@ class Oracle:
 
     def eri_strided(self, first, stride):
         I = np.zeros((self.n,) * 4); c = lib().orc_eri_full_strided(self.h, I.reshape(-1), first, stride); return I, c
+
+    def eri_strided_mt(self, first, stride, nthreads, store=True):
+        """Every stride-th unique shell quartet on `nthreads` host cores (OpenMP); store=False drops the integrals (timing only)."""
+        I = np.zeros((self.n,) * 4) if store else None
+        c = lib().orc_eri_full_strided_mt(self.h, None if I is None else I.ctypes.data_as(C.c_void_p), first, stride, nthreads)
+        return I, c
 
     def n_unique_quartets(self): return lib().orc_n_unique_quartets(self.h)
 

@@ -460,6 +460,57 @@ long orc_eri_full_strided(const Basis *B, double *out, long first, long stride) 
 }
 void orc_eri_full(const Basis *B, double *out) { orc_eri_full_strided(B, out, 0, 1); }
 
+/* The same on `nthreads` host cores (OpenMP over the outer shell index, dynamic schedule): the "all host cores" CPU
+ * baseline of BASELINE.md / SURVEY 8d.  The reference itself is single-threaded; unique quartets write disjoint tensor
+ * elements, so the threads share nothing but the output array.  out == NULL: integrals are evaluated and dropped (timing
+ * of samples whose n^4 tensor would not be worth allocating). */
+long orc_eri_full_strided_mt(const Basis *B, double *out, long first, long stride, int nthreads) {
+    int n = B->nbasis;
+    size_t n2 = (size_t)n * n, n3 = n2 * n;
+    long count = 0;
+    int ns = B->nshells, npair = ns * (ns + 1) / 2;
+    long *base = (long *)malloc(sizeof(long) * (npair + 1));    /* index of the first quartet of bra pair (sa, sb) */
+    int *psa = (int *)malloc(sizeof(int) * npair), *psb = (int *)malloc(sizeof(int) * npair);
+    base[0] = 0;
+    for (int sa = 0, p = 0; sa < ns; sa++)
+        for (int sb = 0; sb <= sa; sb++, p++) {
+            long c = 0;
+            for (int sc = 0; sc <= sa; sc++) c += (sc == sa ? sb : sc) + 1;
+            psa[p] = sa; psb[p] = sb; base[p + 1] = base[p] + c;
+        }
+    { double tmp[1]; orc_eri_shell_quartet(B, 0, 0, 0, 0, tmp); }  /* index tables are built before the threads start */
+#pragma omp parallel num_threads(nthreads) reduction(+ : count)
+    {
+        double *buf = (double *)malloc(sizeof(double) * 15 * 15 * 15 * 15);
+#pragma omp for schedule(dynamic, 1)
+        for (int px = 0; px < npair; px++) {
+            int p = npair - 1 - px;                             /* the bra pairs with the most kets first */
+            int sa = psa[p], sb = psb[p];
+            long idx = base[p];
+            for (int sc = 0; sc <= sa; sc++)
+                for (int sd = 0; sd <= (sc == sa ? sb : sc); sd++, idx++) {
+                    if (idx < first || (idx - first) % stride) continue;
+                    count++;
+                    orc_eri_shell_quartet(B, sa, sb, sc, sd, buf);
+                    if (!out) continue;
+                    const Shell *SA = &B->sh[sa], *SB = &B->sh[sb], *SC = &B->sh[sc], *SD = &B->sh[sd];
+                    for (int fa = 0; fa < SA->nfunc; fa++) for (int fb = 0; fb < SB->nfunc; fb++)
+                    for (int fc = 0; fc < SC->nfunc; fc++) for (int fd = 0; fd < SD->nfunc; fd++) {
+                        double v = buf[((fa * SB->nfunc + fb) * SC->nfunc + fc) * SD->nfunc + fd];
+                        size_t i = SA->off + fa, j = SB->off + fb, k = SC->off + fc, l = SD->off + fd;
+                        out[i * n3 + j * n2 + k * n + l] = v; out[j * n3 + i * n2 + k * n + l] = v;
+                        out[i * n3 + j * n2 + l * n + k] = v; out[j * n3 + i * n2 + l * n + k] = v;
+                        out[k * n3 + l * n2 + i * n + j] = v; out[l * n3 + k * n2 + i * n + j] = v;
+                        out[k * n3 + l * n2 + j * n + i] = v; out[l * n3 + k * n2 + j * n + i] = v;
+                    }
+                }
+        }
+        free(buf);
+    }
+    free(base); free(psa); free(psb);
+    return count;
+}
+
 /* ------------------------------------------------------------------ dense helpers */
 static void matmul(int n, const double *A, const double *B, double *C) {     /* C = A B */
     for (int i = 0; i < n; i++) {

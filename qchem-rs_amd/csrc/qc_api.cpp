@@ -4,6 +4,7 @@
 // unrestricted_hartree_fock (uhf.rs:36-167) - guess, DIIS windows, update order, energy expression, diagonal-only
 // convergence test - with every matrix resident in HBM and every step a HIP kernel, the DIIS (<= 9 x 9) QR solve
 // included; the host takes the convergence decision from two scalars it reads back once per pass.
+#include <dlfcn.h>
 #include <rccl/rccl.h>
 
 #include <chrono>
@@ -15,6 +16,44 @@
 #include <new>
 
 #include "qc_internal.h"
+
+// ---- RCCL, bound at run time.  A process that has imported torch already maps torch's bundled librccl.so.1; linking a
+// second copy by path would leave it to the dynamic loader which of the two same-soname libraries the symbols resolve to.
+// The library is therefore not linked: the first qc_comm_* call takes (1) $QC_RCCL_LIB if set, else (2) the librccl.so.1
+// already mapped into the process (one RCCL per process: torch's, when torch is there), else (3) librccl.so.1 from the
+// loader's search path (rpath /opt/rocm/lib).  qc_rccl_info() reports which one it was.
+struct QcRccl {
+    void *handle = nullptr;
+    std::string path;
+    ncclResult_t (*GetUniqueId)(ncclUniqueId *) = nullptr;
+    ncclResult_t (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*AllReduce)(const void *, void *, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*GetVersion)(int *) = nullptr;
+    bool ok = false;
+};
+static QcRccl &qc_rccl() {
+    static QcRccl R = [] {
+        QcRccl r;
+        const char *env = getenv("QC_RCCL_LIB");
+        if (env && *env) { r.handle = dlopen(env, RTLD_NOW | RTLD_GLOBAL); r.path = env; }
+        if (!r.handle) { r.handle = dlopen("librccl.so.1", RTLD_NOW | RTLD_NOLOAD); r.path = "librccl.so.1 (already mapped in this process)"; }
+        if (!r.handle) { r.handle = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL); r.path = "librccl.so.1 (loader search path)"; }
+        if (!r.handle) { fprintf(stderr, "qchem_hip: cannot load librccl.so.1: %s\n", dlerror()); return r; }
+        r.GetUniqueId = reinterpret_cast<decltype(r.GetUniqueId)>(dlsym(r.handle, "ncclGetUniqueId"));
+        r.CommInitRank = reinterpret_cast<decltype(r.CommInitRank)>(dlsym(r.handle, "ncclCommInitRank"));
+        r.CommDestroy = reinterpret_cast<decltype(r.CommDestroy)>(dlsym(r.handle, "ncclCommDestroy"));
+        r.AllReduce = reinterpret_cast<decltype(r.AllReduce)>(dlsym(r.handle, "ncclAllReduce"));
+        r.GetVersion = reinterpret_cast<decltype(r.GetVersion)>(dlsym(r.handle, "ncclGetVersion"));
+        r.ok = r.GetUniqueId && r.CommInitRank && r.CommDestroy && r.AllReduce;
+        if (r.ok) {
+            Dl_info info;
+            if (dladdr(reinterpret_cast<void *>(r.AllReduce), &info) && info.dli_fname) r.path = info.dli_fname;
+        }
+        return r;
+    }();
+    return R;
+}
 
 namespace {
 
@@ -79,6 +118,8 @@ struct DeviceDiis {
     }
 };
 
+constexpr int QC_SYNC_WORDS = 12;          // 4 doubles + 16 ints of pass scalars, as 64-bit words
+
 struct ScfWork {
     int n;
     DevBuf H, S, X, t1, t2, t3, t4, Fp, Cp, C, w, ework, Fd, scal, small, CpPrev[2], CpNew[2], Fps[2];
@@ -86,10 +127,12 @@ struct ScfWork {
     int npass[2] = {3, 3};                 // refinement passes enqueued per eigensolve (follows what the last one needed)
     int mode[2] = {2, 2};                  // eigensolve of the next pass: 0 refinement, 1 two Jacobi sweeps + refinement, 2 Jacobi
     int *ctl = nullptr;                    // device control words: [4 s + 0..3] eigen-refinement of spin s, [8] DIIS failure
-    double *h_scal = nullptr;              // pinned read-back: 4 doubles (energy, rms^2 per spin) + 16 ints
+    double *h_scal = nullptr;              // pinned read-back: 4 doubles (energy, rms^2 per spin) + 16 ints, then (multi-rank) their complements
+    unsigned long long *d_sync = nullptr;  // multi-rank runs: the same 12 words + their bitwise complements, all-reduced (max) across the ranks
     ~ScfWork() {
         if (ctl) (void)hipFree(ctl);
         if (h_scal) (void)hipHostFree(h_scal);
+        if (d_sync) (void)hipFree(d_sync);
     }
     int init(int n_) {
         n = n_;
@@ -98,14 +141,15 @@ struct ScfWork {
         for (auto b : all) if (b->alloc(nn) != QC_OK) return QC_ERR_HIP;
         if (w.alloc(n) != QC_OK || scal.alloc(16) != QC_OK || small.alloc(2 * n + 16) != QC_OK) return QC_ERR_HIP;
         if (hipMalloc(&ctl, 16 * sizeof(int)) != hipSuccess || hipMemset(ctl, 0, 16 * sizeof(int)) != hipSuccess) return QC_ERR_HIP;
-        if (hipHostMalloc(&h_scal, 4 * sizeof(double) + 16 * sizeof(int)) != hipSuccess) return QC_ERR_HIP;
+        if (hipHostMalloc(&h_scal, 2 * QC_SYNC_WORDS * sizeof(double)) != hipSuccess) return QC_ERR_HIP;
+        if (hipMalloc(&d_sync, 2 * QC_SYNC_WORDS * sizeof(unsigned long long)) != hipSuccess) return QC_ERR_HIP;
         return QC_OK;
     }
 };
 
 // sorted_eigs on device (utils.rs:20-36): Fp -> (Cp, w)
 int device_sorted_eigs(qc_system *S, ScfWork &W, double *dA, double *dV, double *dw) {
-    return qc_eig_device(S->stream, W.n, dA, dV, dw, W.ework.p);
+    return qc_eig_device(S->stream, W.n, dA, dV, dw, W.ework.p, 40, 1e-9, W.ctl + 9);     // ctl[9]: Jacobi sweeps ran out
 }
 
 // start-up shared by both drivers: H = T + V, X = S^-1/2 (rhf.rs:124-131), Hückel matrix (rhf.rs:141-143)
@@ -179,7 +223,7 @@ int roothaan_enqueue(qc_system *S, ScfWork &W, DeviceDiis &diis, const double *d
                                      W.small.p, W.ctl + 4 * spin, 3);
     } else if (W.have_prev[spin])           // first passes, density far from converged: warm-started Jacobi to convergence
         // (the density still moves by O(1) per element here: a sweep that met couplings below 1e-5 leaves 1e-10, far below that)
-        rc = qc_eig_device_warm(st, n, W.Fps[spin].p, W.CpPrev[spin].p, W.CpNew[spin].p, dw_out, W.ework.p, W.t1.p, W.t2.p, 40, 1e-5);
+        rc = qc_eig_device_warm(st, n, W.Fps[spin].p, W.CpPrev[spin].p, W.CpNew[spin].p, dw_out, W.ework.p, W.t1.p, W.t2.p, 40, 1e-5, W.ctl + 9);
     else rc = device_sorted_eigs(S, W, W.Fps[spin].p, W.CpNew[spin].p, dw_out);          // sorted_eigs (rhf.rs:75), cold
     if (rc != QC_OK) return rc;
     qc_gemm(st, n, n, n, 1.0, W.X.p, n, false, W.CpNew[spin].p, n, false, 0.0, dC, n);   // C = X C'
@@ -190,7 +234,7 @@ int roothaan_enqueue(qc_system *S, ScfWork &W, DeviceDiis &diis, const double *d
 int roothaan_redo_eig(qc_system *S, ScfWork &W, double *dw_out, double *dC, int spin) {
     const int n = S->nbasis;
     hipStream_t st = S->stream;
-    int rc = qc_eig_device_refine(st, n, W.Fps[spin].p, W.CpPrev[spin].p, W.CpNew[spin].p, dw_out, W.ework.p, W.t1.p, W.t2.p, W.t3.p, W.t4.p, W.small.p);
+    int rc = qc_eig_device_refine(st, n, W.Fps[spin].p, W.CpPrev[spin].p, W.CpNew[spin].p, dw_out, W.ework.p, W.t1.p, W.t2.p, W.t3.p, W.t4.p, W.small.p, W.ctl + 9);
     if (rc != QC_OK) return rc;
     qc_gemm(st, n, n, n, 1.0, W.X.p, n, false, W.CpNew[spin].p, n, false, 0.0, dC, n);
     return QC_OK;
@@ -229,11 +273,17 @@ int qc_system_create(int natoms, const int32_t *Z, const double *xyz, int nshell
     return QC_OK;
 }
 
-void qc_system_destroy(qc_system *S) {
-    if (!S) return;
-    if (S->comm) { ncclCommDestroy((ncclComm_t)S->comm); S->comm = nullptr; }
+static void system_free(qc_system *S) {
+    if (S->comm) { qc_rccl().CommDestroy((ncclComm_t)S->comm); S->comm = nullptr; }
     qc_device_free(S);
     delete S;
+}
+
+// A handle with live qc_scf_state objects is kept until the last of them ends (their buffers and destructors use its stream).
+void qc_system_destroy(qc_system *S) {
+    if (!S) return;
+    if (S->live_states > 0) { S->zombie = true; return; }
+    system_free(S);
 }
 
 int qc_nbasis(const qc_system *S) { return S ? S->nbasis : QC_ERR_INVALID; }
@@ -343,7 +393,7 @@ int qc_fock_build_device(qc_system *S, const double *dDa, const double *dDb, dou
         // partial Fock matrices -> full, one all-reduce per build ([Ga|Gb] concatenated for UHF; hi and lo planes back to
         // back).  Fixed-point partials are summed as integers: the result is bit-identical on every rank and to the
         // single-GPU build, whatever the ring order.
-        if (ncclAllReduce(S->d_Gred, S->d_Gred, (fx ? 2 : 1) * nspin * nn, fx ? ncclInt64 : ncclDouble, ncclSum, (ncclComm_t)S->comm, st) != ncclSuccess) return QC_ERR_RCCL;
+        if (qc_rccl().AllReduce(S->d_Gred, S->d_Gred, (fx ? 2 : 1) * nspin * nn, fx ? ncclInt64 : ncclDouble, ncclSum, (ncclComm_t)S->comm, st) != ncclSuccess) return QC_ERR_RCCL;
     }
     qc_symmetrize_add(st, n, S->d_Gred, nspin * nn, dGa, dH, dH ? dFa : nullptr, fxs);
     if (two) qc_symmetrize_add(st, n, S->d_Gred + nn, nspin * nn, dGb, dH, dH ? dFb : nullptr, fxs);
@@ -403,12 +453,15 @@ int qc_sym_eig(qc_system *S, int n, const double *A, double *V, double *w) {
     DevBuf dA, dV, dw, dwork;
     if (dA.alloc(nn) != QC_OK || dV.alloc(nn) != QC_OK || dw.alloc(n) != QC_OK || dwork.alloc(nn) != QC_OK) return QC_ERR_HIP;
     QC_HIP_CHECK(hipMemcpyAsync(dA.p, A, nn * sizeof(double), hipMemcpyHostToDevice, S->stream));
-    rc = qc_eig_device(S->stream, n, dA.p, dV.p, dw.p, dwork.p);
+    int flag = 0;
+    QC_HIP_CHECK(hipMemsetAsync(S->d_flag, 0, sizeof(int), S->stream));
+    rc = qc_eig_device(S->stream, n, dA.p, dV.p, dw.p, dwork.p, 40, 1e-9, S->d_flag);
     if (rc != QC_OK) return rc;
     QC_HIP_CHECK(hipMemcpyAsync(V, dV.p, nn * sizeof(double), hipMemcpyDeviceToHost, S->stream));
     QC_HIP_CHECK(hipMemcpyAsync(w, dw.p, n * sizeof(double), hipMemcpyDeviceToHost, S->stream));
+    QC_HIP_CHECK(hipMemcpyAsync(&flag, S->d_flag, sizeof(int), hipMemcpyDeviceToHost, S->stream));
     QC_HIP_CHECK(hipStreamSynchronize(S->stream));
-    return QC_OK;
+    return flag ? QC_EIG_NOT_CONVERGED : QC_OK;
 }
 
 // ---- step-wise drivers: the host (the Rust `core` crate in the north-star design) owns the convergence loop and
@@ -436,6 +489,13 @@ struct qc_scf_state {
         if (ev2) (void)hipEventDestroy(ev2);
     }
 };
+static void system_free(qc_system *S);
+static void scf_state_delete(qc_scf_state *st) {
+    if (!st) return;
+    qc_system *S = st->S;
+    delete st;
+    if (S && --S->live_states == 0 && S->zombie) system_free(S);
+}
 
 static int scf_begin(qc_system *S, bool uhf, int n_alpha, int n_beta, qc_scf_state **out) {
     if (!S || !out) return QC_ERR_INVALID;
@@ -446,8 +506,10 @@ static int scf_begin(qc_system *S, bool uhf, int n_alpha, int n_beta, qc_scf_sta
     const size_t nn = (size_t)n * n;
     qc_scf_state *st = new (std::nothrow) qc_scf_state();
     if (!st) return QC_ERR_INVALID;
-    std::unique_ptr<qc_scf_state> guard(st);
+    struct Del { void operator()(qc_scf_state *p) const { scf_state_delete(p); } };
+    std::unique_ptr<qc_scf_state, Del> guard(st);
     st->S = S; st->uhf = uhf;
+    ++S->live_states;
     st->nocc[0] = st->nocc[1] = S->nelec / 2;                             // rhf.rs:176 / uhf.rs:43-45
     if (uhf && (n_alpha > 0 || n_beta > 0)) { st->nocc[0] = n_alpha; st->nocc[1] = n_beta; }
     if (st->nocc[0] < 0 || st->nocc[1] < 0 || st->nocc[0] > n || st->nocc[1] > n) return QC_ERR_INVALID;
@@ -488,7 +550,10 @@ static int scf_begin(qc_system *S, bool uhf, int n_alpha, int n_beta, qc_scf_sta
         if ((rc = st->diis[s]->init()) != QC_OK) return rc;
     }
     QC_HIP_CHECK(hipEventCreate(&st->ev0)); QC_HIP_CHECK(hipEventCreate(&st->ev1)); QC_HIP_CHECK(hipEventCreate(&st->ev2));
+    int eig_flag = 0;                                                     // the eigensolves of X and of the Hueckel guess
+    QC_HIP_CHECK(hipMemcpyAsync(&eig_flag, st->W.ctl + 9, sizeof(int), hipMemcpyDeviceToHost, S->stream));
     QC_HIP_CHECK(hipStreamSynchronize(S->stream));
+    if (eig_flag) return QC_EIG_NOT_CONVERGED;
     st->ms_setup = now_ms() - t0;
     *out = guard.release();
     return QC_OK;
@@ -539,17 +604,42 @@ static int scf_iterate(qc_scf_state *st, double *energy, double *rms_out) {
     for (int s = 0; s < nspin; ++s)                                       // (the control words were cleared by the previous pass)
         if ((rc = roothaan_enqueue(S, W, *st->diis[s], st->G.p + s * nn, st->D[s].p, st->ws.p + s * n, st->Cs.p + s * nn, s, dE[s], dF[s], have_F)) != QC_OK) return rc;
     int *h_ctl = reinterpret_cast<int *>(W.h_scal + 4);
+    // Multi-rank runs take every decision (convergence, DIIS failure, eigensolve mode, repeat) from the SAME numbers on every
+    // rank: the pass scalars go to device memory, are all-reduced as bit patterns (max) together with their complements - so a
+    // rank whose copy differs is noticed (max(x) != ~max(~x)) - and only then reach the host.  The replicated linear algebra is
+    // deterministic and starts from bit-identical G (integer all-reduce), so the copies agree; this makes a divergence an
+    // error on all ranks in the same pass instead of a hang in the next all-reduce.
+    const bool multi = S->comm != nullptr;
+    double *scal_out = multi ? reinterpret_cast<double *>(W.d_sync) : W.h_scal;
+    int *ctl_out = multi ? reinterpret_cast<int *>(W.d_sync + 4) : h_ctl;
     auto density_and_scalars = [&](int s) -> int {
         if (st->nocc[s] > 0) qc_gemm(sm, n, n, st->nocc[s], st->uhf ? 1.0 : 2.0, st->Cs.p + s * nn, n, false, st->Cs.p + s * nn, n, true, 0.0, st->Dn[s].p, n);
         else QC_HIP_CHECK(hipMemsetAsync(st->Dn[s].p, 0, nn * sizeof(double), sm));
         // energy and rms straight into pinned host memory; the last spin's kernel also hands over and clears the control words
-        qc_energy_rms(sm, n, st->Dn[s].p, st->D[s].p, W.H.p, st->G.p + s * nn, W.h_scal + 2 * s, s == nspin - 1 ? W.ctl : nullptr, h_ctl);
+        qc_energy_rms(sm, n, st->Dn[s].p, st->D[s].p, W.H.p, st->G.p + s * nn, scal_out + 2 * s, s == nspin - 1 ? W.ctl : nullptr, ctl_out);
         return QC_OK;
     };
+    auto publish_scalars = [&]() -> int {
+        if (!multi) return QC_OK;
+        qc_sync_pack(sm, W.d_sync, QC_SYNC_WORDS);
+        if (qc_rccl().AllReduce(W.d_sync, W.d_sync, 2 * QC_SYNC_WORDS, ncclUint64, ncclMax, (ncclComm_t)S->comm, sm) != ncclSuccess) return QC_ERR_RCCL;
+        QC_HIP_CHECK(hipMemcpyAsync(W.h_scal, W.d_sync, 2 * QC_SYNC_WORDS * sizeof(double), hipMemcpyDeviceToHost, sm));
+        return QC_OK;
+    };
+    auto ranks_agree = [&]() -> bool {
+        if (!multi) return true;
+        const unsigned long long *w = reinterpret_cast<const unsigned long long *>(W.h_scal);
+        for (int i = 0; i < QC_SYNC_WORDS; ++i) if (w[QC_SYNC_WORDS + i] != ~w[i]) return false;
+        return true;
+    };
+    if (multi && nspin == 1) QC_HIP_CHECK(hipMemsetAsync(W.d_sync + 2, 0, 2 * sizeof(double), sm));       // unused spin slot
     for (int s = 0; s < nspin; ++s) if ((rc = density_and_scalars(s)) != QC_OK) return rc;
+    if ((rc = publish_scalars()) != QC_OK) return rc;
     QC_HIP_CHECK(hipEventRecord(st->ev2, sm));
     QC_HIP_CHECK(wait_event(st->ev2));
+    if (!ranks_agree()) { fprintf(stderr, "qchem_hip: rank %d: the ranks' SCF scalars differ - replicated state diverged\n", S->rank); return QC_ERR_RCCL; }
     if (h_ctl[8] != 0) return QC_DIIS_SINGULAR;                          // "DIIS failed", rhf.rs:73
+    if (h_ctl[9] != 0) return QC_EIG_NOT_CONVERGED;
     static const bool dbg = getenv("QC_SCF_DEBUG") != nullptr;
     if (dbg) fprintf(stderr, "[scf] ctl a: %d %d %d %d  b: %d %d %d %d  npass %d %d have_prev %d\n", h_ctl[0], h_ctl[1], h_ctl[2], h_ctl[3], h_ctl[4], h_ctl[5], h_ctl[6], h_ctl[7], W.npass[0], W.npass[1], (int)W.have_prev[0]);
     float ms_f = 0, ms_l = 0;
@@ -567,8 +657,10 @@ static int scf_iterate(qc_scf_state *st, double *energy, double *rms_out) {
         redo = true;
     }
     if (redo) {
+        if ((rc = publish_scalars()) != QC_OK) return rc;
         QC_HIP_CHECK(hipEventRecord(st->ev2, sm));
         QC_HIP_CHECK(wait_event(st->ev2));
+        if (!ranks_agree()) return QC_ERR_RCCL;
         float ms_r = 0;
         (void)hipEventElapsedTime(&ms_r, st->ev1, st->ev2);
         ms_l += ms_r;
@@ -597,7 +689,8 @@ static int scf_run(qc_system *S, const qc_hf_config *cfg, qc_hf_output *out, boo
     qc_scf_state *st = nullptr;
     int rc = scf_begin(S, uhf, cfg->n_alpha, cfg->n_beta, &st);
     if (rc != QC_OK) return rc;
-    std::unique_ptr<qc_scf_state> guard(st);
+    struct Del { void operator()(qc_scf_state *p) const { scf_state_delete(p); } };
+    std::unique_ptr<qc_scf_state, Del> guard(st);
     const int n = S->nbasis;
     out->nuclear_repulsion = qc_nuclear_repulsion(S);                    // rhf.rs:39
     out->electronic_energy = 0.0; out->iterations = 0;
@@ -694,7 +787,7 @@ int qc_scf_timings(qc_scf_state *st, double *ms_setup, double *ms_fock, double *
     if (ms_linalg) *ms_linalg = st->ms_linalg;
     return QC_OK;
 }
-void qc_scf_end(qc_scf_state *st) { delete st; }
+void qc_scf_end(qc_scf_state *st) { scf_state_delete(st); }
 
 // sorted_eigs with a starting guess: V0 = eigenvectors of a nearby matrix (what the SCF loop uses from its second pass on)
 int qc_sym_eig_warm(qc_system *S, int n, const double *A, const double *V0, double *V, double *w) {
@@ -708,12 +801,15 @@ int qc_sym_eig_warm(qc_system *S, int n, const double *A, const double *V0, doub
     if (dw.alloc(n) != QC_OK || sm.alloc(2 * n + 16) != QC_OK) return QC_ERR_HIP;
     QC_HIP_CHECK(hipMemcpyAsync(dA.p, A, nn * sizeof(double), hipMemcpyHostToDevice, S->stream));
     QC_HIP_CHECK(hipMemcpyAsync(dV0.p, V0, nn * sizeof(double), hipMemcpyHostToDevice, S->stream));
-    rc = qc_eig_device_refine(S->stream, n, dA.p, dV0.p, dV.p, dw.p, wk.p, t1.p, t2.p, t3.p, t4.p, sm.p);
+    int flag = 0;
+    QC_HIP_CHECK(hipMemsetAsync(S->d_flag, 0, sizeof(int), S->stream));
+    rc = qc_eig_device_refine(S->stream, n, dA.p, dV0.p, dV.p, dw.p, wk.p, t1.p, t2.p, t3.p, t4.p, sm.p, S->d_flag);
     if (rc != QC_OK) return rc;
     QC_HIP_CHECK(hipMemcpyAsync(V, dV.p, nn * sizeof(double), hipMemcpyDeviceToHost, S->stream));
     QC_HIP_CHECK(hipMemcpyAsync(w, dw.p, n * sizeof(double), hipMemcpyDeviceToHost, S->stream));
+    QC_HIP_CHECK(hipMemcpyAsync(&flag, S->d_flag, sizeof(int), hipMemcpyDeviceToHost, S->stream));
     QC_HIP_CHECK(hipStreamSynchronize(S->stream));
-    return QC_OK;
+    return flag ? QC_EIG_NOT_CONVERGED : QC_OK;
 }
 
 // restricted_hartree_fock (rhf.rs:32-108) / unrestricted_hartree_fock (uhf.rs:36-167)
@@ -724,7 +820,7 @@ int qc_scf_uhf(qc_system *S, const qc_hf_config *cfg, qc_hf_output *out) { retur
 int qc_comm_unique_id(uint8_t id[128]) {
     static_assert(sizeof(ncclUniqueId) == 128, "ncclUniqueId size");
     ncclUniqueId u;
-    if (ncclGetUniqueId(&u) != ncclSuccess) return QC_ERR_RCCL;
+    if (!qc_rccl().ok || qc_rccl().GetUniqueId(&u) != ncclSuccess) return QC_ERR_RCCL;
     std::memcpy(id, &u, 128);
     return QC_OK;
 }
@@ -743,9 +839,20 @@ int qc_comm_init(qc_system *S, const uint8_t id[128], int rank, int nranks) {
     ncclUniqueId u;
     std::memcpy(&u, id, 128);
     ncclComm_t comm;
-    if (ncclCommInitRank(&comm, nranks, u, rank) != ncclSuccess) return QC_ERR_RCCL;
+    if (!qc_rccl().ok) return QC_ERR_RCCL;
+    if (S->comm) { qc_rccl().CommDestroy((ncclComm_t)S->comm); S->comm = nullptr; }      // a second init replaces the communicator
+    if (qc_rccl().CommInitRank(&comm, nranks, u, rank) != ncclSuccess) return QC_ERR_RCCL;
     S->comm = comm;
     return QC_OK;
+}
+
+int qc_rccl_info(char *buf, size_t len) {
+    if (!buf || len == 0) return QC_ERR_INVALID;
+    QcRccl &r = qc_rccl();
+    int v = 0;
+    if (r.ok && r.GetVersion) (void)r.GetVersion(&v);
+    snprintf(buf, len, "%s version %d", r.ok ? r.path.c_str() : "unavailable", v);
+    return r.ok ? QC_OK : QC_ERR_RCCL;
 }
 
 int qc_plan_shard(qc_system *S, int rank, int nranks, int64_t *nquartets, double *flops) {

@@ -134,6 +134,8 @@ struct qc_system {
     std::vector<float> unit_ms;              // measured serial time of each launch unit (autotuned once per shard)
     std::vector<int> unit_stream;            // side stream of each launch unit (longest-processing-time assignment)
     std::vector<float> unit_weight;          // durations that order the launches (measured inside concurrent builds)
+    int live_states = 0;                     // qc_scf_state objects that still point at this handle
+    bool zombie = false;                     // qc_system_destroy was called while states were alive: the last qc_scf_end frees the handle
     int fock_mode = 0;                       // 0 direct (default), 1 stored tensor (the reference's own algorithm)
     int accum_fx = 1;                        // 1 (default): fixed-point, order-independent accumulation of G; 0: f64 atomics
     std::string last_error;
@@ -187,11 +189,13 @@ int qc_eig_refine_async(hipStream_t st, int n, double *dA, const double *dV0, do
 void qc_diis_solve(hipStream_t st, int m, int minlen, int maxlen, const int *slots, const double *dots, double *B, double *c, int *flag);
 void qc_lincomb_dev(hipStream_t st, int n, const double *const *Fs, const double *c_dev, int m, double *out);
 // done_tol: the sweeps end after one that met no relative coupling above it (the sweep itself leaves ~done_tol^2 behind)
-int qc_eig_device(hipStream_t st, int n, double *dA /*destroyed*/, double *dV, double *dw, double *d_work, int max_sweeps = 40, double done_tol = 1e-9);
+// notconv (device int, nullable): set to 1 when the sweeps ran out before the criterion was met
+int qc_eig_device(hipStream_t st, int n, double *dA /*destroyed*/, double *dV, double *dw, double *d_work, int max_sweeps = 40, double done_tol = 1e-9,
+                  int *notconv = nullptr);
 int qc_eig_device_warm(hipStream_t st, int n, double *dA, const double *dV0, double *dV, double *dw, double *d_work, double *t1, double *t2,
-                       int max_sweeps = 40, double done_tol = 1e-9);
+                       int max_sweeps = 40, double done_tol = 1e-9, int *notconv = nullptr);
 int qc_eig_device_refine(hipStream_t st, int n, double *dA, const double *dV0, double *dV, double *dw, double *d_work, double *t1, double *t2,
-                         double *t3, double *t4, double *small);
+                         double *t3, double *t4, double *small, int *notconv = nullptr);
 void qc_permute_tensor(hipStream_t st, int n, const double *I, double c_direct, double c_exch, double *T);
 void qc_tensor_gemv(hipStream_t st, int n, const double *T1, const double *D1, const double *T2, const double *D2, double *G);
 void qc_axpby(hipStream_t st, int n, double a, const double *x, double b, const double *y, double *out);
@@ -201,6 +205,7 @@ void qc_symmetrize_add(hipStream_t st, int n, const double *Gt, size_t lo_off, d
 // out[p * count + x] = sum_r Gt[p * plane_stride + r * stride + x], p < (fx ? 2 : 1)
 void qc_reduce_replicas(hipStream_t st, size_t count, int nrep, size_t stride, const double *Gt, double *out, bool fx, size_t plane_stride);
 void qc_count_diff(hipStream_t st, size_t count, const double *a, const double *b, int *flag);
+void qc_sync_pack(hipStream_t st, unsigned long long *w, int nwords);     // w[nwords + i] = ~w[i]
 int qc_lgc_for(int lab, int lcd, int ncd);
 // owner of the i-th (cost-sorted) quartet of launch class `ci`: boustrophedon deal, start rank rotated per class
 inline int qc_shard_owner(size_t i, int nranks, size_t ci) {

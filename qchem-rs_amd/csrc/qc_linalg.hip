@@ -95,7 +95,8 @@ __device__ __forceinline__ void qc_rr_pair(int step, int k, int m, int &p, int &
 
 template <bool V_IN_LDS>
 __global__ __launch_bounds__(QC_EIG_THREADS) void qc_jacobi_kernel(int n, const double *__restrict__ Ain, double *__restrict__ Vg,
-                                                                   double *__restrict__ Vout, double *__restrict__ w, int max_sweeps, double done_tol) {
+                                                                   double *__restrict__ Vout, double *__restrict__ w, int max_sweeps, double done_tol,
+                                                                   int *__restrict__ notconv) {
     extern __shared__ double sm[];
     const int m = (n + 1) & ~1, half = m / 2, ld = m | 1;
     double *A = sm;                                         // m x ld (padding row/column stay zero => identity rotations)
@@ -122,6 +123,7 @@ __global__ __launch_bounds__(QC_EIG_THREADS) void qc_jacobi_kernel(int n, const 
     for (int k = 0; k < nt / 64; ++k) normF2 += red[k];
     __syncthreads();
 
+    bool conv = false;
     for (int sweep = 0; sweep < max_sweeps; ++sweep) {
         double seen = 0.0;                                  // sum of a_pq^2 at the moment each pair is rotated
         for (int step = 0; step < m - 1; ++step) {
@@ -173,8 +175,9 @@ __global__ __launch_bounds__(QC_EIG_THREADS) void qc_jacobi_kernel(int n, const 
         for (int k = 0; k < nt / 64; ++k) off2 += red[k];
         __syncthreads();
         // Jacobi converges quadratically: a sweep that met a relative off-norm <= done_tol (1e-9) leaves <= ~done_tol^2 behind
-        if (2.0 * off2 <= done_tol * done_tol * normF2) break;
+        if (2.0 * off2 <= done_tol * done_tol * normF2) { conv = true; break; }
     }
+    if (!conv && notconv && tid == 0) *notconv = 1;         // sweeps exhausted: the caller reports it instead of using the vectors
     // ascending order (utils.rs:28): rank sort, then permute columns
     for (int i = tid; i < n; i += nt) {
         const double wi = A[i * ld + i];
@@ -225,7 +228,7 @@ __device__ __forceinline__ void qc_hestenes_rotation(double a, double b, double 
 }
 
 __global__ __launch_bounds__(QC_EIG1_THREADS) void qc_jacobi1_kernel(int n, const double *__restrict__ Ain, double *__restrict__ Vout,
-                                                                    double *__restrict__ w, int max_sweeps, double done_tol) {
+                                                                    double *__restrict__ w, int max_sweeps, double done_tol, int *__restrict__ notconv) {
     extern __shared__ double sm[];
     const int m = (n + 1) & ~1, half = m / 2, ld = n | 1;        // column stride (doubles)
     double *G = sm;                                               // m columns x ld (padding column stays zero)
@@ -258,6 +261,7 @@ __global__ __launch_bounds__(QC_EIG1_THREADS) void qc_jacobi1_kernel(int n, cons
     __syncthreads();
 
     const int team = tid / QC_EIG1_TEAM, tl = tid % QC_EIG1_TEAM;
+    bool conv = false;
     for (int sweep = 0; sweep < max_sweeps; ++sweep) {
         for (int step = 0; step < m - 1; ++step) {
             if (team < half) {
@@ -293,8 +297,9 @@ __global__ __launch_bounds__(QC_EIG1_THREADS) void qc_jacobi1_kernel(int n, cons
         __syncthreads();
         if (tid == 0) *flag = 0;
         __syncthreads();
-        if (!any) break;
+        if (!any) { conv = true; break; }
     }
+    if (!conv && notconv && tid == 0) *notconv = 1;
     // eigenvalues = column norms - sigma; ascending rank sort; normalised, permuted columns out
     for (int j = tid; j < n; j += nt) {
         double s2 = 0.0;
@@ -322,7 +327,8 @@ __global__ __launch_bounds__(QC_EIG1_THREADS) void qc_jacobi1_kernel(int n, cons
 // behind a workgroup barrier per step) but only the cold start and the rare fallback of the refinement use it; the SCF
 // loop's eigensolves are GEMMs (qc_eig_device_refine).  Keeps every shipped basis (benzene/6-311++G**: n = 180) usable.
 __global__ __launch_bounds__(QC_EIG_THREADS) void qc_jacobi1g_kernel(int n, const double *__restrict__ Ain, double *__restrict__ G,
-                                                                     double *__restrict__ Vout, double *__restrict__ w, int max_sweeps, double done_tol) {
+                                                                     double *__restrict__ Vout, double *__restrict__ w, int max_sweeps, double done_tol,
+                                                                     int *__restrict__ notconv) {
     extern __shared__ double sm[];
     __shared__ double red[32];
     __shared__ int flag;
@@ -351,6 +357,7 @@ __global__ __launch_bounds__(QC_EIG_THREADS) void qc_jacobi1g_kernel(int n, cons
     if (tid == 0) flag = 0;
     __syncthreads();
     const int team = tid / QC_EIG1_TEAM, tl = tid % QC_EIG1_TEAM, nteams = nt / QC_EIG1_TEAM;
+    bool conv = false;
     for (int sweep = 0; sweep < max_sweeps; ++sweep) {
         for (int step = 0; step < m - 1; ++step) {
             for (int pr = team; pr < half; pr += nteams) {
@@ -379,8 +386,9 @@ __global__ __launch_bounds__(QC_EIG_THREADS) void qc_jacobi1g_kernel(int n, cons
         __syncthreads();
         if (tid == 0) flag = 0;
         __syncthreads();
-        if (!any) break;
+        if (!any) { conv = true; break; }
     }
+    if (!conv && notconv && tid == 0) *notconv = 1;
     for (int j = tid; j < n; j += nt) {
         double s2 = 0.0;
         for (int i = 0; i < n; ++i) s2 = fma(G[(size_t)j * n + i], G[(size_t)j * n + i], s2);
@@ -402,7 +410,7 @@ __global__ __launch_bounds__(QC_EIG_THREADS) void qc_jacobi1g_kernel(int n, cons
 }
 
 // dA: input (left intact), dV: sorted eigenvectors, dw: eigenvalues, d_work: n*n scratch
-int qc_eig_device(hipStream_t st, int n, double *dA, double *dV, double *dw, double *d_work, int max_sweeps, double done_tol) {
+int qc_eig_device(hipStream_t st, int n, double *dA, double *dV, double *dw, double *d_work, int max_sweeps, double done_tol, int *notconv) {
     const int m = (n + 1) & ~1, ld = m | 1;
     const size_t tail = (2 * (m / 2) + 32) * sizeof(double) + (size_t)m * sizeof(int) + 16;
     const size_t lds2 = 2 * (size_t)m * ld * sizeof(double) + tail, lds1 = (size_t)m * ld * sizeof(double) + tail;
@@ -413,14 +421,14 @@ int qc_eig_device(hipStream_t st, int n, double *dA, double *dV, double *dw, dou
         if (l1 <= 160 * 1024) {
             hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(qc_jacobi1_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)l1);
             if (e != hipSuccess) return QC_ERR_HIP;
-            hipLaunchKernelGGL(qc_jacobi1_kernel, dim3(1), dim3(QC_EIG1_THREADS), l1, st, n, dA, dV, dw, max_sweeps, done_tol);
+            hipLaunchKernelGGL(qc_jacobi1_kernel, dim3(1), dim3(QC_EIG1_THREADS), l1, st, n, dA, dV, dw, max_sweeps, done_tol, notconv);
             return hipGetLastError() == hipSuccess ? QC_OK : QC_ERR_HIP;
         }
     }
     const size_t lds = v_in_lds ? lds2 : lds1;
     if (lds > 160 * 1024 || !v_in_lds) {                // n > 128: the global-memory variant
         if (n > 3000) return QC_ERR_UNSUPPORTED;
-        hipLaunchKernelGGL(qc_jacobi1g_kernel, dim3(1), dim3(QC_EIG_THREADS), (size_t)n * 12 + 16, st, n, dA, d_work, dV, dw, max_sweeps, done_tol);
+        hipLaunchKernelGGL(qc_jacobi1g_kernel, dim3(1), dim3(QC_EIG_THREADS), (size_t)n * 12 + 16, st, n, dA, d_work, dV, dw, max_sweeps, done_tol, notconv);
         return hipGetLastError() == hipSuccess ? QC_OK : QC_ERR_HIP;
     }
     auto kern = v_in_lds ? qc_jacobi_kernel<true> : qc_jacobi_kernel<false>;
@@ -429,7 +437,7 @@ int qc_eig_device(hipStream_t st, int n, double *dA, double *dV, double *dw, dou
         if (e != hipSuccess) return QC_ERR_HIP;
     }
     static const int nthreads = getenv("QC_EIG_THREADS") ? atoi(getenv("QC_EIG_THREADS")) : QC_EIG_THREADS;
-    hipLaunchKernelGGL(kern, dim3(1), dim3(nthreads), lds, st, n, dA, d_work, dV, dw, max_sweeps, done_tol);
+    hipLaunchKernelGGL(kern, dim3(1), dim3(nthreads), lds, st, n, dA, d_work, dV, dw, max_sweeps, done_tol, notconv);
     return hipGetLastError() == hipSuccess ? QC_OK : QC_ERR_HIP;
 }
 
@@ -437,10 +445,10 @@ int qc_eig_device(hipStream_t st, int n, double *dA, double *dV, double *dw, dou
 // B = V0^T A V0 is nearly diagonal, Jacobi needs 1-3 sweeps instead of ~8, and V = V0 Q.  The three products are
 // f64 MFMA GEMMs.  t1/t2: n*n scratch each.
 int qc_eig_device_warm(hipStream_t st, int n, double *dA, const double *dV0, double *dV, double *dw, double *d_work, double *t1, double *t2,
-                       int max_sweeps, double done_tol) {
+                       int max_sweeps, double done_tol, int *notconv) {
     qc_gemm(st, n, n, n, 1.0, dA, n, false, dV0, n, false, 0.0, t1, n);        // A V0
     qc_gemm(st, n, n, n, 1.0, dV0, n, true, t1, n, false, 0.0, t2, n);         // V0^T (A V0)
-    int rc = qc_eig_device(st, n, t2, t1, dw, d_work, max_sweeps, done_tol);   // Q -> t1
+    int rc = qc_eig_device(st, n, t2, t1, dw, d_work, max_sweeps, done_tol, notconv);   // Q -> t1
     if (rc != QC_OK) return rc;
     qc_gemm(st, n, n, n, 1.0, dV0, n, false, t1, n, false, 0.0, dV, n);        // V = V0 Q
     return QC_OK;
@@ -609,7 +617,7 @@ __global__ __launch_bounds__(1024) void qc_sort_columns_kernel(int n, const doub
 //     * otherwise apply X <- X (I + E) and take another pass.
 // Scratch: t1..t4, d_work (n*n each), small (n + 8 doubles).
 int qc_eig_device_refine(hipStream_t st, int n, double *dA, const double *dV0, double *dV, double *dw, double *d_work, double *t1, double *t2,
-                         double *t3, double *t4, double *small) {
+                         double *t3, double *t4, double *small, int *notconv) {
     const size_t nn = (size_t)n * n;
     double *lam = small, *stats = small + n;
     double *X = t4;                                            // current eigenvector estimate
@@ -640,7 +648,7 @@ int qc_eig_device_refine(hipStream_t st, int n, double *dA, const double *dV0, d
                 qc_gemm(st, n, n, n, 1.0, dA, n, false, dV0, n, false, 0.0, t1, n);
                 qc_gemm(st, n, n, n, 1.0, dV0, n, true, t1, n, false, 0.0, t2, n);
             }
-            int rc = qc_eig_device(st, n, t2, t1, dw, d_work);                     // Q -> t1 (sorted), eigenvalues -> dw
+            int rc = qc_eig_device(st, n, t2, t1, dw, d_work, 40, 1e-9, notconv);      // Q -> t1 (sorted), eigenvalues -> dw
             if (rc != QC_OK) return rc;
             qc_gemm(st, n, n, n, 1.0, dV0, n, false, t1, n, false, 0.0, dV, n);    // V = V0 Q
             return QC_OK;
@@ -658,7 +666,7 @@ int qc_eig_device_refine(hipStream_t st, int n, double *dA, const double *dV0, d
             // X is orthonormal to ~1e-14 now, so Jacobi on X^T A X (a handful of non-trivial rotations) finishes the job
             qc_gemm(st, n, n, n, 1.0, dA, n, false, X, n, false, 0.0, t1, n);
             qc_gemm(st, n, n, n, 1.0, X, n, true, t1, n, false, 0.0, t2, n);
-            int rc = qc_eig_device(st, n, t2, t1, dw, d_work);
+            int rc = qc_eig_device(st, n, t2, t1, dw, d_work, 40, 1e-9, notconv);
             if (rc != QC_OK) return rc;
             qc_gemm(st, n, n, n, 1.0, X, n, false, t1, n, false, 0.0, dV, n);
             return QC_OK;
@@ -1059,6 +1067,12 @@ void qc_energy_rms(hipStream_t st, int n, const double *Dnew, const double *Dold
                    int *ctl_out) {
     hipLaunchKernelGGL(qc_energy_rms_kernel, dim3(1), dim3(1024), 0, st, n, Dnew, Dold, H, G, out2, ctl, ctl_out);
 }
+
+// w[nwords + i] = ~w[i]: the complements that let a max all-reduce over bit patterns reveal a rank whose words differ
+__global__ void qc_sync_pack_kernel(unsigned long long *w, int nwords) {
+    if ((int)threadIdx.x < nwords) w[nwords + threadIdx.x] = ~w[threadIdx.x];
+}
+void qc_sync_pack(hipStream_t st, unsigned long long *w, int nwords) { hipLaunchKernelGGL(qc_sync_pack_kernel, dim3(1), dim3(64), 0, st, w, nwords); }
 
 // out = sum_i c[i] * Fs[i]   (diis.rs:52-58)
 struct QcCoefList { double c[16]; };

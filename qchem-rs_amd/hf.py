@@ -31,7 +31,7 @@ os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("QCHEM_HIP_LIB") or os.path.join(_HERE, "libqchem_hip.so")
 
-QC_OK, QC_NOT_CONVERGED, QC_DIIS_SINGULAR = 0, 1, 2
+QC_OK, QC_NOT_CONVERGED, QC_DIIS_SINGULAR, QC_EIG_NOT_CONVERGED = 0, 1, 2, 3
 QC_ERR_INVALID, QC_ERR_NO_DEVICE, QC_ERR_HIP, QC_ERR_RCCL, QC_ERR_UNSUPPORTED = -1, -2, -3, -4, -5
 _ERR = {-1: "invalid argument", -2: "no gfx950 device visible (there is no CPU fallback)", -3: "HIP runtime error",
         -4: "RCCL error", -5: "unsupported (angular momentum > f, or n too large for the in-LDS eigensolver)"}
@@ -41,7 +41,7 @@ EXPORTS = ["qc_system_create", "qc_system_destroy", "qc_nbasis", "qc_nelectrons"
            "qc_fock_rhf_device", "qc_fock_uhf_device", "qc_sym_eig", "qc_scf_rhf", "qc_scf_uhf", "qc_comm_unique_id",
            "qc_comm_init", "qc_set_shard", "qc_plan_shard", "qc_set_stream", "qc_device_ready", "qc_work_stats_get",
            "qc_fock_profile", "qc_plan_shard_quartets", "qc_scf_begin_rhf", "qc_scf_begin_uhf", "qc_scf_iterate",
-           "qc_scf_orbital_energies", "qc_scf_density", "qc_scf_spin_square", "qc_scf_timings", "qc_scf_end", "qc_fock_profile_tiers", "qc_sym_eig_warm", "qc_set_fock_mode", "qc_scf_tensor_ms", "qc_set_accumulation", "qc_set_schwarz", "qc_scf_matrix"]
+           "qc_scf_orbital_energies", "qc_scf_density", "qc_scf_spin_square", "qc_scf_timings", "qc_scf_end", "qc_fock_profile_tiers", "qc_sym_eig_warm", "qc_set_fock_mode", "qc_scf_tensor_ms", "qc_set_accumulation", "qc_set_schwarz", "qc_scf_matrix", "qc_rccl_info"]
 
 
 class QcError(RuntimeError):
@@ -136,6 +136,8 @@ def lib():
 def _check(rc: int, what: str):
     if rc < 0:
         raise QcError(f"{what}: {_ERR.get(rc, rc)}")
+    if rc == QC_EIG_NOT_CONVERGED:
+        raise QcError(f"{what}: the Jacobi sweeps of an eigensolve ran out before convergence")
     return rc
 
 
@@ -325,6 +327,13 @@ class ScfStepper:
             self.close()
         except Exception:
             pass
+
+
+def rccl_info() -> str:
+    """Path and version of the RCCL library libqchem_hip.so has bound (dlopen; see include/qchem_hip.h)."""
+    buf = C.create_string_buffer(512)
+    lib().qc_rccl_info(buf, 512)
+    return buf.value.decode()
 
 
 def comm_unique_id() -> bytes:
