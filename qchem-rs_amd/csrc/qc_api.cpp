@@ -122,8 +122,9 @@ constexpr int QC_SYNC_WORDS = 12;          // 4 doubles + 16 ints of pass scalar
 
 struct ScfWork {
     int n;
-    DevBuf H, S, X, t1, t2, t3, t4, Fp, Cp, C, w, ework, Fd, scal, small, CpPrev[2], CpNew[2], Fps[2];
+    DevBuf H, S, X, t1, t2, t3, t4, Fp, Cp, C, w, ework, Fd, scal, small, CpPrev[2], CpNew[2], Fps[2], X0, tri;
     bool have_prev[2] = {false, false};
+    bool cold[2] = {false, false};         // this pass's eigensolve of the spin started from the tridiagonal path (no previous vectors involved)
     int npass[2] = {3, 3};                 // refinement passes enqueued per eigensolve (follows what the last one needed)
     int mode[2] = {2, 2};                  // eigensolve of the next pass: 0 refinement, 1 two Jacobi sweeps + refinement, 2 Jacobi
     int *ctl = nullptr;                    // device control words: [4 s + 0..3] eigen-refinement of spin s, [8] DIIS failure
@@ -137,8 +138,9 @@ struct ScfWork {
     int init(int n_) {
         n = n_;
         const size_t nn = (size_t)n * n;
-        DevBuf *all[] = {&H, &S, &X, &t1, &t2, &t3, &t4, &Fp, &Cp, &C, &ework, &Fd, &CpPrev[0], &CpPrev[1], &CpNew[0], &CpNew[1], &Fps[0], &Fps[1]};
+        DevBuf *all[] = {&H, &S, &X, &t1, &t2, &t3, &t4, &Fp, &Cp, &C, &ework, &Fd, &CpPrev[0], &CpPrev[1], &CpNew[0], &CpNew[1], &Fps[0], &Fps[1], &X0};
         for (auto b : all) if (b->alloc(nn) != QC_OK) return QC_ERR_HIP;
+        if (tri.alloc(qc_eig_tridiag_work_doubles(n)) != QC_OK) return QC_ERR_HIP;
         if (w.alloc(n) != QC_OK || scal.alloc(16) != QC_OK || small.alloc(2 * n + 16) != QC_OK) return QC_ERR_HIP;
         if (hipMalloc(&ctl, 16 * sizeof(int)) != hipSuccess || hipMemset(ctl, 0, 16 * sizeof(int)) != hipSuccess) return QC_ERR_HIP;
         if (hipHostMalloc(&h_scal, 2 * QC_SYNC_WORDS * sizeof(double)) != hipSuccess) return QC_ERR_HIP;
@@ -149,7 +151,8 @@ struct ScfWork {
 
 // sorted_eigs on device (utils.rs:20-36): Fp -> (Cp, w)
 int device_sorted_eigs(qc_system *S, ScfWork &W, double *dA, double *dV, double *dw) {
-    return qc_eig_device(S->stream, W.n, dA, dV, dw, W.ework.p, 40, 1e-9, W.ctl + 9);     // ctl[9]: Jacobi sweeps ran out
+    // (set-up eigensolves: synchronous; ctl[12..15] scratch, ctl[9]: Jacobi sweeps ran out)
+    return qc_eig_cold_sync(S->stream, W.n, dA, W.X0.p, W.tri.p, dV, dw, W.ework.p, W.t1.p, W.t2.p, W.t3.p, W.t4.p, W.small.p, W.ctl + 12, W.ctl + 9);
 }
 
 // start-up shared by both drivers: H = T + V, X = S^-1/2 (rhf.rs:124-131), Hückel matrix (rhf.rs:141-143)
@@ -211,20 +214,20 @@ int roothaan_enqueue(qc_system *S, ScfWork &W, DeviceDiis &diis, const double *d
     if (rc != QC_OK) return rc;
     qc_gemm(st, n, n, n, 1.0, W.Fd.p, n, false, W.X.p, n, false, 0.0, W.t1.p, n);        // F X
     qc_gemm(st, n, n, n, 1.0, W.X.p, n, true, W.t1.p, n, false, 0.0, W.Fps[spin].p, n);  // X^T (F X)
+    // Eigensolve.  Near convergence (mode 0): GEMM refinement from this spin's previous vectors.  Otherwise - first pass, or the
+    // density still moves by more than 1e-3 per element - the tridiagonal path (start vectors from qc_eig_tridiag.hip + the same
+    // refinement); matrices below QC_TRI_MIN_N go to the single-workgroup Jacobi kernels.  Outcome in ctl[4 spin].
+    W.cold[spin] = false;
     if (W.have_prev[spin] && W.mode[spin] == 0)
         rc = qc_eig_refine_async(st, n, W.Fps[spin].p, W.CpPrev[spin].p, W.CpNew[spin].p, dw_out, W.ework.p, W.t1.p, W.t2.p, W.t3.p, W.t4.p,
                                  W.small.p, W.ctl + 4 * spin, W.npass[spin]);
-    else if (W.have_prev[spin] && W.mode[spin] == 1) {
-        // F' moved a lot: two sweeps of rotations in the basis of the previous vectors (Jacobi converges quadratically, the
-        // remaining coupling is then far inside the refinement's reach), finished by the GEMM-based refinement
-        rc = qc_eig_device_warm(st, n, W.Fps[spin].p, W.CpPrev[spin].p, W.CpNew[spin].p, dw_out, W.ework.p, W.t1.p, W.t2.p, 2);
-        if (rc == QC_OK)
-            rc = qc_eig_refine_async(st, n, W.Fps[spin].p, W.CpNew[spin].p, W.CpNew[spin].p, dw_out, W.ework.p, W.t1.p, W.t2.p, W.t3.p, W.t4.p,
-                                     W.small.p, W.ctl + 4 * spin, 3);
-    } else if (W.have_prev[spin])           // first passes, density far from converged: warm-started Jacobi to convergence
-        // (the density still moves by O(1) per element here: a sweep that met couplings below 1e-5 leaves 1e-10, far below that)
-        rc = qc_eig_device_warm(st, n, W.Fps[spin].p, W.CpPrev[spin].p, W.CpNew[spin].p, dw_out, W.ework.p, W.t1.p, W.t2.p, 40, 1e-5, W.ctl + 9);
-    else rc = device_sorted_eigs(S, W, W.Fps[spin].p, W.CpNew[spin].p, dw_out);          // sorted_eigs (rhf.rs:75), cold
+    else if (n >= QC_TRI_MIN_N) {
+        W.cold[spin] = true;
+        rc = qc_eig_cold_async(st, n, W.Fps[spin].p, W.X0.p, W.tri.p, W.CpNew[spin].p, dw_out, W.ework.p, W.t1.p, W.t2.p, W.t3.p, W.t4.p, W.small.p,
+                               W.ctl + 4 * spin, 3);
+    } else if (W.have_prev[spin])
+        rc = qc_eig_device_warm(st, n, W.Fps[spin].p, W.CpPrev[spin].p, W.CpNew[spin].p, dw_out, W.ework.p, W.t1.p, W.t2.p, 40, 1e-9, W.ctl + 9);
+    else rc = qc_eig_device(st, n, W.Fps[spin].p, W.CpNew[spin].p, dw_out, W.ework.p, 40, 1e-9, W.ctl + 9);   // sorted_eigs (rhf.rs:75), cold
     if (rc != QC_OK) return rc;
     qc_gemm(st, n, n, n, 1.0, W.X.p, n, false, W.CpNew[spin].p, n, false, 0.0, dC, n);   // C = X C'
     return QC_OK;
@@ -234,7 +237,11 @@ int roothaan_enqueue(qc_system *S, ScfWork &W, DeviceDiis &diis, const double *d
 int roothaan_redo_eig(qc_system *S, ScfWork &W, double *dw_out, double *dC, int spin) {
     const int n = S->nbasis;
     hipStream_t st = S->stream;
-    int rc = qc_eig_device_refine(st, n, W.Fps[spin].p, W.CpPrev[spin].p, W.CpNew[spin].p, dw_out, W.ework.p, W.t1.p, W.t2.p, W.t3.p, W.t4.p, W.small.p, W.ctl + 9);
+    int rc;
+    if (W.cold[spin] && W.have_prev[spin])    // the tridiagonal start was not good enough: rotations in the basis of the previous vectors
+        rc = qc_eig_device_warm(st, n, W.Fps[spin].p, W.CpPrev[spin].p, W.CpNew[spin].p, dw_out, W.ework.p, W.t1.p, W.t2.p, 40, 1e-9, W.ctl + 9);
+    else if (W.cold[spin]) rc = qc_eig_device(st, n, W.Fps[spin].p, W.CpNew[spin].p, dw_out, W.ework.p, 40, 1e-9, W.ctl + 9);
+    else rc = qc_eig_device_refine(st, n, W.Fps[spin].p, W.CpPrev[spin].p, W.CpNew[spin].p, dw_out, W.ework.p, W.t1.p, W.t2.p, W.t3.p, W.t4.p, W.small.p, W.ctl + 9);
     if (rc != QC_OK) return rc;
     qc_gemm(st, n, n, n, 1.0, W.X.p, n, false, W.CpNew[spin].p, n, false, 0.0, dC, n);
     return QC_OK;
@@ -450,12 +457,16 @@ int qc_sym_eig(qc_system *S, int n, const double *A, double *V, double *w) {
     int rc = qc_device_init(S);
     if (rc != QC_OK) return rc;
     const size_t nn = (size_t)n * n;
-    DevBuf dA, dV, dw, dwork;
-    if (dA.alloc(nn) != QC_OK || dV.alloc(nn) != QC_OK || dw.alloc(n) != QC_OK || dwork.alloc(nn) != QC_OK) return QC_ERR_HIP;
+    DevBuf dA, dV, dw, dwork, x0, tri, t1, t2, t3, t4, sm;
+    DevBuf *all[] = {&dA, &dV, &dwork, &x0, &t1, &t2, &t3, &t4};
+    for (auto b : all) if (b->alloc(nn) != QC_OK) return QC_ERR_HIP;
+    if (dw.alloc(n) != QC_OK || sm.alloc(2 * n + 16) != QC_OK || tri.alloc(qc_eig_tridiag_work_doubles(n)) != QC_OK) return QC_ERR_HIP;
     QC_HIP_CHECK(hipMemcpyAsync(dA.p, A, nn * sizeof(double), hipMemcpyHostToDevice, S->stream));
     int flag = 0;
-    QC_HIP_CHECK(hipMemsetAsync(S->d_flag, 0, sizeof(int), S->stream));
-    rc = qc_eig_device(S->stream, n, dA.p, dV.p, dw.p, dwork.p, 40, 1e-9, S->d_flag);
+    QC_HIP_CHECK(hipMemsetAsync(S->d_flag, 0, 4 * sizeof(int), S->stream));
+    DevBuf ctlb;                                           // 4 control words of the refinement; d_flag[0]: Jacobi sweeps ran out
+    if (ctlb.alloc(2) != QC_OK) return QC_ERR_HIP;
+    rc = qc_eig_cold_sync(S->stream, n, dA.p, x0.p, tri.p, dV.p, dw.p, dwork.p, t1.p, t2.p, t3.p, t4.p, sm.p, reinterpret_cast<int *>(ctlb.p), S->d_flag);
     if (rc != QC_OK) return rc;
     QC_HIP_CHECK(hipMemcpyAsync(V, dV.p, nn * sizeof(double), hipMemcpyDeviceToHost, S->stream));
     QC_HIP_CHECK(hipMemcpyAsync(w, dw.p, n * sizeof(double), hipMemcpyDeviceToHost, S->stream));
@@ -647,8 +658,9 @@ static int scf_iterate(qc_scf_state *st, double *energy, double *rms_out) {
     (void)hipEventElapsedTime(&ms_l, st->ev1, st->ev2);
     bool redo = false;
     for (int s = 0; s < nspin; ++s) {
-        if (!W.have_prev[s] || W.mode[s] == 2) continue;
-        if (h_ctl[4 * s] == 1) { W.npass[s] = W.mode[s] ? 3 : std::max(1, std::min(3, h_ctl[4 * s + 3])); continue; }
+        const bool refined = W.cold[s] || (W.have_prev[s] && W.mode[s] == 0);       // the eigensolve reported through the control word
+        if (!refined) continue;
+        if (h_ctl[4 * s] == 1) { W.npass[s] = W.cold[s] ? 3 : std::max(1, std::min(3, h_ctl[4 * s + 3])); continue; }
         W.npass[s] = 3;
         // the refinement wanted rotations (large step, or a degenerate cluster): repeat this spin's eigensolve the careful way
         if (!redo) QC_HIP_CHECK(hipEventRecord(st->ev1, sm));

@@ -1,0 +1,481 @@
+// qc_eig_tridiag.hip - start vectors for the symmetric eigensolver by Householder tridiagonalisation (gfx950).
+//
+// Replaces the cold / far-from-converged eigensolves behind utils::sorted_eigs (hf/utils.rs:20-36; nalgebra's SymmetricEigen
+// does the same thing: tridiagonalise, then iterate on the tridiagonal matrix).  The parallel Jacobi kernels of qc_linalg.hip
+// touch the whole matrix in every one of their ~6 (n-1) steps and are bound by the LDS port of the single CU they run on
+// (2 n^2 doubles read and written per step: 1.8 us per step at n = 114, 1.1-1.6 ms per eigensolve).  Here
+//   1. qc_tridiag_kernel      A + pert = Q T Q^T: n-2 Householder steps in ONE workgroup, matrix resident in LDS (n <= 139, else in
+//                             global memory), 4 barriers per step, every access along rows (both triangles are kept);
+//   2. qc_tri_eig_kernel      eigenvalues of T by 9-way multisection on division-free Sturm sequences (8 lanes per eigenvalue),
+//                             eigenvectors by twisted factorisation (one lane per eigenvalue, four O(n) sweeps);
+//   3. qc_backtransform_kernel  X0 = Q Z: one wave per eigenvector applies the n-2 reflectors (whole chip);
+// and the result goes into the Ogita-Aishima refinement (qc_eig_refine_async: f64 MFMA GEMMs), which converges quadratically
+// and therefore only needs X0 to ~1e-3: that is why none of the delicate parts of a tridiagonal eigensolver are needed -
+//   * exactly degenerate eigenvalues (benzene's E-type orbital pairs) would leave the twisted vectors of a pair parallel.  A
+//     diagonal pseudo-random perturbation of relative size 1e-9 splits them first (any basis of a degenerate subspace is a valid
+//     answer); the refinement then works on the unperturbed matrix and treats what is left as its "strong pairs";
+//   * a start that is not good enough (orthogonality > 1e-3, clusters the refinement cannot rotate) is detected by the
+//     refinement's control word and answered with the Jacobi kernels - correctness never rests on this file.
+#include <atomic>
+#include <cstdlib>
+
+#include "qc_internal.h"
+
+namespace {
+
+constexpr int TRI_THREADS = 1024;
+constexpr int TRI_TEAM = 8;                         // lanes per matrix row (matvec, update) / per eigenvalue (multisection)
+
+// Lane exchanges inside a 16-lane row through DPP moves of the two 32-bit halves (64-bit DPP exists only for row_newbcast): a few
+// cycles each, where the ds_bpermute behind __shfl_xor costs an LDS round trip - and these reductions sit on the critical path of
+// every Householder step.
+template <int CTRL>
+__device__ __forceinline__ double dpp_move(double x) {
+    int lo = __double2loint(x), hi = __double2hiint(x);
+    lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xf, 0xf, true);
+    hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xf, 0xf, true);
+    return __hiloint2double(hi, lo);
+}
+constexpr int DPP_XOR1 = 0xB1, DPP_XOR2 = 0x4E, DPP_HALF_MIRROR = 0x141, DPP_ROW_MIRROR = 0x140;
+// sum over the 8 lanes of a team (aligned groups of 8), result in every lane
+__device__ __forceinline__ double team_sum(double v) {
+    v += dpp_move<DPP_XOR1>(v);
+    v += dpp_move<DPP_XOR2>(v);
+    v += dpp_move<DPP_HALF_MIRROR>(v);
+    return v;
+}
+// sum over the wave, result in every lane; fixed order
+__device__ __forceinline__ double wave_sum(double v) {
+    v = team_sum(v);
+    v += dpp_move<DPP_ROW_MIRROR>(v);                    // 16-lane row sums
+    auto row = [&](int l) { return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), l), __builtin_amdgcn_readlane(__double2loint(v), l)); };
+    return (row(0) + row(16)) + (row(32) + row(48));
+}
+// Workgroup barrier that waits for the LDS traffic only.  __syncthreads() also waits for every outstanding global store
+// (s_waitcnt vmcnt(0)) - here the reflector rows a step writes for the LATER kernels, a ~2.5 us round trip per step that made
+// a Householder step cost the same for n = 24 as for n = 128.  Nothing inside these kernels reads those stores back.
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+// deterministic pseudo-random number in [-1, 1) from an index (splitmix64)
+__device__ __forceinline__ double hash_unit(unsigned long long i) {
+    unsigned long long z = (i + 1) * 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    z ^= z >> 31;
+    return (double)(long long)(z >> 11) * 0x1p-52 - 1.0;
+}
+
+// 1 / x to a few ulp: hardware estimate + two Newton steps (half the dependent latency of the IEEE division sequence)
+__device__ __forceinline__ double fast_rcp(double x) {
+    double r = __builtin_amdgcn_rcp(x);
+    r = fma(fma(-x, r, 1.0), r, r);
+    return fma(fma(-x, r, 1.0), r, r);
+}
+
+// ---- 1. A + diag(pert) = Q T Q^T.  Vr[k * n + i]: Householder vector of step k (zero for i <= k, one at k + 1); tri = [d (n) | e (n) | tau (n) | e^2 (n)].
+template <bool IN_LDS>
+__global__ __launch_bounds__(TRI_THREADS) void qc_tridiag_kernel(int n, int ld, const double *__restrict__ Ain, double rel_pert, double *__restrict__ Awork,
+                                                                  double *__restrict__ Vr, double *__restrict__ tri) {
+    extern __shared__ double sm[];
+    double *A = IN_LDS ? sm : Awork;                     // n rows of stride ld, both triangles
+    double *p = IN_LDS ? sm + (size_t)n * ld : sm;       // n (at least 16)
+    double *sc = p + (n < 16 ? 16 : n);                  // 8 scalars
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    double *d = tri, *e = tri + n, *tau = tri + 2 * n;
+
+    // load (symmetric part), scale = max |a_ii| + row sums -> perturbation size
+    double amax = 0.0;
+    for (int x = tid; x < n * n; x += TRI_THREADS) {
+        const int i = x / n, j = x - i * n;
+        const double a = 0.5 * (Ain[x] + Ain[(size_t)j * n + i]);
+        A[(size_t)i * ld + j] = a;
+        amax = fmax(amax, fabs(a));
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) amax = fmax(amax, __shfl_xor(amax, o, 64));
+    if (lane == 0) p[wave] = amax;
+    __syncthreads();
+    if (tid == 0) {
+        double m = 0.0;
+        for (int k = 0; k < TRI_THREADS / 64; ++k) m = fmax(m, p[k]);
+        sc[0] = m;
+    }
+    __syncthreads();
+    const double pert = rel_pert * sc[0];
+    for (int i = tid; i < n; i += TRI_THREADS) A[(size_t)i * ld + i] += pert * hash_unit((unsigned long long)i);
+    __syncthreads();
+
+    // Two barriers per step, no single-wave phases: the Householder scalars of row k + 1 are worked out (rsqrt / rcp forms - the
+    // IEEE sqrt and division sequences are most of a step when every wave runs them) by the team that has just updated that
+    // row, while the other waves still update theirs; v is never materialised (v_j = row_k[j] * inv) and every wave forms the
+    // scalar p.v itself.
+    const int tl = tid & (TRI_TEAM - 1), team = tid / TRI_TEAM;
+    auto leave_row_scalars = [&](const double *row, int kk) {      // team-wide: sc[2..4] = beta, tau, 1 / (x0 - beta) of row kk
+        double s2 = 0.0;
+        for (int j = kk + 2 + tl; j < n; j += TRI_TEAM) s2 = fma(row[j], row[j], s2);
+        s2 = team_sum(s2);
+        const double x0 = row[kk + 1];
+        double beta = x0, t = 0.0, inv = 0.0;
+        if (s2 > 0.0) {
+            const double nn2 = fma(x0, x0, s2);
+            double r = __builtin_amdgcn_rsq(nn2);                   // 1 / ||x||, two Newton steps
+            r = r * fma(-0.5 * nn2 * r, r, 1.5);
+            r = r * fma(-0.5 * nn2 * r, r, 1.5);
+            const double mu = nn2 * r;
+            beta = x0 <= 0.0 ? mu : -mu;
+            t = (beta - x0) * (x0 <= 0.0 ? r : -r);                 // (beta - x0) / beta
+            inv = fast_rcp(x0 - beta);
+        }
+        if (tl == 0) { sc[2] = beta; sc[3] = t; sc[4] = inv; }
+    };
+    if (team == 0) leave_row_scalars(A, 0);
+    __syncthreads();
+    for (int k = 0; k + 2 < n; ++k) {
+        const int m = n - k - 1;                         // trailing block: indices k + 1 .. n - 1
+        const double *rowk = A + (size_t)k * ld;
+        const double beta = sc[2], t = sc[3], inv = sc[4];
+        if (tid == 0) { d[k] = rowk[k]; e[k] = beta; tau[k] = t; tri[3 * n + k] = beta * beta; }
+        for (int i = tid; i < n; i += TRI_THREADS) Vr[(size_t)k * n + i] = i <= k ? 0.0 : (i == k + 1 ? 1.0 : rowk[i] * inv);
+        if (t != 0.0) {                                  // (workgroup-uniform)
+            // p = tau A22 v: one team of 8 lanes per row
+            for (int r = team; r < m; r += TRI_THREADS / TRI_TEAM) {
+                const double *row = A + (size_t)(k + 1 + r) * ld;
+                double s = tl == 0 ? row[k + 1] : 0.0;   // v_{k+1} = 1
+#pragma unroll 4
+                for (int j = k + 2 + tl; j < n; j += TRI_TEAM) s = fma(row[j], rowk[j] * inv, s);
+                s = team_sum(s);
+                if (tl == 0) p[k + 1 + r] = t * s;
+            }
+            if (IN_LDS) lds_barrier(); else __syncthreads();
+            double pv = 0.0;                             // p . v, by every wave for itself
+            for (int i = k + 1 + lane; i < n; i += 64) pv = fma(p[i], i == k + 1 ? 1.0 : rowk[i] * inv, pv);
+            const double K = 0.5 * t * wave_sum(pv);
+            // A22 -= v w^T + w v^T,  w = p - K v
+            for (int r = team; r < m; r += TRI_THREADS / TRI_TEAM) {
+                const int i = k + 1 + r;
+                double *row = A + (size_t)i * ld;
+                const double vi = r == 0 ? 1.0 : rowk[i] * inv, wi = fma(-K, vi, p[i]);
+#pragma unroll 4
+                for (int j = k + 1 + tl; j < n; j += TRI_TEAM) {
+                    const double vj = j == k + 1 ? 1.0 : rowk[j] * inv, wj = fma(-K, vj, p[j]);
+                    row[j] -= fma(vi, wj, wi * vj);
+                }
+                // (LDS: the DS unit serves a wave's operations in order, so the team sees its own lanes' stores)
+                if (IN_LDS && r == 0) leave_row_scalars(row, k + 1);
+            }
+        } else if (IN_LDS && team == 0) leave_row_scalars(A + (size_t)(k + 1) * ld, k + 1);
+        if (IN_LDS) lds_barrier(); else __syncthreads();
+        if (!IN_LDS) {                                    // matrix in global memory: the row is read back behind the barrier
+            if (team == 0) leave_row_scalars(A + (size_t)(k + 1) * ld, k + 1);
+            __syncthreads();
+        }
+    }
+    if (tid == 0) {
+        const double el = A[(size_t)(n - 2) * ld + n - 1];
+        d[n - 2] = A[(size_t)(n - 2) * ld + n - 2]; e[n - 2] = el; tau[n - 2] = 0.0; tri[3 * n + n - 2] = el * el;
+        d[n - 1] = A[(size_t)(n - 1) * ld + n - 1]; e[n - 1] = 0.0; tau[n - 1] = 0.0; tri[3 * n + n - 1] = 0.0;
+    }
+}
+
+// ---- 1b. the same for n <= 128 with the matrix in REGISTERS: team r (8 lanes) owns row r, lane l of it the column pairs
+// (2 l, 2 l + 1) + 16 u.  The LDS kernel above moves the trailing block through the LDS port three times per step (48 m^2 bytes)
+// and waits for every one of those loads; here a step touches LDS only for vectors (the row being eliminated, v, p; double-
+// buffered so that two barriers per step suffice), and the two O(n^2) phases are unpredicated FMAs on registers: columns that
+// are already finished meet v_j = 0 (their stale register contents stay finite - each step adds a bounded multiple of p_j).
+// What limits a step is the instruction count of the 16 waves on the CU's four SIMDs, hence the bare loops.
+constexpr int TR_U = 8;                                  // column pairs per lane: 8 lanes * 2 * 8 = 128
+__global__ __launch_bounds__(TRI_THREADS) void qc_tridiag_reg_kernel(int n, const double *__restrict__ Ain, double rel_pert, double *__restrict__ Vr,
+                                                                      double *__restrict__ tri) {
+    __shared__ double2 vbuf[2][64], pbuf[2][64];
+    __shared__ double rowbuf[128], sc[2][4], red[16];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, tl = tid & (TRI_TEAM - 1), row = tid / TRI_TEAM;
+    double *d = tri, *e = tri + n, *tau = tri + 2 * n;
+    double2 a[TR_U];
+    double amax = 0.0;
+    const double pert_unit = hash_unit((unsigned long long)row);
+#pragma unroll
+    for (int u = 0; u < TR_U; ++u) {
+        const int j = 2 * tl + 16 * u;
+        a[u].x = (row < n && j < n) ? 0.5 * (Ain[(size_t)row * n + j] + Ain[(size_t)j * n + row]) : 0.0;
+        a[u].y = (row < n && j + 1 < n) ? 0.5 * (Ain[(size_t)row * n + j + 1] + Ain[(size_t)(j + 1) * n + row]) : 0.0;
+        amax = fmax(amax, fmax(fabs(a[u].x), fabs(a[u].y)));
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) amax = fmax(amax, __shfl_xor(amax, o, 64));
+    if (lane == 0) red[wave] = amax;
+    if (tid < 64) { vbuf[0][tid] = vbuf[1][tid] = pbuf[0][tid] = pbuf[1][tid] = make_double2(0.0, 0.0); }
+    __syncthreads();
+    amax = 0.0;
+    for (int k = 0; k < TRI_THREADS / 64; ++k) amax = fmax(amax, red[k]);
+    const double pert = rel_pert * amax * pert_unit;
+#pragma unroll
+    for (int u = 0; u < TR_U; ++u) {
+        const int j = 2 * tl + 16 * u;
+        a[u].x += j == row ? pert : 0.0;
+        a[u].y += j + 1 == row ? pert : 0.0;
+    }
+
+    for (int k = 0; k + 2 < n; ++k) {
+        double2 *vb = vbuf[k & 1], *pb = pbuf[k & 1];
+        double *scb = sc[k & 1];
+        if (wave == (k >> 3)) {                          // (wave-uniform) the wave that holds row k builds the Householder vector
+            if (row == k) {
+#pragma unroll
+                for (int u = 0; u < TR_U; ++u) reinterpret_cast<double2 *>(rowbuf)[tl + 8 * u] = a[u];
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");      // same wave: the DS unit serves its operations in order
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            const double xa = rowbuf[lane], xb = rowbuf[lane + 64];
+            const double s2 = wave_sum((lane > k + 1 ? xa * xa : 0.0) + (lane + 64 > k + 1 ? xb * xb : 0.0));
+            const double x0 = rowbuf[k + 1], dk = rowbuf[k];
+            double beta = x0, t = 0.0, inv = 0.0;
+            if (s2 > 0.0) {
+                const double nn2 = fma(x0, x0, s2);
+                double r = __builtin_amdgcn_rsq(nn2);               // 1 / ||x||, two Newton steps
+                r = r * fma(-0.5 * nn2 * r, r, 1.5);
+                r = r * fma(-0.5 * nn2 * r, r, 1.5);
+                const double mu = nn2 * r;
+                beta = x0 <= 0.0 ? mu : -mu;
+                t = (beta - x0) * (x0 <= 0.0 ? r : -r);             // (beta - x0) / beta
+                inv = fast_rcp(x0 - beta);
+            }
+            const double va = lane <= k ? 0.0 : (lane == k + 1 ? 1.0 : xa * inv);
+            const double vb1 = lane + 64 <= k ? 0.0 : (lane + 64 == k + 1 ? 1.0 : xb * inv);
+            reinterpret_cast<double *>(vb)[lane] = va;
+            reinterpret_cast<double *>(vb)[lane + 64] = vb1;
+            if (lane == 0) { scb[0] = t; d[k] = dk; e[k] = beta; tau[k] = t; tri[3 * n + k] = beta * beta; }
+            double *vrow = Vr + (size_t)k * n;           // (for the back-transformation kernel; nothing here waits for these stores)
+            if (lane < n) vrow[lane] = va;
+            if (lane + 64 < n) vrow[lane + 64] = vb1;
+        }
+        lds_barrier();
+        const double t = scb[0];
+        const bool busy = t != 0.0 && 8 * wave + 7 > k;   // (wave-uniform: some row of this wave is still in the trailing block)
+        double2 v[TR_U];
+        double y = 0.0;
+        if (busy) {
+#pragma unroll
+            for (int u = 0; u < TR_U; ++u) {
+                if (16 * u + 15 > k) { v[u] = vb[tl + 8 * u]; y = fma(a[u].x, v[u].x, fma(a[u].y, v[u].y, y)); }     // (uniform skip of finished columns)
+                else v[u] = make_double2(0.0, 0.0);
+            }
+            y = t * team_sum(y);
+            if (tl == 0 && row > k) reinterpret_cast<double *>(pb)[row] = y;
+        }
+        lds_barrier();
+        if (busy) {
+            double pv = 0.0;
+#pragma unroll
+            for (int u = 0; u < TR_U; ++u)
+                if (16 * u + 15 > k) { const double2 p2 = pb[tl + 8 * u]; pv = fma(p2.x, v[u].x, fma(p2.y, v[u].y, pv)); }
+            const double K = 0.5 * t * team_sum(pv);
+            const double vi = reinterpret_cast<double *>(vb)[row], wi = fma(-K, vi, y);
+            if (row > k) {
+#pragma unroll
+                for (int u = 0; u < TR_U; ++u)
+                    if (16 * u + 15 > k) {                // (p_j is read a second time rather than kept: registers)
+                        const double2 p2 = pb[tl + 8 * u];
+                        a[u].x -= fma(vi, fma(-K, v[u].x, p2.x), wi * v[u].x);
+                        a[u].y -= fma(vi, fma(-K, v[u].y, p2.y), wi * v[u].y);
+                    }
+            }
+        }
+    }
+    // last 2 x 2 block
+    if (row == n - 2 || row == n - 1) {
+        double dk = 0.0, ek = 0.0;
+#pragma unroll
+        for (int u = 0; u < TR_U; ++u) {
+            const int j = 2 * tl + 16 * u;
+            dk += (j == row ? a[u].x : 0.0) + (j + 1 == row ? a[u].y : 0.0);
+            ek += (j == row + 1 ? a[u].x : 0.0) + (j + 1 == row + 1 ? a[u].y : 0.0);
+        }
+        dk = team_sum(dk); ek = team_sum(ek);
+        if (tl == 0) { d[row] = dk; e[row] = row == n - 1 ? 0.0 : ek; tau[row] = 0.0; tri[3 * n + row] = row == n - 1 ? 0.0 : ek * ek; }
+    }
+}
+
+// number of eigenvalues of T below x: sign changes of the Sturm sequence p_i = (d_i - x) p_{i-1} - e_{i-1}^2 p_{i-2}, without divisions.
+// d / e2 are read with wave-uniform indices from global memory (scalar loads, eight steps at a time); rescaled every 8 steps.
+__device__ __forceinline__ int sturm_count(int n, const double *__restrict__ d, const double *__restrict__ e2, double x) {
+    double q = 1.0, p = d[0] - x;
+    int cnt = p < 0.0 ? 1 : 0;
+    int i = 1;
+    for (; i + 8 <= n; i += 8) {
+        double dd[8], ee[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { dd[u] = d[i + u]; ee[u] = e2[i + u - 1]; }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const double pn = fma(dd[u] - x, p, -(ee[u] * q));
+            cnt += ((pn < 0.0) != (p < 0.0)) ? 1 : 0;
+            q = p; p = pn;
+        }
+        const double s = fmax(fabs(p), fabs(q));
+        if (s > 0x1p300) { p *= 0x1p-300; q *= 0x1p-300; }
+        else if (s < 0x1p-300 && s > 0.0) { p *= 0x1p300; q *= 0x1p300; }
+    }
+    for (; i < n; ++i) {
+        const double pn = fma(d[i] - x, p, -(e2[i - 1] * q));
+        cnt += ((pn < 0.0) != (p < 0.0)) ? 1 : 0;
+        q = p; p = pn;
+    }
+    return cnt;
+}
+
+// ---- 2. eigenpairs of the tridiagonal matrix, TE_WAVES of them per workgroup.  Z[i * n + j] = component i of the (unnormalised)
+// eigenvector of the j-th eigenvalue (ascending); out = [lambda (n) | 1 / ||z_j|| (n)].  tri = [d | e | tau | e^2].
+//   eigenvalue j: one wave, 65-way multisection on Sturm counts (9 rounds: the interval shrinks 65-fold per round, the lanes'
+//   verdicts meet in one ballot);
+//   eigenvector j: twisted factorisation (Fernando; Parlett & Dhillon) by lanes 0 and 1 of that wave - forward pivots D+ (lane 0)
+//   and backward pivots D- (lane 1) are independent recurrences and run side by side into two LDS arrays; twist index
+//   r = argmin |D+_k + D-_k - (d_k - lambda)|; then z_r = 1 with the downward (lane 0) and upward (lane 1) one-term recurrences.
+constexpr int TE_WAVES = 4;
+__global__ __launch_bounds__(TE_WAVES * 64) void qc_tri_eig_kernel(int n, const double *__restrict__ tri, double *__restrict__ Zg, double *__restrict__ out) {
+    extern __shared__ double sm[];                       // per wave: D+ (n) | D- (n)
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int j = blockIdx.x * TE_WAVES + wave;
+    if (j >= n) return;
+    double *Dp = sm + (size_t)wave * 2 * n, *Dm = Dp + n;
+    const double *__restrict__ d = tri, *__restrict__ e = tri + n, *__restrict__ e2 = tri + 3 * n;
+    // Gershgorin interval
+    double lo = 1e300, hi = -1e300;
+    for (int i = lane; i < n; i += 64) {
+        const double r = (i > 0 ? fabs(e[i - 1]) : 0.0) + (i + 1 < n ? fabs(e[i]) : 0.0);
+        lo = fmin(lo, d[i] - r); hi = fmax(hi, d[i] + r);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { lo = fmin(lo, __shfl_xor(lo, o, 64)); hi = fmax(hi, __shfl_xor(hi, o, 64)); }
+    { const double w = fmax(hi - lo, 1e-300); lo -= 1e-3 * w; hi += 1e-3 * w; }
+    const double tiny = 1e-300 + 0x1p-52 * 0x1p-52 * fmax(fabs(lo), fabs(hi));
+    for (int round = 0; round < 10; ++round) {
+        const double h = (hi - lo) * (1.0 / 65.0);
+        const double x = lo + h * (lane + 1);
+        const unsigned long long above = __ballot(sturm_count(n, d, e2, x) > j);     // lanes whose point lies above eigenvalue j
+        const int first = above ? __builtin_ctzll(above) : 64;
+        const double nlo = lo + h * first, nhi = first == 64 ? hi : lo + h * (first + 1);
+        lo = nlo; hi = nhi;
+        if (!(hi - lo > 0x1p-52 * fmax(fabs(lo), fabs(hi)))) break;                  // (wave-uniform)
+    }
+    const double l = 0.5 * (lo + hi);
+    auto guard = [&](double x) { return fabs(x) < tiny ? tiny : x; };
+    if (lane == 0) {                                     // D+_i = (d_i - l) - e_{i-1}^2 / D+_{i-1}
+        double dp = guard(d[0] - l);
+        Dp[0] = dp;
+        for (int i = 1; i < n; ++i) { dp = guard(fma(-e2[i - 1], fast_rcp(dp), d[i] - l)); Dp[i] = dp; }
+    } else if (lane == 1) {                              // D-_i = (d_i - l) - e_i^2 / D-_{i+1}
+        double dm = guard(d[n - 1] - l);
+        Dm[n - 1] = dm;
+        for (int i = n - 2; i >= 0; --i) { dm = guard(fma(-e2[i], fast_rcp(dm), d[i] - l)); Dm[i] = dm; }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    double gmin = 1e300;
+    int r = 0;
+    for (int i = lane; i < n; i += 64) {
+        const double g = fabs(Dp[i] + Dm[i] - (d[i] - l));
+        if (g < gmin) { gmin = g; r = i; }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const double g2 = __shfl_xor(gmin, o, 64);
+        const int r2 = __shfl_xor(r, o, 64);
+        if (g2 < gmin || (g2 == gmin && r2 < r)) { gmin = g2; r = r2; }
+    }
+    // z_r = 1; downwards z_i = -(e_i / D+_i) z_{i+1} (lane 0); upwards z_{i+1} = -(e_i / D-_{i+1}) z_i (lane 1)
+    double nrm = 0.0;
+    if (lane == 0) {
+        double zi = 1.0;
+        nrm = 1.0;
+        Zg[(size_t)r * n + j] = 1.0;
+        for (int i = r - 1; i >= 0; --i) {
+            zi = -(e[i] * fast_rcp(Dp[i])) * zi;
+            Zg[(size_t)i * n + j] = zi;
+            nrm = fma(zi, zi, nrm);
+        }
+    } else if (lane == 1) {
+        double zi = 1.0;
+        for (int i = r; i + 1 < n; ++i) {
+            zi = -(e[i] * fast_rcp(Dm[i + 1])) * zi;
+            Zg[(size_t)(i + 1) * n + j] = zi;
+            nrm = fma(zi, zi, nrm);
+        }
+    }
+    nrm += __shfl(nrm, 1, 64);
+    if (lane == 0) { out[j] = l; out[n + j] = rsqrt(nrm); }
+}
+
+// ---- 3. X0 = Q Z, Q = H_0 H_1 ... H_{n-3}: one wave per eigenvector, its components in registers (NPL per lane), reflectors from L2
+template <int NPL>
+__global__ __launch_bounds__(256) void qc_backtransform_kernel(int n, const double *__restrict__ Zg, const double *__restrict__ Vr, const double *__restrict__ tri,
+                                                               const double *__restrict__ evn, double *__restrict__ X0) {
+    const int lane = threadIdx.x & 63, j = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (j >= n) return;
+    const double *tau = tri + 2 * n;
+    const double sc = evn[n + j];
+    double x[NPL];
+#pragma unroll
+    for (int u = 0; u < NPL; ++u) { const int i = lane + 64 * u; x[u] = i < n ? Zg[(size_t)i * n + j] * sc : 0.0; }
+    double vn[NPL];
+    int k = n - 3;
+    if (k >= 0) {
+#pragma unroll
+        for (int u = 0; u < NPL; ++u) { const int i = lane + 64 * u; vn[u] = i < n ? Vr[(size_t)k * n + i] : 0.0; }
+    }
+    for (; k >= 0; --k) {
+        double vv[NPL];
+#pragma unroll
+        for (int u = 0; u < NPL; ++u) vv[u] = vn[u];
+        if (k > 0) {
+#pragma unroll
+            for (int u = 0; u < NPL; ++u) { const int i = lane + 64 * u; vn[u] = i < n ? Vr[(size_t)(k - 1) * n + i] : 0.0; }   // next reflector, one step ahead
+        }
+        const double t = tau[k];
+        double s = 0.0;
+#pragma unroll
+        for (int u = 0; u < NPL; ++u) s = fma(vv[u], x[u], s);
+        s = t * wave_sum(s);
+#pragma unroll
+        for (int u = 0; u < NPL; ++u) x[u] = fma(-s, vv[u], x[u]);
+    }
+#pragma unroll
+    for (int u = 0; u < NPL; ++u) { const int i = lane + 64 * u; if (i < n) X0[(size_t)i * n + j] = x[u]; }
+}
+
+}  // namespace
+
+size_t qc_eig_tridiag_work_doubles(int n) { return 2 * (size_t)n * n + 8 * (size_t)n + 16; }
+
+// Approximate eigenvectors (columns of dX0, ascending eigenvalues, orthonormal to ~1e-6 for generic matrices) of the symmetric dA,
+// which is left intact.  work: qc_eig_tridiag_work_doubles(n) doubles.  Asynchronous on `st`.
+int qc_eig_tridiag_start(hipStream_t st, int n, const double *dA, double *dX0, double *work) {
+    if (n < QC_TRI_MIN_N || n > 64 * 8) return QC_ERR_UNSUPPORTED;
+    double *Vr = work, *Zg = work + (size_t)n * n, *tri = Zg + (size_t)n * n, *evn = tri + 4 * (size_t)n;
+    static std::atomic<bool> raised{false};
+    if (!raised.load(std::memory_order_acquire)) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(qc_tridiag_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, QC_LDS_MAX) != hipSuccess) return QC_ERR_HIP;
+        raised.store(true, std::memory_order_release);
+    }
+    const double rel_pert = 1e-9;
+    const size_t small = ((size_t)n + 32) * sizeof(double);
+    // row stride: 8 mod 32 doubles, so that the eight rows a wave reads at a time fall into disjoint LDS banks (when that still fits)
+    int ld = n + ((8 - n % 32) + 32) % 32;
+    if ((size_t)n * ld * sizeof(double) + small > (size_t)QC_LDS_MAX - 1024) ld = n;
+    const size_t lds_a = (size_t)n * ld * sizeof(double) + small;
+    static const bool no_reg = getenv("QC_TRI_LDS") != nullptr;       // A/B switch
+    if (n <= TRI_TEAM * 2 * TR_U && !no_reg)
+        hipLaunchKernelGGL(qc_tridiag_reg_kernel, dim3(1), dim3(TRI_THREADS), 0, st, n, dA, rel_pert, Vr, tri);
+    else if (lds_a <= (size_t)QC_LDS_MAX - 1024)
+        hipLaunchKernelGGL(qc_tridiag_kernel<true>, dim3(1), dim3(TRI_THREADS), lds_a, st, n, ld, dA, rel_pert, (double *)nullptr, Vr, tri);
+    else        // matrix in global memory (Zg's storage is free until the next kernel)
+        hipLaunchKernelGGL(qc_tridiag_kernel<false>, dim3(1), dim3(TRI_THREADS), small, st, n, n, dA, rel_pert, Zg, Vr, tri);
+    hipLaunchKernelGGL(qc_tri_eig_kernel, dim3((n + TE_WAVES - 1) / TE_WAVES), dim3(TE_WAVES * 64), (size_t)TE_WAVES * 2 * n * sizeof(double), st, n, tri, Zg, evn);
+    const int npl = (n + 63) / 64;
+    const dim3 grid((n + 3) / 4), block(256);
+#define QC_BT_CASE(N) case N: hipLaunchKernelGGL(qc_backtransform_kernel<N>, grid, block, 0, st, n, Zg, Vr, tri, evn, dX0); break;
+    switch (npl) { QC_BT_CASE(1) QC_BT_CASE(2) QC_BT_CASE(3) QC_BT_CASE(4) QC_BT_CASE(5) QC_BT_CASE(6) QC_BT_CASE(7) QC_BT_CASE(8) default: return QC_ERR_UNSUPPORTED; }
+#undef QC_BT_CASE
+    return hipGetLastError() == hipSuccess ? QC_OK : QC_ERR_HIP;
+}

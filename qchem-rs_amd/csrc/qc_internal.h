@@ -196,6 +196,17 @@ int qc_eig_device_warm(hipStream_t st, int n, double *dA, const double *dV0, dou
                        int max_sweeps = 40, double done_tol = 1e-9, int *notconv = nullptr);
 int qc_eig_device_refine(hipStream_t st, int n, double *dA, const double *dV0, double *dV, double *dw, double *d_work, double *t1, double *t2,
                          double *t3, double *t4, double *small, int *notconv = nullptr);
+// Tridiagonalisation-based start vectors (qc_eig_tridiag.hip) + refinement: the cold eigensolve.  ctl[0..3] zero on entry; outcome in
+// ctl[0] (1 done: dV / dw hold the sorted eigenpairs; 2: the start was not good enough - repeat with qc_eig_device).  dX0: n*n scratch,
+// triwork: qc_eig_tridiag_work_doubles(n).  Smaller matrices (n < QC_TRI_MIN_N) are for the single-workgroup Jacobi kernels.
+constexpr int QC_TRI_MIN_N = 24;
+size_t qc_eig_tridiag_work_doubles(int n);
+int qc_eig_tridiag_start(hipStream_t st, int n, const double *dA, double *dX0, double *work);
+int qc_eig_cold_async(hipStream_t st, int n, double *dA, double *dX0, double *triwork, double *dV, double *dw, double *d_work, double *t1, double *t2,
+                      double *t3, double *t4, double *small, int *ctl, int npass = 3);
+// synchronous: cold_async, then the Jacobi kernels if the control word asks for them (ctl: 4 ints of device scratch)
+int qc_eig_cold_sync(hipStream_t st, int n, double *dA, double *dX0, double *triwork, double *dV, double *dw, double *d_work, double *t1, double *t2,
+                     double *t3, double *t4, double *small, int *ctl, int *notconv = nullptr);
 void qc_permute_tensor(hipStream_t st, int n, const double *I, double c_direct, double c_exch, double *T);
 void qc_tensor_gemv(hipStream_t st, int n, const double *T1, const double *D1, const double *T2, const double *D2, double *G);
 void qc_axpby(hipStream_t st, int n, double a, const double *x, double b, const double *y, double *out);

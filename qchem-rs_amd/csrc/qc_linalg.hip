@@ -727,6 +727,29 @@ int qc_eig_refine_async(hipStream_t st, int n, double *dA, const double *dV0, do
     return hipGetLastError() == hipSuccess ? QC_OK : QC_ERR_HIP;
 }
 
+int qc_eig_cold_async(hipStream_t st, int n, double *dA, double *dX0, double *triwork, double *dV, double *dw, double *d_work, double *t1, double *t2,
+                      double *t3, double *t4, double *small, int *ctl, int npass) {
+    int rc = qc_eig_tridiag_start(st, n, dA, dX0, triwork);
+    if (rc != QC_OK) return rc;
+    return qc_eig_refine_async(st, n, dA, dX0, dV, dw, d_work, t1, t2, t3, t4, small, ctl, npass);
+}
+
+int qc_eig_cold_sync(hipStream_t st, int n, double *dA, double *dX0, double *triwork, double *dV, double *dw, double *d_work, double *t1, double *t2,
+                     double *t3, double *t4, double *small, int *ctl, int *notconv) {
+    static const bool force_jacobi = getenv("QC_EIG_JACOBI") != nullptr;      // A/B switch: the single-workgroup Jacobi kernels only
+    if (n < QC_TRI_MIN_N || force_jacobi) return qc_eig_device(st, n, dA, dV, dw, d_work, 40, 1e-9, notconv);
+    if (hipMemsetAsync(ctl, 0, 4 * sizeof(int), st) != hipSuccess) return QC_ERR_HIP;
+    int rc = qc_eig_cold_async(st, n, dA, dX0, triwork, dV, dw, d_work, t1, t2, t3, t4, small, ctl, 4);
+    if (rc != QC_OK) return rc;
+    int h[4] = {0, 0, 0, 0};
+    if (hipMemcpyAsync(h, ctl, 4 * sizeof(int), hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) return QC_ERR_HIP;
+    static const bool dbg = getenv("QC_EIG_DEBUG") != nullptr;
+    if (dbg) fprintf(stderr, "[eig cold n=%d] ctl %d %d %d passes %d\n", n, h[0], h[1], h[2], h[3]);
+    if (h[0] == 1) return QC_OK;
+    if (hipMemsetAsync(ctl, 0, 4 * sizeof(int), st) != hipSuccess) return QC_ERR_HIP;
+    return qc_eig_device(st, n, dA, dV, dw, d_work, 40, 1e-9, notconv);      // rotations: the start was not good enough
+}
+
 // DIIS coefficients on the device (diis.rs:40-51): B is kept slot-indexed in HBM, the new row <e_0, e_j> arrives in
 // `dots` (window order, newest first); Householder QR with the arithmetic of nalgebra's qr().solve(); one thread.
 struct QcDiisArgs { int m, minlen, maxlen; int slot[12]; };
