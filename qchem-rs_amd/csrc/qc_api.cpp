@@ -218,10 +218,11 @@ int roothaan_enqueue(qc_system *S, ScfWork &W, DeviceDiis &diis, const double *d
     // density still moves by more than 1e-3 per element - the tridiagonal path (start vectors from qc_eig_tridiag.hip + the same
     // refinement); matrices below QC_TRI_MIN_N go to the single-workgroup Jacobi kernels.  Outcome in ctl[4 spin].
     W.cold[spin] = false;
+    static const bool force_jacobi = getenv("QC_EIG_JACOBI") != nullptr;      // A/B switch: no tridiagonal path
     if (W.have_prev[spin] && W.mode[spin] == 0)
         rc = qc_eig_refine_async(st, n, W.Fps[spin].p, W.CpPrev[spin].p, W.CpNew[spin].p, dw_out, W.ework.p, W.t1.p, W.t2.p, W.t3.p, W.t4.p,
                                  W.small.p, W.ctl + 4 * spin, W.npass[spin]);
-    else if (n >= QC_TRI_MIN_N) {
+    else if (n >= QC_TRI_MIN_N && !force_jacobi) {
         W.cold[spin] = true;
         rc = qc_eig_cold_async(st, n, W.Fps[spin].p, W.X0.p, W.tri.p, W.CpNew[spin].p, dw_out, W.ework.p, W.t1.p, W.t2.p, W.t3.p, W.t4.p, W.small.p,
                                W.ctl + 4 * spin, 3);
@@ -591,6 +592,7 @@ static int scf_iterate(qc_scf_state *st, double *energy, double *rms_out) {
     hipStream_t sm = S->stream;
     const int nspin = st->uhf ? 2 : 1;
     int rc;
+    const double th0 = now_ms();
     QC_HIP_CHECK(hipEventRecord(st->ev0, sm));
     double *dE[2] = {nullptr, nullptr}, *dF[2] = {nullptr, nullptr};       // this pass's DIIS sample buffers (error, Fock matrix) per spin
     for (int s = 0; s < nspin; ++s) st->diis[s]->next_sample(&dE[s], &dF[s]);
@@ -647,12 +649,14 @@ static int scf_iterate(qc_scf_state *st, double *energy, double *rms_out) {
     for (int s = 0; s < nspin; ++s) if ((rc = density_and_scalars(s)) != QC_OK) return rc;
     if ((rc = publish_scalars()) != QC_OK) return rc;
     QC_HIP_CHECK(hipEventRecord(st->ev2, sm));
+    const double th1 = now_ms();
     QC_HIP_CHECK(wait_event(st->ev2));
+    const double th2 = now_ms();
     if (!ranks_agree()) { fprintf(stderr, "qchem_hip: rank %d: the ranks' SCF scalars differ - replicated state diverged\n", S->rank); return QC_ERR_RCCL; }
     if (h_ctl[8] != 0) return QC_DIIS_SINGULAR;                          // "DIIS failed", rhf.rs:73
     if (h_ctl[9] != 0) return QC_EIG_NOT_CONVERGED;
     static const bool dbg = getenv("QC_SCF_DEBUG") != nullptr;
-    if (dbg) fprintf(stderr, "[scf] ctl a: %d %d %d %d  b: %d %d %d %d  npass %d %d have_prev %d\n", h_ctl[0], h_ctl[1], h_ctl[2], h_ctl[3], h_ctl[4], h_ctl[5], h_ctl[6], h_ctl[7], W.npass[0], W.npass[1], (int)W.have_prev[0]);
+    if (dbg) fprintf(stderr, "[scf] ctl a: %d %d %d %d  b: %d %d %d %d  npass %d %d have_prev %d mode %d cold %d | host enqueue %.0f us, then waited %.0f us\n", h_ctl[0], h_ctl[1], h_ctl[2], h_ctl[3], h_ctl[4], h_ctl[5], h_ctl[6], h_ctl[7], W.npass[0], W.npass[1], (int)W.have_prev[0], W.mode[0], (int)W.cold[0], (th1 - th0) * 1e3, (th2 - th1) * 1e3);
     float ms_f = 0, ms_l = 0;
     (void)hipEventElapsedTime(&ms_f, st->ev0, st->ev1);
     (void)hipEventElapsedTime(&ms_l, st->ev1, st->ev2);
