@@ -224,6 +224,8 @@ int roothaan_enqueue(qc_system *S, ScfWork &W, DeviceDiis &diis, const double *d
                                  W.small.p, W.ctl + 4 * spin, W.npass[spin]);
     else if (n >= QC_TRI_MIN_N && !force_jacobi) {
         W.cold[spin] = true;
+        // (three refinement passes are enqueued: two finish most starts - the third is then five empty launches - but near-degenerate
+        // clusters of a nearly converged benzene need it, and running out of passes costs a Jacobi eigensolve)
         rc = qc_eig_cold_async(st, n, W.Fps[spin].p, W.X0.p, W.tri.p, W.CpNew[spin].p, dw_out, W.ework.p, W.t1.p, W.t2.p, W.t3.p, W.t4.p, W.small.p,
                                W.ctl + 4 * spin, 3);
     } else if (W.have_prev[spin])
@@ -353,6 +355,21 @@ int qc_eri_full(qc_system *S, double *out) {
 
 }  // extern "C"
 
+// Everything of a fixed-point build that depends on the densities alone, enqueued ahead of time (the SCF pass does this as soon as
+// its new density exists, so that it runs while the host turns around): zeroed accumulator planes, this build's fixed-point unit,
+// the UHF density sum.  qc_fock_build_device recognises the densities and then goes straight to the class kernels.
+int qc_fock_prepare_device(qc_system *S, const double *dDa, const double *dDb, bool uhf) {
+    S->prepared = false;
+    if (!S->accum_fx) return QC_OK;
+    const int n = S->nbasis;
+    const size_t nn = (size_t)n * n, plane = (size_t)QC_NREP * (uhf ? 2 : 1) * nn;
+    QC_HIP_CHECK(hipMemsetAsync(S->d_Gtmp, 0, 2 * plane * sizeof(double), S->stream));
+    qc_fx_scale(S->stream, n, dDa, uhf ? dDb : nullptr, S->imax, S->d_fxs);
+    if (uhf) qc_axpby(S->stream, n, 1.0, dDa, 1.0, dDb, S->d_Dj);
+    S->prepared = true; S->prep_Da = dDa; S->prep_Db = uhf ? dDb : nullptr;
+    return QC_OK;
+}
+
 int qc_fock_build_device(qc_system *S, const double *dDa, const double *dDb, double *dGa, double *dGb, bool uhf, int *twin_cache,
                          const double *dH, double *dFa, double *dFb, bool *f_done) {
     const int n = S->nbasis;
@@ -383,18 +400,22 @@ int qc_fock_build_device(qc_system *S, const double *dDa, const double *dDb, dou
     const int nspin = two ? 2 : 1;
     // accumulation phase: zero the replicas, density sum, every class kernel on the side streams, replica fold
     const size_t plane = (size_t)QC_NREP * nspin * nn;          // one accumulator plane: [replica][spin][n*n]
-    QC_HIP_CHECK(hipMemsetAsync(S->d_Gtmp, 0, (fx ? 2 : 1) * plane * sizeof(double), st));
+    const bool ready = fx && S->prepared && S->prep_Da == dDa && S->prep_Db == (uhf ? dDb : nullptr);   // qc_fock_prepare_device ran for these
+    S->prepared = false;
     QcFockArgs a{};
     a.nrep = QC_NREP; a.rep_stride = nspin * nn; a.fxs = fxs; a.fx_lo = plane;
-    if (fx) qc_fx_scale(st, n, dDa, uhf ? dDb : nullptr, S->imax, S->d_fxs);      // this build's fixed-point unit, from its densities
+    if (!ready) {
+        QC_HIP_CHECK(hipMemsetAsync(S->d_Gtmp, 0, (fx ? 2 : 1) * plane * sizeof(double), st));
+        if (fx) qc_fx_scale(st, n, dDa, uhf ? dDb : nullptr, S->imax, S->d_fxs);      // this build's fixed-point unit, from its densities
+    }
     if (uhf) {
-        qc_axpby(st, n, 1.0, dDa, 1.0, dDb, S->d_Dj);
+        if (!ready) qc_axpby(st, n, 1.0, dDa, 1.0, dDb, S->d_Dj);
         a.Dj = S->d_Dj; a.Dk0 = dDa; a.Dk1 = two ? dDb : nullptr; a.cK = 1.0;
     } else {
         a.Dj = dDa; a.Dk0 = dDa; a.Dk1 = nullptr; a.cK = 0.5;
     }
     a.G0 = S->d_Gtmp; a.G1 = S->d_Gtmp + nn;
-    int rc = qc_launch_fock_classes(S, a, nullptr);
+    int rc = qc_launch_fock_classes(S, a, nullptr, nullptr, ready);
     if (rc != QC_OK) return rc;
     qc_reduce_replicas(st, nspin * nn, QC_NREP, nspin * nn, S->d_Gtmp, S->d_Gred, fx, plane);
     if (S->comm) {
@@ -648,6 +669,9 @@ static int scf_iterate(qc_scf_state *st, double *energy, double *rms_out) {
     if (multi && nspin == 1) QC_HIP_CHECK(hipMemsetAsync(W.d_sync + 2, 0, 2 * sizeof(double), sm));       // unused spin slot
     for (int s = 0; s < nspin; ++s) if ((rc = density_and_scalars(s)) != QC_OK) return rc;
     if ((rc = publish_scalars()) != QC_OK) return rc;
+    // the next pass's build starts from Dn: its density-only preliminaries run while the host turns around
+    auto prepare_next = [&]() -> int { return st->stored ? QC_OK : qc_fock_prepare_device(S, st->Dn[0].p, st->uhf ? st->Dn[1].p : nullptr, st->uhf); };
+    if ((rc = prepare_next()) != QC_OK) return rc;
     QC_HIP_CHECK(hipEventRecord(st->ev2, sm));
     const double th1 = now_ms();
     QC_HIP_CHECK(wait_event(st->ev2));
@@ -674,6 +698,7 @@ static int scf_iterate(qc_scf_state *st, double *energy, double *rms_out) {
     }
     if (redo) {
         if ((rc = publish_scalars()) != QC_OK) return rc;
+        if ((rc = prepare_next()) != QC_OK) return rc;                    // (the density changed)
         QC_HIP_CHECK(hipEventRecord(st->ev2, sm));
         QC_HIP_CHECK(wait_event(st->ev2));
         if (!ranks_agree()) return QC_ERR_RCCL;
@@ -931,6 +956,7 @@ int qc_fock_profile(qc_system *S, const double *dD, double *dG, int reps, float 
     const size_t nn = (size_t)n * n;
     std::vector<float> acc(S->classes.size(), 0.f), one(S->classes.size(), 0.f);
     float tot = 0.f;
+    S->prepared = false;
     if (S->accum_fx) qc_fx_scale(S->stream, n, dD, nullptr, S->imax, S->d_fxs);
     Event ev0, ev1;
     if (ev0.create() != QC_OK || ev1.create() != QC_OK) return QC_ERR_HIP;
@@ -975,6 +1001,7 @@ int qc_fock_profile_tiers(qc_system *S, const double *dD, double *dG, int reps, 
     const int NU = QC_NUNITS;
     std::vector<float> acc(NU, 0.f), one(NU, 0.f);
     float tot = 0.f;
+    S->prepared = false;
     if (S->accum_fx) qc_fx_scale(S->stream, S->nbasis, dD, nullptr, S->imax, S->d_fxs);
     Event ev0, ev1;
     if (ev0.create() != QC_OK || ev1.create() != QC_OK) return QC_ERR_HIP;

@@ -226,7 +226,7 @@ static void tier_units(qc_system *S, std::vector<std::vector<int>> &units) {
 // replicas), so each goes to its own side stream forked from / joined to the handle's stream.
 // Profiling mode (class_ms != nullptr): one single-segment launch per class bucket, serial on the handle's stream with
 // a hipEvent between consecutive launches; unit_ms (optional, 14 entries) times the real tier launches the same way.
-int qc_launch_fock_classes(qc_system *S, const QcFockArgs &fa, float *class_ms, float *unit_ms) {
+int qc_launch_fock_classes(qc_system *S, const QcFockArgs &fa, float *class_ms, float *unit_ms, bool nofork) {
     const QcKernelArgs a = base_args(S, fa);
     std::vector<std::vector<int>> units;
     tier_units(S, units);
@@ -282,7 +282,9 @@ int qc_launch_fock_classes(qc_system *S, const QcFockArgs &fa, float *class_ms, 
     // first), join.  `ev` (tuning only): [0] fork, [1] join, [2 + 2u], [3 + 2u] around unit u.
     auto launch_concurrent = [&](hipEvent_t *ev, bool per_unit) -> int {
         if (ev) QC_HIP_CHECK(hipEventRecord(ev[0], S->stream));
-        QC_HIP_CHECK(hipEventRecord(S->ev_fork, S->stream));
+        // (nofork: everything the launches depend on has completed - the host waited for the handle's stream after it was enqueued)
+        const bool fork = ev != nullptr || !nofork;
+        if (fork) QC_HIP_CHECK(hipEventRecord(S->ev_fork, S->stream));
         // Issue order (the host needs ~8 us per launch, so it matters): inside a stream heaviest first; across streams the
         // first launch of every stream before any second one, streams in the order of their total load - the chain that
         // ends the build gets going first and no stream sits empty while another one's queue is being filled.
@@ -307,7 +309,7 @@ int qc_launch_fock_classes(qc_system *S, const QcFockArgs &fa, float *class_ms, 
         for (int u : order) {
             const int k = S->unit_stream[u];
             hipStream_t st = k == kmain ? S->stream : S->side[k];
-            if (!used[k]) { if (k != kmain) QC_HIP_CHECK(hipStreamWaitEvent(st, S->ev_fork, 0)); used[k] = true; }
+            if (!used[k]) { if (k != kmain && fork) QC_HIP_CHECK(hipStreamWaitEvent(st, S->ev_fork, 0)); used[k] = true; }
             if (ev && per_unit) QC_HIP_CHECK(hipEventRecord(ev[2 + 2 * u], st));
             int rc = launch_segments(S, u, segs_of(units[u]), st, a);
             if (rc != QC_OK) return rc;

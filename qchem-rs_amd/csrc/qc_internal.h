@@ -134,6 +134,10 @@ struct qc_system {
     std::vector<float> unit_ms;              // measured serial time of each launch unit (autotuned once per shard)
     std::vector<int> unit_stream;            // side stream of each launch unit (longest-processing-time assignment)
     std::vector<float> unit_weight;          // durations that order the launches (measured inside concurrent builds)
+    // accumulators zeroed, fixed-point scale (and the UHF density sum) already enqueued for a build from exactly these densities, and the host
+    // has waited for the handle's stream since (qc_fock_prepare_device): the build then starts its side streams without a fork
+    bool prepared = false;
+    const double *prep_Da = nullptr, *prep_Db = nullptr;
     int live_states = 0;                     // qc_scf_state objects that still point at this handle
     bool zombie = false;                     // qc_system_destroy was called while states were alive: the last qc_scf_end frees the handle
     int fock_mode = 0;                       // 0 direct (default), 1 stored tensor (the reference's own algorithm)
@@ -176,7 +180,8 @@ int qc_schwarz_device(qc_system *S);     // fills pairQ / imax from the (P|P) qu
 // fixed-point scale of a build from its densities: out[0] = 2^S, out[1] = 2^-S, S = min(QC_FX_MAXBITS, 60 - ceil(log2(4 imax sum|D|)))
 void qc_fx_scale(hipStream_t st, int n, const double *Da, const double *Db /*nullable*/, double imax, double *out);
 int qc_one_electron_device(qc_system *S, int which /* 0 S, 1 T, 2 V */, double *d_out);
-int qc_launch_fock_classes(qc_system *S, const QcFockArgs &a, float *class_ms /*nullable*/, float *unit_ms = nullptr /*nullable, 14*/);
+int qc_launch_fock_classes(qc_system *S, const QcFockArgs &a, float *class_ms /*nullable*/, float *unit_ms = nullptr /*nullable, 14*/, bool nofork = false);
+int qc_fock_prepare_device(qc_system *S, const double *dDa, const double *dDb, bool uhf);
 // (dH with dFa / dFb: the Fock matrices H + G are written by the closing kernel as well; *f_done tells whether both were)
 int qc_fock_build_device(qc_system *S, const double *dDa, const double *dDb, double *dGa, double *dGb, bool uhf, int *twin_cache = nullptr,
                          const double *dH = nullptr, double *dFa = nullptr, double *dFb = nullptr, bool *f_done = nullptr);

@@ -1,9 +1,18 @@
-# Round profile set: tests, default bench, rocprofv3 kernel stats of the same command, PMC passes (run via gpurun)
-set -e
+# Round profile set (run on the GPU box through gpurun): bash tools/run_profiles.sh <round tag, e.g. r02>
+# Per workload: (1) the bench line itself, (2) rocprofv3 --kernel-trace --stats of the same command, (3) PMC passes in their own
+# runs (separate --pmc passes, nothing but --kernel-trace beside them).  Under rocprofv3 the program goes directly after `--`.
+TAG=${1:-r02}
 R=$GRAFT_REPO_ROOT
-python -m pytest tests -m gpu -x -q 2>&1 | tail -3
-python bench.py > $R/gpurun_out/bench_default.json 2> $R/gpurun_out/bench_default.err
+O=$R/gpurun_out/prof_$TAG
+mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_default -- python $R/bench.py > $R/gpurun_out/bench_under_rocprof.json 2> $R/gpurun_out/bench_under_rocprof.err
-cd $R && bash tools/run_pmc.sh h2o_ccpvtz pmc_h2o > /dev/null
-echo done
+for W in h2o_ccpvtz c6h6_ccpvdz; do
+  ARGS="$R/bench.py --workload $W --no-extras --no-cpu-baseline --steps 20 --warmup 3"
+  python $ARGS > $O/${W}_bench.json 2> $O/${W}_bench.err || exit 1
+  rocprofv3 --kernel-trace --stats --output-format csv -d $O/${W}_trace -- python $ARGS > $O/${W}_bench_under_rocprof.json 2> $O/${W}_trace.err || exit 1
+  rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_ACTIVE_INST_VALU --output-format csv -d $O/${W}_sq -- python $ARGS > /dev/null 2> $O/${W}_sq.err || exit 1
+  rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA SQ_BUSY_CYCLES SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT --output-format csv -d $O/${W}_mfma -- python $ARGS > /dev/null 2> $O/${W}_mfma.err || exit 1
+  rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/${W}_fetch -- python $ARGS > /dev/null 2> $O/${W}_fetch.err || exit 1
+  rocprofv3 --kernel-trace --pmc WRITE_SIZE TCC_EA0_ATOMIC_sum --output-format csv -d $O/${W}_write -- python $ARGS > /dev/null 2> $O/${W}_write.err || exit 1
+  echo "$W done"
+done
