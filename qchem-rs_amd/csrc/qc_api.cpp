@@ -244,7 +244,8 @@ int roothaan_redo_eig(qc_system *S, ScfWork &W, double *dw_out, double *dC, int 
     if (W.cold[spin] && W.have_prev[spin])    // the tridiagonal start was not good enough: rotations in the basis of the previous vectors
         rc = qc_eig_device_warm(st, n, W.Fps[spin].p, W.CpPrev[spin].p, W.CpNew[spin].p, dw_out, W.ework.p, W.t1.p, W.t2.p, 40, 1e-9, W.ctl + 9);
     else if (W.cold[spin]) rc = qc_eig_device(st, n, W.Fps[spin].p, W.CpNew[spin].p, dw_out, W.ework.p, 40, 1e-9, W.ctl + 9);
-    else rc = qc_eig_device_refine(st, n, W.Fps[spin].p, W.CpPrev[spin].p, W.CpNew[spin].p, dw_out, W.ework.p, W.t1.p, W.t2.p, W.t3.p, W.t4.p, W.small.p, W.ctl + 9);
+    else     // the refinement from the previous vectors was not perturbative after all: the tridiagonal path (its own fallback: the Jacobi kernels)
+        rc = qc_eig_cold_sync(st, n, W.Fps[spin].p, W.X0.p, W.tri.p, W.CpNew[spin].p, dw_out, W.ework.p, W.t1.p, W.t2.p, W.t3.p, W.t4.p, W.small.p, W.ctl + 12, W.ctl + 9);
     if (rc != QC_OK) return rc;
     qc_gemm(st, n, n, n, 1.0, W.X.p, n, false, W.CpNew[spin].p, n, false, 0.0, dC, n);
     return QC_OK;
@@ -712,7 +713,8 @@ static int scf_iterate(qc_scf_state *st, double *energy, double *rms_out) {
         e_sum += W.h_scal[2 * s]; rms_sum += rms_s;
         // the refinement is perturbative: on its own once the density has nearly stopped moving, behind two Jacobi sweeps
         // while it still moves, not at all in the first wild passes
-        W.mode[s] = rms_s >= 1.0 ? 2 : (rms_s >= 1e-3 || redo) ? 1 : 0;
+        static const double warm_rms = getenv("QC_EIG_WARM_RMS") ? atof(getenv("QC_EIG_WARM_RMS")) : 1e-3;
+        W.mode[s] = rms_s >= 1.0 ? 2 : (rms_s >= warm_rms || redo) ? 1 : 0;
         std::swap(st->D[s].p, st->Dn[s].p);                              // D += 1.0 * dD
         std::swap(W.CpPrev[s].p, W.CpNew[s].p);
         W.have_prev[s] = true;

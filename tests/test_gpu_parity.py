@@ -202,6 +202,17 @@ def test_rccl_path_single_rank_communicator():
     assert np.abs(s.fock_rhf(D) - o.g_rhf(D, o.eri())).max() < TOL_INT * 10
     Ga, Gb = s.fock_uhf(D, 0.5 * D)
     assert np.abs(Ga - o.g_uhf(D, 0.5 * D, o.eri())).max() < TOL_INT * 10
+    # the whole multi-rank SCF pass (integer all-reduce of the hi / lo planes, pass scalars all-reduced as bit patterns and
+    # checked for agreement before any decision is taken) with that communicator: same result as without one, bit for bit
+    out = q.restricted_hartree_fock(s, q.HartreeFockConfig(100, 1e-10))
+    ref = o.rhf(100, 1e-10)
+    assert out is not None and abs(out.total_energy() - ref["total_energy"]) < TOL_E and out.iterations == ref["iterations"]
+    s1 = q.System(load_system("water", "STO-3G"))
+    out1 = q.restricted_hartree_fock(s1, q.HartreeFockConfig(100, 1e-10))
+    assert out1.electronic_energy == out.electronic_energy and out1.orbital_energies == out.orbital_energies
+    outu = q.unrestricted_hartree_fock(s, q.HartreeFockConfig(100, 1e-10))
+    assert outu is not None and abs(outu.total_energy() - ref["total_energy"]) < TOL_E
+    assert "rccl" in q.rccl_info().lower()
 
 
 def test_step_api_matches_driver():
