@@ -124,6 +124,13 @@ struct ScfWork {
     int n;
     DevBuf H, S, X, t1, t2, t3, t4, Fp, Cp, C, w, ework, Fd, scal, small, CpPrev[2], CpNew[2], Fps[2], X0, tri;
     bool have_prev[2] = {false, false};
+    // Open-shell runs (n_alpha != n_beta) use the rotation-based eigensolvers only.  Their SCF solutions of interest include
+    // saddles of the UHF functional that are kept by spatial symmetry alone (O2 triplet, BASELINE config 4): Jacobi rotations
+    // never mix functions that are not coupled, so symmetry-equivalent blocks of F' get bit-identical treatment and the
+    // iteration stays on the symmetric determinant exactly like the reference's fixed sequence of operations; Householder
+    // reflectors mix everything and seed the unstable direction with rounding noise (measured: the run then leaves the saddle
+    // for the 0.024 Eh lower broken-symmetry determinant after ~60 passes).
+    bool rotations_only = false;
     bool cold[2] = {false, false};         // this pass's eigensolve of the spin started from the tridiagonal path (no previous vectors involved)
     int npass[2] = {3, 3};                 // refinement passes enqueued per eigensolve (follows what the last one needed)
     int mode[2] = {2, 2};                  // eigensolve of the next pass: 0 refinement, 1 two Jacobi sweeps + refinement, 2 Jacobi
@@ -152,6 +159,7 @@ struct ScfWork {
 // sorted_eigs on device (utils.rs:20-36): Fp -> (Cp, w)
 int device_sorted_eigs(qc_system *S, ScfWork &W, double *dA, double *dV, double *dw) {
     // (set-up eigensolves: synchronous; ctl[12..15] scratch, ctl[9]: Jacobi sweeps ran out)
+    if (W.rotations_only) return qc_eig_device(S->stream, W.n, dA, dV, dw, W.ework.p, 40, 1e-9, W.ctl + 9);
     return qc_eig_cold_sync(S->stream, W.n, dA, W.X0.p, W.tri.p, dV, dw, W.ework.p, W.t1.p, W.t2.p, W.t3.p, W.t4.p, W.small.p, W.ctl + 12, W.ctl + 9);
 }
 
@@ -222,7 +230,7 @@ int roothaan_enqueue(qc_system *S, ScfWork &W, DeviceDiis &diis, const double *d
     if (W.have_prev[spin] && W.mode[spin] == 0)
         rc = qc_eig_refine_async(st, n, W.Fps[spin].p, W.CpPrev[spin].p, W.CpNew[spin].p, dw_out, W.ework.p, W.t1.p, W.t2.p, W.t3.p, W.t4.p,
                                  W.small.p, W.ctl + 4 * spin, W.npass[spin]);
-    else if (n >= QC_TRI_MIN_N && !force_jacobi) {
+    else if (n >= QC_TRI_MIN_N && !force_jacobi && !W.rotations_only) {
         W.cold[spin] = true;
         // (three refinement passes are enqueued: two finish most starts - the third is then five empty launches - but near-degenerate
         // clusters of a nearly converged benzene need it, and running out of passes costs a Jacobi eigensolve)
@@ -244,6 +252,8 @@ int roothaan_redo_eig(qc_system *S, ScfWork &W, double *dw_out, double *dC, int 
     if (W.cold[spin] && W.have_prev[spin])    // the tridiagonal start was not good enough: rotations in the basis of the previous vectors
         rc = qc_eig_device_warm(st, n, W.Fps[spin].p, W.CpPrev[spin].p, W.CpNew[spin].p, dw_out, W.ework.p, W.t1.p, W.t2.p, 40, 1e-9, W.ctl + 9);
     else if (W.cold[spin]) rc = qc_eig_device(st, n, W.Fps[spin].p, W.CpNew[spin].p, dw_out, W.ework.p, 40, 1e-9, W.ctl + 9);
+    else if (W.rotations_only)
+        rc = qc_eig_device_refine(st, n, W.Fps[spin].p, W.CpPrev[spin].p, W.CpNew[spin].p, dw_out, W.ework.p, W.t1.p, W.t2.p, W.t3.p, W.t4.p, W.small.p, W.ctl + 9);
     else     // the refinement from the previous vectors was not perturbative after all: the tridiagonal path (its own fallback: the Jacobi kernels)
         rc = qc_eig_cold_sync(st, n, W.Fps[spin].p, W.X0.p, W.tri.p, W.CpNew[spin].p, dw_out, W.ework.p, W.t1.p, W.t2.p, W.t3.p, W.t4.p, W.small.p, W.ctl + 12, W.ctl + 9);
     if (rc != QC_OK) return rc;
@@ -359,7 +369,7 @@ int qc_eri_full(qc_system *S, double *out) {
 // Everything of a fixed-point build that depends on the densities alone, enqueued ahead of time (the SCF pass does this as soon as
 // its new density exists, so that it runs while the host turns around): zeroed accumulator planes, this build's fixed-point unit,
 // the UHF density sum.  qc_fock_build_device recognises the densities and then goes straight to the class kernels.
-int qc_fock_prepare_device(qc_system *S, const double *dDa, const double *dDb, bool uhf) {
+int qc_fock_prepare_device(qc_system *S, const double *dDa, const double *dDb, bool uhf, const void *owner) {
     S->prepared = false;
     if (!S->accum_fx) return QC_OK;
     const int n = S->nbasis;
@@ -367,12 +377,12 @@ int qc_fock_prepare_device(qc_system *S, const double *dDa, const double *dDb, b
     QC_HIP_CHECK(hipMemsetAsync(S->d_Gtmp, 0, 2 * plane * sizeof(double), S->stream));
     qc_fx_scale(S->stream, n, dDa, uhf ? dDb : nullptr, S->imax, S->d_fxs);
     if (uhf) qc_axpby(S->stream, n, 1.0, dDa, 1.0, dDb, S->d_Dj);
-    S->prepared = true; S->prep_Da = dDa; S->prep_Db = uhf ? dDb : nullptr;
+    S->prepared = true; S->prep_Da = dDa; S->prep_Db = uhf ? dDb : nullptr; S->prep_owner = owner;
     return QC_OK;
 }
 
 int qc_fock_build_device(qc_system *S, const double *dDa, const double *dDb, double *dGa, double *dGb, bool uhf, int *twin_cache,
-                         const double *dH, double *dFa, double *dFb, bool *f_done) {
+                         const double *dH, double *dFa, double *dFb, bool *f_done, const void *owner) {
     const int n = S->nbasis;
     const size_t nn = (size_t)n * n;
     hipStream_t st = S->stream;
@@ -401,7 +411,7 @@ int qc_fock_build_device(qc_system *S, const double *dDa, const double *dDb, dou
     const int nspin = two ? 2 : 1;
     // accumulation phase: zero the replicas, density sum, every class kernel on the side streams, replica fold
     const size_t plane = (size_t)QC_NREP * nspin * nn;          // one accumulator plane: [replica][spin][n*n]
-    const bool ready = fx && S->prepared && S->prep_Da == dDa && S->prep_Db == (uhf ? dDb : nullptr);   // qc_fock_prepare_device ran for these
+    const bool ready = fx && S->prepared && owner != nullptr && S->prep_owner == owner && S->prep_Da == dDa && S->prep_Db == (uhf ? dDb : nullptr);   // qc_fock_prepare_device ran for these
     S->prepared = false;
     QcFockArgs a{};
     a.nrep = QC_NREP; a.rep_stride = nspin * nn; a.fxs = fxs; a.fx_lo = plane;
@@ -516,6 +526,7 @@ struct qc_scf_state {
     hipEvent_t ev0 = nullptr, ev1 = nullptr, ev2 = nullptr;
     double ms_fock = 0, ms_linalg = 0, ms_setup = 0;
     ~qc_scf_state() {
+        if (S && S->prep_owner == this) { S->prepared = false; S->prep_owner = nullptr; }
         delete diis[0]; delete diis[1];
         if (S && S->stream) (void)hipStreamSynchronize(S->stream);
         if (ev0) (void)hipEventDestroy(ev0);
@@ -548,6 +559,7 @@ static int scf_begin(qc_system *S, bool uhf, int n_alpha, int n_beta, qc_scf_sta
     if (uhf && (n_alpha > 0 || n_beta > 0)) { st->nocc[0] = n_alpha; st->nocc[1] = n_beta; }
     if (st->nocc[0] < 0 || st->nocc[1] < 0 || st->nocc[0] > n || st->nocc[1] > n) return QC_ERR_INVALID;
     const int nspin = uhf ? 2 : 1;
+    st->W.rotations_only = uhf && st->nocc[0] != st->nocc[1];
     if ((rc = st->W.init(n)) != QC_OK) return rc;
     for (int s = 0; s < nspin; ++s) if (st->D[s].alloc(nn) != QC_OK || st->Dn[s].alloc(nn) != QC_OK) return QC_ERR_HIP;
     if (st->G.alloc(nspin * nn) != QC_OK || st->Cs.alloc(nspin * nn) != QC_OK || st->ws.alloc(nspin * n) != QC_OK) return QC_ERR_HIP;
@@ -631,7 +643,7 @@ static int scf_iterate(qc_scf_state *st, double *energy, double *rms_out) {
             qc_tensor_gemv(sm, n, st->T4.p, st->D[0].p, nullptr, nullptr, st->G.p);   // rhf.rs:152-167
         }
     } else if ((rc = qc_fock_build_device(S, st->D[0].p, st->uhf ? st->D[1].p : nullptr, st->G.p, st->uhf ? st->G.p + nn : nullptr, st->uhf,
-                                          &st->twin, W.H.p, dF[0], dF[1], &have_F)) != QC_OK) return rc;
+                                          &st->twin, W.H.p, dF[0], dF[1], &have_F, st)) != QC_OK) return rc;
     // (Enqueueing the *next* pass's build here, ahead of the wait below, was tried: its side-stream launches then sit
     // behind unsignalled barriers while the main queue still works, and with 8 hardware queues on 4 pipes the blocked
     // queues stall their pipe neighbours - 1.6 ms per pass instead of 0.6.)
@@ -671,7 +683,7 @@ static int scf_iterate(qc_scf_state *st, double *energy, double *rms_out) {
     for (int s = 0; s < nspin; ++s) if ((rc = density_and_scalars(s)) != QC_OK) return rc;
     if ((rc = publish_scalars()) != QC_OK) return rc;
     // the next pass's build starts from Dn: its density-only preliminaries run while the host turns around
-    auto prepare_next = [&]() -> int { return st->stored ? QC_OK : qc_fock_prepare_device(S, st->Dn[0].p, st->uhf ? st->Dn[1].p : nullptr, st->uhf); };
+    auto prepare_next = [&]() -> int { return st->stored ? QC_OK : qc_fock_prepare_device(S, st->Dn[0].p, st->uhf ? st->Dn[1].p : nullptr, st->uhf, st); };
     if ((rc = prepare_next()) != QC_OK) return rc;
     QC_HIP_CHECK(hipEventRecord(st->ev2, sm));
     const double th1 = now_ms();

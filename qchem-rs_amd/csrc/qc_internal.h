@@ -138,6 +138,7 @@ struct qc_system {
     // has waited for the handle's stream since (qc_fock_prepare_device): the build then starts its side streams without a fork
     bool prepared = false;
     const double *prep_Da = nullptr, *prep_Db = nullptr;
+    const void *prep_owner = nullptr;        // the qc_scf_state that enqueued them (addresses alone could be recycled by a later state)
     int live_states = 0;                     // qc_scf_state objects that still point at this handle
     bool zombie = false;                     // qc_system_destroy was called while states were alive: the last qc_scf_end frees the handle
     int fock_mode = 0;                       // 0 direct (default), 1 stored tensor (the reference's own algorithm)
@@ -181,10 +182,10 @@ int qc_schwarz_device(qc_system *S);     // fills pairQ / imax from the (P|P) qu
 void qc_fx_scale(hipStream_t st, int n, const double *Da, const double *Db /*nullable*/, double imax, double *out);
 int qc_one_electron_device(qc_system *S, int which /* 0 S, 1 T, 2 V */, double *d_out);
 int qc_launch_fock_classes(qc_system *S, const QcFockArgs &a, float *class_ms /*nullable*/, float *unit_ms = nullptr /*nullable, 14*/, bool nofork = false);
-int qc_fock_prepare_device(qc_system *S, const double *dDa, const double *dDb, bool uhf);
+int qc_fock_prepare_device(qc_system *S, const double *dDa, const double *dDb, bool uhf, const void *owner);
 // (dH with dFa / dFb: the Fock matrices H + G are written by the closing kernel as well; *f_done tells whether both were)
 int qc_fock_build_device(qc_system *S, const double *dDa, const double *dDb, double *dGa, double *dGb, bool uhf, int *twin_cache = nullptr,
-                         const double *dH = nullptr, double *dFa = nullptr, double *dFb = nullptr, bool *f_done = nullptr);
+                         const double *dH = nullptr, double *dFa = nullptr, double *dFb = nullptr, bool *f_done = nullptr, const void *owner = nullptr);
 
 // dense linear algebra on the handle's stream (all row-major n x n, device pointers)
 void qc_gemm(hipStream_t st, int m, int n, int k, double alpha, const double *A, int lda, bool ta, const double *B,

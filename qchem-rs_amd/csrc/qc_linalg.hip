@@ -27,17 +27,20 @@ __device__ __forceinline__ void qc_gemm_tile(const QcGemmArgs &g) {
     const bool aok = ai < m, bok = bj < n;
     const size_t a_i = g.ta ? (size_t)ai : (size_t)ai * g.lda, a_k = g.ta ? (size_t)g.lda : 1;
     const size_t b_j = g.tb ? (size_t)bj * g.ldb : (size_t)bj, b_k = g.tb ? 1 : (size_t)g.ldb;
+    // The operands of 64 k-values (4 x 4 MFMA steps) are requested before the first MFMA of the chunk: a tile is a chain of L2
+    // round trips otherwise, one per 16 k-values.
     double4_t acc = {0.0, 0.0, 0.0, 0.0};
-    for (int k0 = 0; k0 < k; k0 += 16) {
-        double av[4], bv[4];
+    for (int k0 = 0; k0 < k; k0 += 64) {
+        double av[16], bv[16];
 #pragma unroll
-        for (int s = 0; s < 4; ++s) {
+        for (int s = 0; s < 16; ++s) {
             const int kk = k0 + 4 * s + lk;
             av[s] = (aok && kk < k) ? A[a_i + kk * a_k] : 0.0;
             bv[s] = (bok && kk < k) ? B[b_j + kk * b_k] : 0.0;
         }
 #pragma unroll
-        for (int s = 0; s < 4; ++s) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[s], bv[s], acc, 0, 0, 0);
+        for (int s = 0; s < 16; ++s)
+            if (k0 + 4 * s < k) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[s], bv[s], acc, 0, 0, 0);     // (uniform)
     }
     if (bok) {
 #pragma unroll
