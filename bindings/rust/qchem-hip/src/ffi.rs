@@ -57,6 +57,14 @@ extern "C" {
     pub fn qc_scf_spin_square(st: *mut QcScfState, s2: *mut f64) -> c_int;
     pub fn qc_scf_end(st: *mut QcScfState);
     pub fn qc_set_fock_mode(sys: *mut QcSystem, mode: c_int) -> c_int;
+    /// 1 (default): exact, order-independent accumulation of G; 0: f64 atomics.
+    pub fn qc_set_accumulation(sys: *mut QcSystem, fixed_point: c_int) -> c_int;
+    /// Schwarz threshold of the work lists (default 1e-12; 0 = every quartet, uhf.rs:49-50).
+    pub fn qc_set_schwarz(sys: *mut QcSystem, tau: f64) -> c_int;
+    /// 0 overlap, 1 core Hamiltonian, 2 X = S^-1/2 of a state (rhf.rs:41,48,124-131).
+    pub fn qc_scf_matrix(st: *mut QcScfState, which: c_int, out: *mut f64) -> c_int;
+    /// "<path> version <code>" of the RCCL copy bound at run time.
+    pub fn qc_rccl_info(buf: *mut std::os::raw::c_char, len: usize) -> c_int;
     pub fn qc_comm_unique_id(id: *mut u8) -> c_int;
     pub fn qc_comm_init(sys: *mut QcSystem, id: *const u8, rank: c_int, nranks: c_int) -> c_int;
     pub fn qc_set_stream(sys: *mut QcSystem, hip_stream: *mut c_void) -> c_int;
