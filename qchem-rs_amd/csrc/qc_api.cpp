@@ -697,6 +697,7 @@ static int scf_iterate(qc_scf_state *st, double *energy, double *rms_out) {
     float ms_f = 0, ms_l = 0;
     (void)hipEventElapsedTime(&ms_f, st->ev0, st->ev1);
     (void)hipEventElapsedTime(&ms_l, st->ev1, st->ev2);
+    if (!st->stored && !S->comm) qc_fock_feedback(S, ms_f);              // (multi-rank: every rank keeps its tuner's choice)
     bool redo = false;
     for (int s = 0; s < nspin; ++s) {
         const bool refined = W.cold[s] || (W.have_prev[s] && W.mode[s] == 0);       // the eigensolve reported through the control word

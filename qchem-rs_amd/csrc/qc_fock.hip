@@ -66,6 +66,7 @@ static int upload_slots(qc_system *S) {
 
 int qc_device_reshard(qc_system *S) {
     S->unit_ms.clear(); S->unit_stream.clear();
+    S->cand_stream.clear(); S->cand_weight.clear(); S->cand_ms.clear(); S->cand_n.clear(); S->cand_frozen = false; S->cand_skip = false; S->cand_cur = 0;
     qc_build_shards(S);
     if (!S->device_ready) return QC_OK;
     return upload_slots(S);
@@ -353,7 +354,8 @@ int qc_launch_fock_classes(qc_system *S, const QcFockArgs &fa, float *class_ms, 
             std::vector<float> dur(units.size(), 0.f);
             for (size_t u = 0; u < units.size(); ++u)
                 if (!units[u].empty()) QC_HIP_CHECK(hipEventElapsedTime(&dur[u], ev[2 + 2 * u], ev[3 + 2 * u]));
-            cand.push_back(S->unit_stream); weight.push_back(S->unit_weight); total.push_back(tot);
+            // (a candidate keeps the durations measured in ITS build: they order the launches - longest chain first - when it is replayed)
+            cand.push_back(S->unit_stream); weight.push_back(dur); total.push_back(tot);
             if (dbg) {
                 fprintf(stderr, "[tune] cand %d total %.3f ms:", round, tot);
                 for (size_t u = 0; u < units.size(); ++u) if (!units[u].empty()) fprintf(stderr, " u%zu@s%d %.0f/%.0f", u, S->unit_stream[u], dur[u] * 1e3, S->unit_ms[u] * 1e3);
@@ -369,6 +371,7 @@ int qc_launch_fock_classes(qc_system *S, const QcFockArgs &fa, float *class_ms, 
         std::sort(rank.begin(), rank.end(), [&](size_t x, size_t y) { return total[x] < total[y]; });
         size_t best = rank[0];
         float best_t = 1e30f;
+        S->cand_stream.clear(); S->cand_weight.clear(); S->cand_ms.clear(); S->cand_n.clear();
         for (size_t r = 0; r < std::min<size_t>(3, rank.size()); ++r) {
             S->unit_stream = cand[rank[r]]; S->unit_weight = weight[rank[r]];
             float tmin = 1e30f;
@@ -382,11 +385,40 @@ int qc_launch_fock_classes(qc_system *S, const QcFockArgs &fa, float *class_ms, 
             }
             if (dbg) fprintf(stderr, "[tune] final cand %zu: %.3f ms\n", rank[r], tmin);
             if (tmin < best_t) { best_t = tmin; best = rank[r]; }
+            // the finalists stay available: inside SCF runs the passes themselves decide between them (qc_fock_feedback)
+            S->cand_stream.push_back(cand[rank[r]]); S->cand_weight.push_back(weight[rank[r]]); S->cand_ms.push_back(0.0); S->cand_n.push_back(0);
+            if (rank[r] == best) S->cand_cur = (int)S->cand_stream.size() - 1;
         }
         S->unit_stream = cand[best]; S->unit_weight = weight[best];
+        S->cand_skip = true;                             // (the time of THIS build contains the tuning)
         if (fa.G0) QC_HIP_CHECK(hipMemsetAsync(fa.G0, 0, gbytes, S->stream));
     }
     return launch_concurrent(nullptr, false);
+}
+
+// Online choice between the tuner's finalists.  The tuning builds run back to back; inside an SCF pass a build follows ~20 small
+// linear-algebra kernels and a host turn-around, and which finalist is fastest THERE differed from run to run by up to 20 % of the
+// build (0.31-0.38 ms on H2O/cc-pVTZ).  The SCF pass reports the hipEvent time of each of its builds: every finalist gets
+// QC_ONLINE_SAMPLES of them in turn (the first after a switch is not counted), then the best mean stays.  Stream assignment does not
+// change results (integer accumulation), only time.
+constexpr int QC_ONLINE_SAMPLES = 3;
+void qc_fock_feedback(qc_system *S, float build_ms) {
+    const int nc = (int)S->cand_stream.size();
+    if (nc < 2 || S->cand_frozen || S->unit_stream.empty()) return;
+    const int c = S->cand_cur;
+    if (S->cand_skip) S->cand_skip = false;            // first build after a switch: not counted
+    else { S->cand_ms[c] += build_ms; S->cand_n[c] += 1; }
+    if (S->cand_n[c] < QC_ONLINE_SAMPLES) return;
+    int next = -1;
+    for (int k = 0; k < nc; ++k) if (S->cand_n[k] < QC_ONLINE_SAMPLES) { next = k; break; }
+    if (next < 0) {                                     // every finalist sampled: keep the best
+        next = 0;
+        for (int k = 1; k < nc; ++k) if (S->cand_ms[k] / S->cand_n[k] < S->cand_ms[next] / S->cand_n[next]) next = k;
+        S->cand_frozen = true;
+        static const bool dbg = getenv("QC_TUNE_DEBUG") != nullptr;
+        if (dbg) { fprintf(stderr, "[tune] online:"); for (int k = 0; k < nc; ++k) fprintf(stderr, " cand %d %.3f ms", k, S->cand_ms[k] / S->cand_n[k]); fprintf(stderr, " -> %d\n", next); }
+    }
+    if (next != c) { S->cand_cur = next; S->unit_stream = S->cand_stream[next]; S->unit_weight = S->cand_weight[next]; S->cand_skip = true; }
 }
 
 // Schwarz pass (the reference's own TODO at uhf.rs:49-50): the (P|P) quartet of every stored pair through the

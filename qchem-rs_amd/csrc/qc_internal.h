@@ -134,6 +134,13 @@ struct qc_system {
     std::vector<float> unit_ms;              // measured serial time of each launch unit (autotuned once per shard)
     std::vector<int> unit_stream;            // side stream of each launch unit (longest-processing-time assignment)
     std::vector<float> unit_weight;          // durations that order the launches (measured inside concurrent builds)
+    // the tuner's finalists and their build times as seen by SCF passes (qc_fock_feedback)
+    std::vector<std::vector<int>> cand_stream;
+    std::vector<std::vector<float>> cand_weight;
+    std::vector<double> cand_ms;
+    std::vector<int> cand_n;
+    int cand_cur = 0;
+    bool cand_frozen = false, cand_skip = false;
     // accumulators zeroed, fixed-point scale (and the UHF density sum) already enqueued for a build from exactly these densities, and the host
     // has waited for the handle's stream since (qc_fock_prepare_device): the build then starts its side streams without a fork
     bool prepared = false;
@@ -182,6 +189,7 @@ int qc_schwarz_device(qc_system *S);     // fills pairQ / imax from the (P|P) qu
 void qc_fx_scale(hipStream_t st, int n, const double *Da, const double *Db /*nullable*/, double imax, double *out);
 int qc_one_electron_device(qc_system *S, int which /* 0 S, 1 T, 2 V */, double *d_out);
 int qc_launch_fock_classes(qc_system *S, const QcFockArgs &a, float *class_ms /*nullable*/, float *unit_ms = nullptr /*nullable, 14*/, bool nofork = false);
+void qc_fock_feedback(qc_system *S, float build_ms);      // hipEvent time of a build inside an SCF pass (no-op once the choice is made)
 int qc_fock_prepare_device(qc_system *S, const double *dDa, const double *dDb, bool uhf, const void *owner);
 // (dH with dFa / dFb: the Fock matrices H + G are written by the closing kernel as well; *f_done tells whether both were)
 int qc_fock_build_device(qc_system *S, const double *dDa, const double *dDb, double *dGa, double *dGb, bool uhf, int *twin_cache = nullptr,
