@@ -16,6 +16,7 @@
  *     reference's `expect("DIIS failed")` panic), or a negative error.  Nothing throws across the boundary.
  *   - a qc_system handle owns its HIP stream and device buffers; it is not thread-safe; distinct handles may be used
  *     from distinct threads.  No global mutable state.
+ *   - nothing is printed unless QC_LOG is set: then the drivers write the reference's per-iteration log line (rhf.rs:90-92) to stderr.
  *   - there is NO CPU fallback: any call that needs the GPU returns QC_ERR_NO_DEVICE when no gfx950 device is visible.
  *     Creating a handle, querying sizes, the one-electron matrices and the work plan are host-only and work anywhere.
  */

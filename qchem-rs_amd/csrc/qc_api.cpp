@@ -755,6 +755,9 @@ static int scf_run(qc_system *S, const qc_hf_config *cfg, qc_hf_output *out, boo
         double e = 0.0, rms = 0.0;
         rc = scf_iterate(st, &e, &rms);
         if (rc != QC_OK) { status = rc; break; }
+        // the reference's per-iteration log line (rhf.rs:90-92, uhf.rs:138; `log::info!`, silent unless a logger is installed): QC_LOG=1
+        static const bool log_info = getenv("QC_LOG") != nullptr;
+        if (log_info) fprintf(stderr, "iteration %-4zu - electronic energy %1.4f. density rms %1.4e\n", it, e, rms);
         const bool conv = uhf ? (rms / 2.0 < cfg->epsilon) : (rms < cfg->epsilon);   // uhf.rs:139 / rhf.rs:94
         if (conv) {
             out->electronic_energy = e; out->iterations = it;
