@@ -62,6 +62,9 @@ def lib():
         L.orc_uhf.argtypes = [C.c_void_p, C.c_long, C.c_double, C.c_int, C.c_int, C.c_void_p, _dp, _dp,
                               C.POINTER(_Result), C.c_void_p, C.c_void_p]
         L.orc_uhf.restype = C.c_int
+        L.orc_uhf_traced.argtypes = [C.c_void_p, C.c_long, C.c_double, C.c_int, C.c_int, C.c_void_p, _dp, _dp,
+                                     C.POINTER(_Result), C.c_void_p, C.c_void_p, C.POINTER(C.c_long), C.c_void_p, C.c_void_p]
+        L.orc_uhf_traced.restype = C.c_int
         _lib = L
     return _lib
 
@@ -153,13 +156,16 @@ class Oracle:
             out["trace_energy"] = te[:tl.value].copy(); out["trace_rms"] = tr[:tl.value].copy()
         return out
 
-    def uhf(self, max_iterations=100, epsilon=1e-6, n_alpha=-1, n_beta=-1, eri=None):
+    def uhf(self, max_iterations=100, epsilon=1e-6, n_alpha=-1, n_beta=-1, eri=None, trace=False):
         n = self.n
         wa, wb = np.zeros(n), np.zeros(n); res = _Result(); Da, Db = np.zeros((n, n)), np.zeros((n, n))
         ep = None if eri is None else np.ascontiguousarray(eri).ctypes.data_as(C.c_void_p)
-        st = lib().orc_uhf(self.h, max_iterations, epsilon, n_alpha, n_beta, ep, wa, wb, C.byref(res),
-                           Da.ctypes.data_as(C.c_void_p), Db.ctypes.data_as(C.c_void_p))
-        return dict(status=st, electronic_energy=res.electronic_energy, nuclear_repulsion=res.nuclear_repulsion,
+        tl = C.c_long(0); te = np.zeros(max_iterations + 2); tr = np.zeros(max_iterations + 2)
+        st = lib().orc_uhf_traced(self.h, max_iterations, epsilon, n_alpha, n_beta, ep, wa, wb, C.byref(res),
+                                  Da.ctypes.data_as(C.c_void_p), Db.ctypes.data_as(C.c_void_p), C.byref(tl),
+                                  te.ctypes.data_as(C.c_void_p), tr.ctypes.data_as(C.c_void_p))
+        extra = dict(trace_energy=te[:tl.value].copy(), trace_rms=tr[:tl.value].copy()) if trace else {}
+        return dict(**extra, status=st, electronic_energy=res.electronic_energy, nuclear_repulsion=res.nuclear_repulsion,
                     iterations=res.iterations, orbital_energies_alpha=wa, orbital_energies_beta=wb,
                     density_alpha=Da, density_beta=Db,
                     total_energy=res.electronic_energy + res.nuclear_repulsion)

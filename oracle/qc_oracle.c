@@ -844,8 +844,9 @@ int orc_rhf(const Basis *B, long max_iterations, double epsilon, const double *e
 
 /* unrestricted_hartree_fock (uhf.rs:36-167).  n_alpha/n_beta < 0 => the reference's rule N/2 (uhf.rs:43-45);
  * other values are this build's extension and have no reference counterpart. */
-int orc_uhf(const Basis *B, long max_iterations, double epsilon, int n_alpha, int n_beta, const double *eri_in,
-            double *eps_a, double *eps_b, OrcResult *res, double *Da_out, double *Db_out) {
+int orc_uhf_traced(const Basis *B, long max_iterations, double epsilon, int n_alpha, int n_beta, const double *eri_in,
+                   double *eps_a, double *eps_b, OrcResult *res, double *Da_out, double *Db_out,
+                   long *trace_len, double *trace_energy, double *trace_rms) {
     int n = B->nbasis, nn = n * n;
     int nelec = 0; for (int a = 0; a < B->natoms; a++) nelec += B->Z[a];
     if (n_alpha < 0) n_alpha = nelec / 2;
@@ -870,6 +871,7 @@ int orc_uhf(const Basis *B, long max_iterations, double epsilon, int n_alpha, in
     huckel_density(n, H, S, X, n_beta, 1.0, D[1]);
     Diis *diis[2] = { diis_new(2, 8, n), diis_new(2, 8, n) };
     res->status = 1; res->iterations = 0; res->electronic_energy = 0.0;
+    if (trace_len) *trace_len = 0;
     for (long it = 0; it <= max_iterations && res->status == 1; it++) {
         for (int s = 0; s < 2; s++) {
             orc_g_uhf(n, D[s], D[1 - s], eri_in, G[s]);
@@ -890,6 +892,10 @@ int orc_uhf(const Basis *B, long max_iterations, double epsilon, int n_alpha, in
             rms_sum += sqrt(rms / n);
         }
         double density_rms = rms_sum / 2.0;
+        if (trace_len) {   /* per pass: the energy expression of uhf.rs:145-153 on the new densities and the rms uhf.rs:137 compares */
+            trace_energy[*trace_len] = energy_half_trace(n, D[0], H, G[0]) + energy_half_trace(n, D[1], H, G[1]);
+            trace_rms[*trace_len] = density_rms; (*trace_len)++;
+        }
         if (density_rms / 2.0 < epsilon) {
             res->electronic_energy = energy_half_trace(n, D[0], H, G[0]) + energy_half_trace(n, D[1], H, G[1]);
             res->iterations = it; res->status = 0;
@@ -902,6 +908,11 @@ int orc_uhf(const Basis *B, long max_iterations, double epsilon, int n_alpha, in
     for (int s = 0; s < 2; s++) { free(D[s]); free(G[s]); free(C[s]); free(w[s]); }
     free(S); free(Tk); free(Vn); free(H); free(X); free(F); free(Er); free(Fd); free(t); free(Fp); free(Cp); free(Dn); free(I);
     return res->status;
+}
+
+int orc_uhf(const Basis *B, long max_iterations, double epsilon, int n_alpha, int n_beta, const double *eri_in,
+            double *eps_a, double *eps_b, OrcResult *res, double *Da_out, double *Db_out) {
+    return orc_uhf_traced(B, max_iterations, epsilon, n_alpha, n_beta, eri_in, eps_a, eps_b, res, Da_out, Db_out, NULL, NULL, NULL);
 }
 
 /* Start-up pieces exposed so tests can compare the GPU path stage by stage */
