@@ -230,7 +230,7 @@ int roothaan_enqueue(qc_system *S, ScfWork &W, DeviceDiis &diis, const double *d
     if (W.have_prev[spin] && W.mode[spin] == 0)
         rc = qc_eig_refine_async(st, n, W.Fps[spin].p, W.CpPrev[spin].p, W.CpNew[spin].p, dw_out, W.ework.p, W.t1.p, W.t2.p, W.t3.p, W.t4.p,
                                  W.small.p, W.ctl + 4 * spin, W.npass[spin]);
-    else if (n >= QC_TRI_MIN_N && !force_jacobi && !W.rotations_only) {
+    else if (qc_tri_ok(n) && !force_jacobi && !W.rotations_only) {
         W.cold[spin] = true;
         // (three refinement passes are enqueued: two finish most starts - the third is then five empty launches - but near-degenerate
         // clusters of a nearly converged benzene need it, and running out of passes costs a Jacobi eigensolve)

@@ -451,7 +451,7 @@ size_t qc_eig_tridiag_work_doubles(int n) { return 2 * (size_t)n * n + 8 * (size
 // Approximate eigenvectors (columns of dX0, ascending eigenvalues, orthonormal to ~1e-6 for generic matrices) of the symmetric dA,
 // which is left intact.  work: qc_eig_tridiag_work_doubles(n) doubles.  Asynchronous on `st`.
 int qc_eig_tridiag_start(hipStream_t st, int n, const double *dA, double *dX0, double *work) {
-    if (n < QC_TRI_MIN_N || n > 64 * 8) return QC_ERR_UNSUPPORTED;
+    if (!qc_tri_ok(n)) return QC_ERR_UNSUPPORTED;
     double *Vr = work, *Zg = work + (size_t)n * n, *tri = Zg + (size_t)n * n, *evn = tri + 4 * (size_t)n;
     static std::atomic<bool> raised{false};
     if (!raised.load(std::memory_order_acquire)) {

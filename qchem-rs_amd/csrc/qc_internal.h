@@ -213,7 +213,8 @@ int qc_eig_device_refine(hipStream_t st, int n, double *dA, const double *dV0, d
 // Tridiagonalisation-based start vectors (qc_eig_tridiag.hip) + refinement: the cold eigensolve.  ctl[0..3] zero on entry; outcome in
 // ctl[0] (1 done: dV / dw hold the sorted eigenpairs; 2: the start was not good enough - repeat with qc_eig_device).  dX0: n*n scratch,
 // triwork: qc_eig_tridiag_work_doubles(n).  Smaller matrices (n < QC_TRI_MIN_N) are for the single-workgroup Jacobi kernels.
-constexpr int QC_TRI_MIN_N = 24;
+constexpr int QC_TRI_MIN_N = 24, QC_TRI_MAX_N = 512;
+inline bool qc_tri_ok(int n) { return n >= QC_TRI_MIN_N && n <= QC_TRI_MAX_N; }
 size_t qc_eig_tridiag_work_doubles(int n);
 int qc_eig_tridiag_start(hipStream_t st, int n, const double *dA, double *dX0, double *work);
 int qc_eig_cold_async(hipStream_t st, int n, double *dA, double *dX0, double *triwork, double *dV, double *dw, double *d_work, double *t1, double *t2,

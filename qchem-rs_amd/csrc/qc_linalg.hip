@@ -740,7 +740,7 @@ int qc_eig_cold_async(hipStream_t st, int n, double *dA, double *dX0, double *tr
 int qc_eig_cold_sync(hipStream_t st, int n, double *dA, double *dX0, double *triwork, double *dV, double *dw, double *d_work, double *t1, double *t2,
                      double *t3, double *t4, double *small, int *ctl, int *notconv) {
     static const bool force_jacobi = getenv("QC_EIG_JACOBI") != nullptr;      // A/B switch: the single-workgroup Jacobi kernels only
-    if (n < QC_TRI_MIN_N || force_jacobi) return qc_eig_device(st, n, dA, dV, dw, d_work, 40, 1e-9, notconv);
+    if (!qc_tri_ok(n) || force_jacobi) return qc_eig_device(st, n, dA, dV, dw, d_work, 40, 1e-9, notconv);
     if (hipMemsetAsync(ctl, 0, 4 * sizeof(int), st) != hipSuccess) return QC_ERR_HIP;
     int rc = qc_eig_cold_async(st, n, dA, dX0, triwork, dV, dw, d_work, t1, t2, t3, t4, small, ctl, 4);
     if (rc != QC_OK) return rc;
