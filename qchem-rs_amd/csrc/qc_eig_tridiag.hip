@@ -297,7 +297,9 @@ __global__ __launch_bounds__(TRI_THREADS) void qc_tridiag_reg_kernel(int n, cons
 }
 
 // number of eigenvalues of T below x: sign changes of the Sturm sequence p_i = (d_i - x) p_{i-1} - e_{i-1}^2 p_{i-2}, without divisions.
-// d / e2 are read with wave-uniform indices from global memory (scalar loads, eight steps at a time); rescaled every 8 steps.
+// d / e2 sit in LDS and are read with wave-uniform addresses (broadcast reads, eight steps requested at a time: as scalar loads from
+// global memory every chunk waited ~500 cycles for its operands - SMEM returns out of order, so nothing could be kept in flight
+// across the wait - 720 cycles per chunk against 300 now); rescaled every 8 steps.
 __device__ __forceinline__ int sturm_count(int n, const double *__restrict__ d, const double *__restrict__ e2, double x) {
     double q = 1.0, p = d[0] - x;
     int cnt = p < 0.0 ? 1 : 0;
@@ -333,12 +335,14 @@ __device__ __forceinline__ int sturm_count(int n, const double *__restrict__ d, 
 //   r = argmin |D+_k + D-_k - (d_k - lambda)|; then z_r = 1 with the downward (lane 0) and upward (lane 1) one-term recurrences.
 constexpr int TE_WAVES = 4;
 __global__ __launch_bounds__(TE_WAVES * 64) void qc_tri_eig_kernel(int n, const double *__restrict__ tri, double *__restrict__ Zg, double *__restrict__ out) {
-    extern __shared__ double sm[];                       // per wave: D+ (n) | D- (n)
+    extern __shared__ double sm[];                       // d | e | e^2 (n each, shared by the workgroup), then per wave: D+ (n) | D- (n)
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int j = blockIdx.x * TE_WAVES + wave;
+    double *d = sm, *e = sm + n, *e2 = sm + 2 * n;
+    for (int i = threadIdx.x; i < n; i += TE_WAVES * 64) { d[i] = tri[i]; e[i] = tri[n + i]; e2[i] = tri[3 * n + i]; }
+    __syncthreads();
     if (j >= n) return;
-    double *Dp = sm + (size_t)wave * 2 * n, *Dm = Dp + n;
-    const double *__restrict__ d = tri, *__restrict__ e = tri + n, *__restrict__ e2 = tri + 3 * n;
+    double *Dp = sm + 3 * n + (size_t)wave * 2 * n, *Dm = Dp + n;
     // Gershgorin interval
     double lo = 1e300, hi = -1e300;
     for (int i = lane; i < n; i += 64) {
@@ -349,7 +353,10 @@ __global__ __launch_bounds__(TE_WAVES * 64) void qc_tri_eig_kernel(int n, const 
     for (int o = 32; o > 0; o >>= 1) { lo = fmin(lo, __shfl_xor(lo, o, 64)); hi = fmax(hi, __shfl_xor(hi, o, 64)); }
     { const double w = fmax(hi - lo, 1e-300); lo -= 1e-3 * w; hi += 1e-3 * w; }
     const double tiny = 1e-300 + 0x1p-52 * 0x1p-52 * fmax(fabs(lo), fabs(hi));
-    for (int round = 0; round < 10; ++round) {
+    // Nine rounds: the interval shrinks to 65^-9 = 5e-17 of the Gershgorin range.  (Eight - 3e-15 - are not enough: the twisted
+    // factorisation needs the eigenvalue to well below the smallest gap, ~1e-10 of the scale for pairs that are only split by the
+    // perturbation, and with eight rounds the doubly degenerate test spectra at n = 114 came out parallel enough to be rejected.)
+    for (int round = 0; round < 9; ++round) {
         const double h = (hi - lo) * (1.0 / 65.0);
         const double x = lo + h * (lane + 1);
         const unsigned long long above = __ballot(sturm_count(n, d, e2, x) > j);     // lanes whose point lies above eigenvalue j
@@ -360,14 +367,24 @@ __global__ __launch_bounds__(TE_WAVES * 64) void qc_tri_eig_kernel(int n, const 
     }
     const double l = 0.5 * (lo + hi);
     auto guard = [&](double x) { return fabs(x) < tiny ? tiny : x; };
-    if (lane == 0) {                                     // D+_i = (d_i - l) - e_{i-1}^2 / D+_{i-1}
-        double dp = guard(d[0] - l);
-        Dp[0] = dp;
-        for (int i = 1; i < n; ++i) { dp = guard(fma(-e2[i - 1], fast_rcp(dp), d[i] - l)); Dp[i] = dp; }
-    } else if (lane == 1) {                              // D-_i = (d_i - l) - e_i^2 / D-_{i+1}
-        double dm = guard(d[n - 1] - l);
-        Dm[n - 1] = dm;
-        for (int i = n - 2; i >= 0; --i) { dm = guard(fma(-e2[i], fast_rcp(dm), d[i] - l)); Dm[i] = dm; }
+    // The two pivot recurrences, D+_i = (d_i - l) - e_{i-1}^2 / D+_{i-1} upwards (lane 0) and D-_i = (d_i - l) - e_i^2 / D-_{i+1} downwards
+    // (lane 1), as ONE instruction stream: in two branches the wave would run them one after the other.  Operands of four steps are
+    // requested ahead of the dependent chain (rcp + Newton + fma per step).
+    if (lane < 2) {
+        const int up = lane == 0;
+        double *arr = up ? Dp : Dm;
+        const int i0 = up ? 0 : n - 1;
+        double piv = guard(d[i0] - l);
+        arr[i0] = piv;
+        int s = 1;
+        for (; s + 4 <= n; s += 4) {
+            int ii[4]; double dv[4], fv[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { ii[u] = up ? s + u : n - 1 - s - u; dv[u] = d[ii[u]]; fv[u] = e2[up ? ii[u] - 1 : ii[u]]; }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { piv = guard(fma(-fv[u], fast_rcp(piv), dv[u] - l)); arr[ii[u]] = piv; }
+        }
+        for (; s < n; ++s) { const int i = up ? s : n - 1 - s; piv = guard(fma(-e2[up ? i - 1 : i], fast_rcp(piv), d[i] - l)); arr[i] = piv; }
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
@@ -384,22 +401,27 @@ __global__ __launch_bounds__(TE_WAVES * 64) void qc_tri_eig_kernel(int n, const 
         const int r2 = __shfl_xor(r, o, 64);
         if (g2 < gmin || (g2 == gmin && r2 < r)) { gmin = g2; r = r2; }
     }
-    // z_r = 1; downwards z_i = -(e_i / D+_i) z_{i+1} (lane 0); upwards z_{i+1} = -(e_i / D-_{i+1}) z_i (lane 1)
+    // The multipliers -(e_i / D+_i) and -(e_i / D-_{i+1}) do not depend on z: all lanes form them at once (in place of the pivots),
+    // the two serial recurrences z_i = m_i z_{i+1} (lane 0, downwards from r) and z_{i+1} = m_i z_i (lane 1, upwards) are then bare
+    // multiplications - again one instruction stream for both lanes.
+    for (int i = lane; i < n; i += 64) {
+        if (i < r) Dp[i] = -(e[i] * fast_rcp(Dp[i]));
+        if (i >= r && i + 1 < n) Dm[i + 1] = -(e[i] * fast_rcp(Dm[i + 1]));
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     double nrm = 0.0;
-    if (lane == 0) {
+    if (lane < 2) {
+        const int down = lane == 0;
+        const int steps = down ? r : n - 1 - r;           // lane 0: i = r-1 .. 0;  lane 1: i = r+1 .. n-1
         double zi = 1.0;
-        nrm = 1.0;
-        Zg[(size_t)r * n + j] = 1.0;
-        for (int i = r - 1; i >= 0; --i) {
-            zi = -(e[i] * fast_rcp(Dp[i])) * zi;
+        if (down) { nrm = 1.0; Zg[(size_t)r * n + j] = 1.0; }
+        const double *mul = down ? Dp : Dm;
+        for (int s = 1; s <= steps; ++s) {
+            const int i = down ? r - s : r + s;
+            zi *= mul[i];
             Zg[(size_t)i * n + j] = zi;
-            nrm = fma(zi, zi, nrm);
-        }
-    } else if (lane == 1) {
-        double zi = 1.0;
-        for (int i = r; i + 1 < n; ++i) {
-            zi = -(e[i] * fast_rcp(Dm[i + 1])) * zi;
-            Zg[(size_t)(i + 1) * n + j] = zi;
             nrm = fma(zi, zi, nrm);
         }
     }
@@ -471,7 +493,7 @@ int qc_eig_tridiag_start(hipStream_t st, int n, const double *dA, double *dX0, d
         hipLaunchKernelGGL(qc_tridiag_kernel<true>, dim3(1), dim3(TRI_THREADS), lds_a, st, n, ld, dA, rel_pert, (double *)nullptr, Vr, tri);
     else        // matrix in global memory (Zg's storage is free until the next kernel)
         hipLaunchKernelGGL(qc_tridiag_kernel<false>, dim3(1), dim3(TRI_THREADS), small, st, n, n, dA, rel_pert, Zg, Vr, tri);
-    hipLaunchKernelGGL(qc_tri_eig_kernel, dim3((n + TE_WAVES - 1) / TE_WAVES), dim3(TE_WAVES * 64), (size_t)TE_WAVES * 2 * n * sizeof(double), st, n, tri, Zg, evn);
+    hipLaunchKernelGGL(qc_tri_eig_kernel, dim3((n + TE_WAVES - 1) / TE_WAVES), dim3(TE_WAVES * 64), (size_t)(TE_WAVES * 2 + 3) * n * sizeof(double), st, n, tri, Zg, evn);
     const int npl = (n + 63) / 64;
     const dim3 grid((n + 3) / 4), block(256);
 #define QC_BT_CASE(N) case N: hipLaunchKernelGGL(qc_backtransform_kernel<N>, grid, block, 0, st, n, Zg, Vr, tri, evn, dX0); break;
