@@ -72,6 +72,36 @@ int qc_device_reshard(qc_system *S) {
     return upload_slots(S);
 }
 
+// Recurrence plans of the cooperative Hermite-Coulomb tables (qc_build_r in qc_fock_kernel.h), every total order 0..QC_LTOT.  Work array
+// of order L: level n (the R^n values) starts at rwork(L) - rwork(L - n), inside a level the Hermite index.  Record = {target | source1 << 16,
+// source2 | c << 16 | axis << 24}, byte offsets; entries of stage N = t+u+v are contiguous, levels n = 0 .. L-N, position r inside the order.
+static std::vector<int> qc_build_rplan() {
+    std::vector<int> plan;
+    for (int L = 0; L <= QC_LTOT; ++L) {
+        if ((int)plan.size() != 2 * qc_plan_off(L)) abort();
+        const int RWL = qc_rwork(L);
+        for (int N = 1; N <= L; ++N) {
+            const int cnt = (N + 1) * (N + 2) / 2;
+            for (int n = 0; n <= L - N; ++n)
+                for (int r = 0; r < cnt; ++r) {
+                    int s = 0;
+                    while ((s + 1) * (s + 2) / 2 <= r) ++s;
+                    const int v = r - s * (s + 1) / 2, u = s - v, t = N - s;
+                    const int o0 = RWL - qc_rwork(L - n), o1 = RWL - qc_rwork(L - n - 1);
+                    int s1, s2, c, ax;
+                    if (t > 0) { ax = 0; c = t - 1; s1 = qc_hidx(t - 1, u, v); s2 = t > 1 ? qc_hidx(t - 2, u, v) : s1; }
+                    else if (u > 0) { ax = 1; c = u - 1; s1 = qc_hidx(t, u - 1, v); s2 = u > 1 ? qc_hidx(t, u - 2, v) : s1; }
+                    else { ax = 2; c = v - 1; s1 = qc_hidx(t, u, v - 1); s2 = v > 1 ? qc_hidx(t, u, v - 2) : s1; }
+                    const int dst = 8 * (o0 + qc_hidx(t, u, v)), b1 = 8 * (o1 + s1), b2 = 8 * (o1 + s2);
+                    plan.push_back(dst | (b1 << 16));
+                    plan.push_back(b2 | (c << 16) | (ax << 24));
+                }
+        }
+    }
+    plan.push_back(0); plan.push_back(0);
+    return plan;
+}
+
 int qc_device_init(qc_system *S) {
     if (S->device_ready) return QC_OK;
     if (qc_device_ready() != QC_OK) return QC_ERR_NO_DEVICE;
@@ -109,6 +139,11 @@ int qc_device_init(qc_system *S) {
     }
     QC_HIP_CHECK(hipMalloc(&S->d_boys, tab.size() * sizeof(double)));
     QC_HIP_CHECK(hipMemcpy(S->d_boys, tab.data(), tab.size() * sizeof(double), hipMemcpyHostToDevice));
+    {
+        const std::vector<int> plan = qc_build_rplan();
+        QC_HIP_CHECK(hipMalloc(&S->d_rplan, plan.size() * sizeof(int)));
+        QC_HIP_CHECK(hipMemcpy(S->d_rplan, plan.data(), plan.size() * sizeof(int), hipMemcpyHostToDevice));
+    }
     QC_HIP_CHECK(hipMalloc(&S->d_D, 2 * nn * sizeof(double)));
     QC_HIP_CHECK(hipMalloc(&S->d_G, 2 * nn * sizeof(double)));
     QC_HIP_CHECK(hipMalloc(&S->d_Gtmp, (size_t)2 * QC_NREP * 2 * nn * sizeof(double)));
@@ -131,10 +166,10 @@ void qc_device_free(qc_system *S) {
         if (c.d_bundles) { (void)hipFree(c.d_bundles); c.d_bundles = nullptr; }
         if (c.d_ketlist) { (void)hipFree(c.d_ketlist); c.d_ketlist = nullptr; }
     }
-    void *ptrs[] = {S->d_shells, S->d_pairdata, S->d_pairdataT, S->d_pspack, S->d_pairs, S->d_boys, S->d_D, S->d_G, S->d_Gtmp, S->d_Gred, S->d_Dj, S->d_flag, S->d_fxs};
+    void *ptrs[] = {S->d_rplan, S->d_shells, S->d_pairdata, S->d_pairdataT, S->d_pspack, S->d_pairs, S->d_boys, S->d_D, S->d_G, S->d_Gtmp, S->d_Gred, S->d_Dj, S->d_flag, S->d_fxs};
     S->d_flag = nullptr; S->d_fxs = nullptr;
     for (void *p : ptrs) if (p) (void)hipFree(p);
-    S->d_shells = nullptr; S->d_pairdata = S->d_pairdataT = S->d_pspack = nullptr; S->d_pairs = nullptr; S->d_boys = S->d_D = S->d_G = S->d_Gtmp = S->d_Gred = S->d_Dj = nullptr;
+    S->d_shells = nullptr; S->d_pairdata = S->d_pairdataT = S->d_pspack = nullptr; S->d_pairs = nullptr; S->d_rplan = nullptr; S->d_boys = S->d_D = S->d_G = S->d_Gtmp = S->d_Gred = S->d_Dj = nullptr;
     for (int i = 0; i < QC_NSTREAMS; ++i) {
         if (S->side[i]) (void)hipStreamDestroy(S->side[i]);
         if (S->ev_join[i]) (void)hipEventDestroy(S->ev_join[i]);
@@ -149,7 +184,7 @@ void qc_device_free(qc_system *S) {
 
 static QcKernelArgs base_args(qc_system *S, const QcFockArgs &fa) {
     QcKernelArgs a{};
-    a.pairs = S->d_pairs; a.pairdata = S->d_pairdata; a.pairdataT = S->d_pairdataT; a.boys = S->d_boys; a.n = S->nbasis;
+    a.pairs = S->d_pairs; a.pairdata = S->d_pairdata; a.pairdataT = S->d_pairdataT; a.boys = S->d_boys; a.rplan = reinterpret_cast<const int2 *>(S->d_rplan); a.n = S->nbasis;
     a.Dj = fa.Dj; a.Dk0 = fa.Dk0; a.Dk1 = fa.Dk1; a.G0 = fa.G0; a.G1 = fa.G1; a.cK = fa.cK; a.eri_out = fa.eri_out;
     a.nrep = fa.nrep > 0 ? fa.nrep : 1; a.rep_stride = fa.rep_stride; a.fxs = fa.fxs; a.fx_lo = fa.fx_lo; a.schwarz_out = fa.schwarz_out;
     return a;

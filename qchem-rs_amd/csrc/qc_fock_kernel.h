@@ -33,6 +33,7 @@ struct QcKernelArgs {
     const double *pairdata;
     const double *pairdataT;  // same blocks, expansion stored [ab][h] (A operand of the MFMA step 3)
     const double *boys;
+    const int2 *rplan;        // recurrence plans of the cooperative R tables, all orders (qc_plan_off)
     int n;
     const double *Dj, *Dk0, *Dk1;
     double *G0, *G1;          // replica 0 of the accumulation targets
@@ -179,12 +180,14 @@ __device__ __forceinline__ void qc_step2_dpp_first(const double *__restrict__ Ec
     for (int k = 0; k < NR; ++k) Rd[k] = Rw[min(16 * k + l16, HR - 1)];
 }
 // one primitive quartet on its own (cooperative-table classes: the table of the next one does not exist yet)
+// (`e` = the first batch of ket coefficients, requested by the caller before it built the table)
 template <int LAB, int LCD>
-__device__ __forceinline__ void qc_step2_dpp(double (&W)[qc_nherm(LAB)], const double *__restrict__ Ecd, int ncd, double sc,
+__device__ __forceinline__ void qc_step2_dpp(double (&W)[qc_nherm(LAB)], const double (&e)[QC_DPP_BATCH], const double *__restrict__ Ecd, int ncd, double sc,
                                              const double *__restrict__ Rw, int lane) {
-    constexpr int NR = (qc_nherm(LAB + LCD) + 15) / 16;
-    double e[QC_DPP_BATCH], Rd[NR], eN[QC_DPP_BATCH], RdN[NR];
-    qc_step2_dpp_first<LAB, LCD, NR>(Ecd, ncd, Rw, lane & 15, e, Rd);
+    constexpr int NR = (qc_nherm(LAB + LCD) + 15) / 16, HR = qc_nherm(LAB + LCD);
+    double Rd[NR], eN[QC_DPP_BATCH], RdN[NR];
+#pragma unroll
+    for (int k = 0; k < NR; ++k) Rd[k] = Rw[min(16 * k + (lane & 15), HR - 1)];
     qc_step2_dpp_from<LAB, LCD, NR, 0>(W, Rd, e, Ecd, ncd, sc, Ecd, Rw, lane & 15, eN, RdN);
 }
 
@@ -248,12 +251,15 @@ __host__ __device__ constexpr int qc_roff(int n) {
     return o;
 }
 
-// Cooperative Hermite-Coulomb table R^0_{tuv}, t+u+v <= L, by the `C` lanes of a group (lane-in-group `li`), in LDS.
+// Cooperative Hermite-Coulomb table R^0_{tuv}, t+u+v <= L, by the C lanes of a group (lane-in-group `li`), in LDS.
 // On return Rw[0 .. nherm(L)) holds R^0.  Every lane of the workgroup must call this (it contains barriers).
-// Entry (n; t,u,v) of stage N = t+u+v is decoded from its flat index arithmetically (no table lookups):
-// position r inside order N: s = u+v = floor((sqrt(8r+1)-1)/2), v = r - s(s+1)/2; level offset = rwork(L) - rwork(L-n).
-template <int L>
-__device__ __forceinline__ void qc_build_r(double *__restrict__ Rw, int li, int C, double alpha, double X, double Y, double Z,
+// Stage N = t+u+v computes its (L-N+1)(N+1)(N+2)/2 entries (levels n <= L-N) from stage N-1:
+//   R^n_{t,u,v} = g R^{n+1}_{(t,u,v) - e_g} + c R^{n+1}_{(t,u,v) - 2 e_g},  g = the first axis with a non-zero index, c = that index - 1.
+// Which entry reads what is the same for every quartet, so it comes from a plan (host-built once per order, qc_build_rplan; staged in
+// LDS by the workgroup): a record holds the byte offsets of the target and the two sources, c and the axis - decoding (n,t,u,v) from the
+// flat index instead cost ~100 instructions per entry, integer multiplies at a quarter of the rate, 15 us per table for a lone wave at L = 12.
+template <int L, int C>
+__device__ __forceinline__ void qc_build_r(double *__restrict__ Rw, const int2 *__restrict__ plan, int li, double alpha, double X, double Y, double Z,
                                            const double (&F)[L + 1]) {
     if (li == 0) {
         double f = 1.0;
@@ -261,29 +267,23 @@ __device__ __forceinline__ void qc_build_r(double *__restrict__ Rw, int li, int 
         for (int n = 0; n <= L; ++n) { Rw[qc_roff<L>(n)] = f * F[n]; f *= -2.0 * alpha; }
     }
     __syncthreads();
+    char *const Rb = reinterpret_cast<char *>(Rw);
+    int base = 0;
 #pragma unroll
     for (int N = 1; N <= L; ++N) {
-        constexpr int RWL = qc_rwork(L);
-        const int cnt = (N + 1) * (N + 2) / 2, total = (L - N + 1) * cnt, base = qc_nherm(N - 1);
-        for (int e = li; e < total; e += C) {
-            const int n = e / cnt, r = e - n * cnt;
-            const int s = (int)((sqrtf(8.0f * r + 1.0f) - 1.0f) * 0.5f + 1e-3f);
-            const int v = r - s * (s + 1) / 2, u = s - v, t = N - s;
-            const int o0 = RWL - qc_rwork(L - n), o1 = RWL - qc_rwork(L - n - 1);   // offsets of levels n, n+1
-            const double *up = Rw + o1;
-            double val;
-            if (t > 0) {
-                val = X * up[qc_hidx(t - 1, u, v)];
-                if (t > 1) val = fma((double)(t - 1), up[qc_hidx(t - 2, u, v)], val);
-            } else if (u > 0) {
-                val = Y * up[qc_hidx(t, u - 1, v)];
-                if (u > 1) val = fma((double)(u - 1), up[qc_hidx(t, u - 2, v)], val);
-            } else {
-                val = Z * up[qc_hidx(t, u, v - 1)];
-                if (v > 1) val = fma((double)(v - 1), up[qc_hidx(t, u, v - 2)], val);
-            }
-            Rw[o0 + base + r] = val;
+        const int total = (L - N + 1) * ((N + 1) * (N + 2) / 2);
+#pragma unroll
+        for (int k = 0; k * C < total; ++k) {
+            const int e = li + k * C;
+            const bool ok = e < total;
+            const int2 pe = plan[base + (ok ? e : 0)];
+            const int ax = pe.y >> 24;
+            const double g = ax == 0 ? X : (ax == 1 ? Y : Z);
+            const double r1 = *reinterpret_cast<const double *>(Rb + (pe.x >> 16)), r2 = *reinterpret_cast<const double *>(Rb + (pe.y & 0xffff));
+            const double val = fma((double)((pe.y >> 16) & 0xff), r2, g * r1);
+            if (ok) *reinterpret_cast<double *>(Rb + (pe.x & 0xffff)) = val;
         }
+        base += total;
         __syncthreads();
     }
 }
@@ -308,6 +308,12 @@ __device__ __forceinline__ void qc_fock_body(const QcKernelArgs &a, const QcSlot
     double *const Iblk = Rw + qc_region0(L, LGC);
     const size_t rep = (size_t)(blk % a.nrep) * a.rep_stride;   // accumulation replica of this workgroup
     constexpr bool MFMA = qc_use_mfma(LAB, LCD) && LGC == 6;   // contractions on the matrix cores (one slot per wave)
+    // recurrence plan of this class's R tables: behind the groups' regions, shared by them (read after the first barrier below)
+    int2 *const plan = reinterpret_cast<int2 *>(lds + (size_t)G * slot_words);
+    if constexpr (!HOIST) {
+        const int2 *__restrict__ gp = a.rplan + qc_plan_off(L);
+        for (int i = lane; i < qc_nplan(L); i += 64) plan[i] = gp[i];
+    }
     if constexpr (MFMA) {
         int *const tab = reinterpret_cast<int *>(Rw + slot_words - 48);
         for (int h = lane; h < qc_nherm(QC_LPAIR); h += 64) {       // (N, s, v) of Hermite index h, packed
@@ -320,7 +326,16 @@ __device__ __forceinline__ void qc_fock_body(const QcKernelArgs &a, const QcSlot
         __syncthreads();
     }
 
+#ifdef QC_PHASE_TIMING
+    long long tph[8] = {};
+#define QC_T(i) do { const long long t_ = wall_clock64(); tph[i] += t_ - tlast; tlast = t_; } while (0)
+#else
+#define QC_T(i) do {} while (0)
+#endif
     for (int wave = blk; wave * G < nslots; wave += nblk) {
+#ifdef QC_PHASE_TIMING
+        long long tlast = wall_clock64();
+#endif
         const int slot = wave * G + g;
         const bool active = slot < nslots;
         const QcSlot sl = slots[active ? slot : nslots - 1];
@@ -347,6 +362,7 @@ __device__ __forceinline__ void qc_fock_body(const QcKernelArgs &a, const QcSlot
                 }
             }
         }
+        QC_T(0);
         const int strideB = qc_pair_stride(LAB, nab), strideK = qc_pair_stride(LCD, ncd);
         const int len = active ? sl.hi - sl.lo : 0;
         int maxlen = len;                                   // uniform trip count: the longest slot of this wave
@@ -443,10 +459,12 @@ __device__ __forceinline__ void qc_fock_body(const QcKernelArgs &a, const QcSlot
             const int K_cd = pk.K;
             int ij = sl.lo / K_cd, kl = sl.lo - ij * K_cd;
             for (int itq = 0; itq < len; ++itq) {
+                QC_T(1);
                 if (ij != cur_ij) {
                     if (cur_ij >= 0) flush(cur_ij);
                     cur_ij = ij;
                 }
+                QC_T(4);
                 const double4 cb = *reinterpret_cast<const double4 *>(braBase + (size_t)ij * strideB);
                 const double *ket = ketBase + (size_t)kl * strideK;
                 const double4 ck = *reinterpret_cast<const double4 *>(ket);
@@ -475,32 +493,45 @@ __device__ __forceinline__ void qc_fock_body(const QcKernelArgs &a, const QcSlot
                         av[mt] = sg * Rw[N * (N + 1) * (N + 2) / 6 + ss * (ss + 1) / 2 + v1[mt] + v2];
                     }
                 };
-                double bvA[4], avA[MT];
-                load_b(0, bvA);
+                // B fragments travel PD k-steps ahead of their MFMAs (a k-step is 4 MT NT matrix instructions, ~400-800 cycles for a lone
+                // wave; a ket block comes from the L2 / the memory-side cache in 500-1200): the first PD are requested before the Boys
+                // function and the R table, a buffer is refilled as soon as its MFMAs have issued.  A fragments (LDS) one step ahead.
+                constexpr int PD = MT >= 5 ? 3 : (MT >= 3 ? 5 : 6);
+                double bv[PD][4], avA[MT];
+#pragma unroll
+                for (int d = 0; d < PD; ++d) load_b(min(d, KS - 1), bv[d]);
                 double F[L + 1];
                 qc_boys<L>(alpha * (X * X + Y * Y + Z * Z), a.boys, F);
                 __syncthreads();                  // previous iteration's readers of Rw are done
-                qc_build_r<L>(Rw, lane, 64, alpha, X, Y, Z, F);
+                QC_T(1);
+                qc_build_r<L, 64>(Rw, plan, lane, alpha, X, Y, Z, F);
+                QC_T(2);
                 load_a(0, avA);
-                for (int ks = 0; ks < KS; ++ks) {
-                    double bvB[4], avB[MT];
-                    const int kn = min(ks + 1, KS - 1);
-                    load_b(kn, bvB);
-                    load_a(kn, avB);
-                    __builtin_amdgcn_sched_barrier(0);
+                for (int ks0 = 0; ks0 < KS; ks0 += PD) {
 #pragma unroll
-                    for (int mt = 0; mt < MT; ++mt)
+                    for (int d = 0; d < PD; ++d) {
+                        const int ks = ks0 + d;
+                        if (ks >= KS) break;
+                        double avB[MT];
+                        load_a(min(ks + 1, KS - 1), avB);
+                        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                        for (int nt = 0; nt < 4; ++nt)
-                            if (nt < NT) Wacc[mt][nt] = __builtin_amdgcn_mfma_f64_16x16x4f64(avA[mt], bvA[nt], Wacc[mt][nt], 0, 0, 0);
+                        for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-                    for (int nt = 0; nt < 4; ++nt) bvA[nt] = bvB[nt];
+                            for (int nt = 0; nt < 4; ++nt)
+                                if (nt < NT) Wacc[mt][nt] = __builtin_amdgcn_mfma_f64_16x16x4f64(avA[mt], bv[d][nt], Wacc[mt][nt], 0, 0, 0);
+                        __builtin_amdgcn_sched_barrier(0);
+                        if (ks + PD < KS) load_b(ks + PD, bv[d]);
 #pragma unroll
-                    for (int mt = 0; mt < MT; ++mt) avA[mt] = avB[mt];
+                        for (int mt = 0; mt < MT; ++mt) avA[mt] = avB[mt];
+                    }
                 }
+                QC_T(3);
                 if (++kl == K_cd) { kl = 0; ++ij; }
             }
+            QC_T(1);
             if (cur_ij >= 0) flush(cur_ij);
+            QC_T(4);
           }
         } else {
         for (int pass = 0; pass < npass; ++pass) {
@@ -642,6 +673,12 @@ __device__ __forceinline__ void qc_fock_body(const QcKernelArgs &a, const QcSlot
                     hb = *reinterpret_cast<const double4 *>(braBase + (size_t)ij * strideB);
                     hk = *reinterpret_cast<const double4 *>(ketBase + (size_t)kl * strideK);
                 }
+                double e0[QC_DPP_BATCH];               // first ket coefficients: on their way while the table is built
+                {
+                    const double *E0 = ket + 4 + (colok ? col : 0);
+#pragma unroll
+                    for (int j = 0; j < QC_DPP_BATCH; ++j) e0[j] = (j < HCD) ? E0[(size_t)j * ncd] : 0.0;
+                }
                 const double p = cb.x, q = ck.x;
                 const double X = cb.y - ck.y, Y = cb.z - ck.z, Z = cb.w - ck.w;
                 const double pq_sum = p + q;
@@ -652,14 +689,15 @@ __device__ __forceinline__ void qc_fock_body(const QcKernelArgs &a, const QcSlot
                 const double sc = (valid && colok) ? pref : 0.0;
                 const double *Ecd = ket + 4 + (colok ? col : 0);
                 __syncthreads();                  // previous iteration's readers of Rw are done
-                qc_build_r<L>(Rw, li, C, alpha, X, Y, Z, F);
-                qc_step2_dpp<LAB, LCD>(W, Ecd, ncd, sc, Rw, lane);
+                qc_build_r<L, C>(Rw, plan, li, alpha, X, Y, Z, F);
+                qc_step2_dpp<LAB, LCD>(W, e0, Ecd, ncd, sc, Rw, lane);
             }
             }
             if (cur_ij >= 0) flush(cur_ij);
         }
         }
         __syncthreads();
+        QC_T(5);
 
         if (active) {
             const double f = (pb.shA_eq_shB ? 0.5 : 1.0) * (pk.shA_eq_shB ? 0.5 : 1.0) * (sl.bra == sl.ket ? 0.5 : 1.0);
@@ -751,7 +789,14 @@ __device__ __forceinline__ void qc_fock_body(const QcKernelArgs &a, const QcSlot
             }
         }
         __syncthreads();   // the slot regions are reused by the next batch of slots
+        QC_T(6);
     }
+#ifdef QC_PHASE_TIMING
+    if (MFMA && lane == 0 && blk < 2 && digest)
+        printf("[phase] <%d,%d,%d> blk %d/%d nslots %d: setup %lld  boys+hdr %lld  rtab %lld  kloop %lld  flush %lld  tail %lld  digest %lld  (10 ns units)\n", LAB, LCD, LGC, blk, nblk, nslots,
+               tph[0], tph[1], tph[2], tph[3], tph[4], tph[5], tph[6]);
+#endif
+#undef QC_T
 }
 
 // One launch = one "tier" of a bra class: all (LCD, LGC) buckets of LAB with LCD <= 3 (tier 0: moderate register

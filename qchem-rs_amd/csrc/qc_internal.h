@@ -48,6 +48,10 @@ __host__ __device__ constexpr int qc_hidx(int t, int u, int v) {
 // doubles per primitive-pair block: header [p,Px,Py,Pz] + E (nherm x nab), padded to a multiple of 4 (32-byte rows)
 __host__ __device__ constexpr int qc_pair_stride(int L, int nab) { return (4 + qc_nherm(L) * nab + 3) & ~3; }
 __host__ __device__ constexpr int qc_rwork(int L) { return (L + 1) * (L + 2) * (L + 3) * (L + 4) / 24; }
+// Recurrence plan of the cooperative Hermite-Coulomb table (qc_build_r): one 8-byte record per entry (n; t,u,v) with t+u+v >= 1,
+// stage by stage; plans of all orders L are concatenated, L's starts at qc_plan_off(L)
+__host__ __device__ constexpr int qc_nplan(int L) { return qc_rwork(L) - (L + 1); }
+__host__ __device__ constexpr int qc_plan_off(int L) { int o = 0; for (int l = 0; l < L; ++l) o += qc_nplan(l); return o; }
 
 struct QcShell {
     int atom, L, pure, nprim, ncart, nfunc, off;
@@ -124,6 +128,7 @@ struct qc_system {
     size_t shell_blob_off[5] = {};
     QcPairDesc *d_pairs = nullptr;
     double *d_boys = nullptr;
+    int *d_rplan = nullptr;       // recurrence plans of the Hermite-Coulomb tables (qc_build_rplan)
     double *d_D = nullptr, *d_G = nullptr;   // 2 * n*n each (alpha/beta or Dj/Dk)
     double *d_Gtmp = nullptr;                // accumulation target: [plane (hi, lo)][replica][spin][n*n]
     double *d_Gred = nullptr;                // replicas folded: [plane][spin][n*n]

@@ -418,7 +418,7 @@ void qc_build_shards(qc_system *S) {
             words = std::max(words, w);
         }
         c.slot_words = words;
-        c.lds_bytes = words * 8 * (64 >> c.LGC);
+        c.lds_bytes = words * 8 * (64 >> c.LGC) + (qc_hoisted(c.LAB + c.LCD) ? 0 : qc_nplan(c.LAB + c.LCD) * 8);   // + the R recurrence plan
         if (c.bm) {   // I[nab * ncd][65]: one column per lane
             int mx = 0;
             c.bm_rows = 0;
