@@ -72,6 +72,38 @@ int qc_device_reshard(qc_system *S) {
     return upload_slots(S);
 }
 
+// Gather records of the matrix-core classes (qc_fock_body, MFMA branch): step 2's A fragment of k-step ks is, in lane l = 16 q4 + i16 and
+// row tile mt, the R value at the Hermite index of h1 + h2 with h1 = 16 mt + i16, h2 = 4 ks + q4.  Which LDS word that is does not
+// depend on the quartet: record (ks, l) = eight u16 - byte offsets into the R table for mt = 0..5, one spare, flags (bit 0 = odd ket
+// order: the value enters with a minus sign; bit 1 = h2 inside the ket's Hermite range).
+static std::vector<unsigned> qc_build_gidx() {
+    std::vector<unsigned> out;
+    std::vector<int> ht, hu, hv;
+    for (int N = 0; N <= QC_LPAIR; ++N)
+        for (int t = N; t >= 0; --t)
+            for (int u = N - t; u >= 0; --u) { ht.push_back(t); hu.push_back(u); hv.push_back(N - t - u); }
+    for (size_t h = 0; h < ht.size(); ++h) if (qc_hidx(ht[h], hu[h], hv[h]) != (int)h) abort();
+    for (int LAB = 3; LAB <= 6; ++LAB)
+        for (int LCD = 5; LCD <= 6; ++LCD) {
+            if ((int)out.size() != 4 * qc_gidx_off(LAB, LCD)) abort();
+            const int HAB = qc_nherm(LAB), HCD = qc_nherm(LCD), MT = (HAB + 15) / 16;
+            for (int ks = 0; ks < qc_gidx_ksteps(LCD); ++ks)
+                for (int lane = 0; lane < 64; ++lane) {
+                    const int q4 = lane >> 4, i16 = lane & 15, h2 = 4 * ks + q4;
+                    const bool ok = h2 < HCD;
+                    unsigned short w[8] = {};
+                    for (int mt = 0; mt < MT; ++mt) {
+                        const int h1 = std::min(16 * mt + i16, HAB - 1), g = ok ? h2 : 0;
+                        w[mt] = (unsigned short)(8 * qc_hidx(ht[h1] + ht[g], hu[h1] + hu[g], hv[h1] + hv[g]));
+                    }
+                    w[7] = ok ? (unsigned short)(2 | ((ht[h2] + hu[h2] + hv[h2]) & 1)) : 0;
+                    for (int k = 0; k < 4; ++k) out.push_back((unsigned)w[2 * k] | ((unsigned)w[2 * k + 1] << 16));
+                }
+        }
+    out.resize(out.size() + 4, 0u);
+    return out;
+}
+
 // Recurrence plans of the cooperative Hermite-Coulomb tables (qc_build_r in qc_fock_kernel.h), every total order 0..QC_LTOT.  Work array
 // of order L: level n (the R^n values) starts at rwork(L) - rwork(L - n), inside a level the Hermite index.  Record = {target | source1 << 16,
 // source2 | c << 16 | axis << 24}, byte offsets; entries of stage N = t+u+v are contiguous, levels n = 0 .. L-N, position r inside the order.
@@ -143,6 +175,9 @@ int qc_device_init(qc_system *S) {
         const std::vector<int> plan = qc_build_rplan();
         QC_HIP_CHECK(hipMalloc(&S->d_rplan, plan.size() * sizeof(int)));
         QC_HIP_CHECK(hipMemcpy(S->d_rplan, plan.data(), plan.size() * sizeof(int), hipMemcpyHostToDevice));
+        const std::vector<unsigned> gi = qc_build_gidx();
+        QC_HIP_CHECK(hipMalloc(&S->d_gidx, gi.size() * sizeof(unsigned)));
+        QC_HIP_CHECK(hipMemcpy(S->d_gidx, gi.data(), gi.size() * sizeof(unsigned), hipMemcpyHostToDevice));
     }
     QC_HIP_CHECK(hipMalloc(&S->d_D, 2 * nn * sizeof(double)));
     QC_HIP_CHECK(hipMalloc(&S->d_G, 2 * nn * sizeof(double)));
@@ -166,10 +201,10 @@ void qc_device_free(qc_system *S) {
         if (c.d_bundles) { (void)hipFree(c.d_bundles); c.d_bundles = nullptr; }
         if (c.d_ketlist) { (void)hipFree(c.d_ketlist); c.d_ketlist = nullptr; }
     }
-    void *ptrs[] = {S->d_rplan, S->d_shells, S->d_pairdata, S->d_pairdataT, S->d_pspack, S->d_pairs, S->d_boys, S->d_D, S->d_G, S->d_Gtmp, S->d_Gred, S->d_Dj, S->d_flag, S->d_fxs};
+    void *ptrs[] = {S->d_rplan, S->d_gidx, S->d_shells, S->d_pairdata, S->d_pairdataT, S->d_pspack, S->d_pairs, S->d_boys, S->d_D, S->d_G, S->d_Gtmp, S->d_Gred, S->d_Dj, S->d_flag, S->d_fxs};
     S->d_flag = nullptr; S->d_fxs = nullptr;
     for (void *p : ptrs) if (p) (void)hipFree(p);
-    S->d_shells = nullptr; S->d_pairdata = S->d_pairdataT = S->d_pspack = nullptr; S->d_pairs = nullptr; S->d_rplan = nullptr; S->d_boys = S->d_D = S->d_G = S->d_Gtmp = S->d_Gred = S->d_Dj = nullptr;
+    S->d_shells = nullptr; S->d_pairdata = S->d_pairdataT = S->d_pspack = nullptr; S->d_pairs = nullptr; S->d_rplan = nullptr; S->d_gidx = nullptr; S->d_boys = S->d_D = S->d_G = S->d_Gtmp = S->d_Gred = S->d_Dj = nullptr;
     for (int i = 0; i < QC_NSTREAMS; ++i) {
         if (S->side[i]) (void)hipStreamDestroy(S->side[i]);
         if (S->ev_join[i]) (void)hipEventDestroy(S->ev_join[i]);
@@ -184,7 +219,7 @@ void qc_device_free(qc_system *S) {
 
 static QcKernelArgs base_args(qc_system *S, const QcFockArgs &fa) {
     QcKernelArgs a{};
-    a.pairs = S->d_pairs; a.pairdata = S->d_pairdata; a.pairdataT = S->d_pairdataT; a.boys = S->d_boys; a.rplan = reinterpret_cast<const int2 *>(S->d_rplan); a.n = S->nbasis;
+    a.pairs = S->d_pairs; a.pairdata = S->d_pairdata; a.pairdataT = S->d_pairdataT; a.boys = S->d_boys; a.rplan = reinterpret_cast<const int2 *>(S->d_rplan); a.gidx = reinterpret_cast<const uint4 *>(S->d_gidx); a.n = S->nbasis;
     a.Dj = fa.Dj; a.Dk0 = fa.Dk0; a.Dk1 = fa.Dk1; a.G0 = fa.G0; a.G1 = fa.G1; a.cK = fa.cK; a.eri_out = fa.eri_out;
     a.nrep = fa.nrep > 0 ? fa.nrep : 1; a.rep_stride = fa.rep_stride; a.fxs = fa.fxs; a.fx_lo = fa.fx_lo; a.schwarz_out = fa.schwarz_out;
     return a;

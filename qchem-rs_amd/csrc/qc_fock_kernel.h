@@ -34,6 +34,7 @@ struct QcKernelArgs {
     const double *pairdataT;  // same blocks, expansion stored [ab][h] (A operand of the MFMA step 3)
     const double *boys;
     const int2 *rplan;        // recurrence plans of the cooperative R tables, all orders (qc_plan_off)
+    const uint4 *gidx;        // gather records of the matrix-core classes (qc_gidx_off)
     int n;
     const double *Dj, *Dk0, *Dk1;
     double *G0, *G1;          // replica 0 of the accumulation targets
@@ -295,7 +296,8 @@ __device__ __forceinline__ void qc_fock_body(const QcKernelArgs &a, const QcSlot
     static_assert(LGC >= 4, "a lane group is made of whole 16-lane rows (DPP row broadcasts)");
     constexpr int C = 1 << LGC, G = 64 >> LGC;
     extern __shared__ double lds[];
-    const int lane = threadIdx.x, g = lane >> LGC, li = lane & (C - 1);
+    // (a 64-lane group is the whole workgroup: group index 0 as a constant keeps the slot and everything derived from it in scalar registers)
+    const int lane = threadIdx.x, g = (LGC == 6) ? 0 : lane >> LGC, li = (LGC == 6) ? lane : lane & (C - 1);
     const double *__restrict__ pd = a.pairdata;
     const int n = a.n;
     const bool uhf = a.Dk1 != nullptr;
@@ -314,18 +316,6 @@ __device__ __forceinline__ void qc_fock_body(const QcKernelArgs &a, const QcSlot
         const int2 *__restrict__ gp = a.rplan + qc_plan_off(L);
         for (int i = lane; i < qc_nplan(L); i += 64) plan[i] = gp[i];
     }
-    if constexpr (MFMA) {
-        int *const tab = reinterpret_cast<int *>(Rw + slot_words - 48);
-        for (int h = lane; h < qc_nherm(QC_LPAIR); h += 64) {       // (N, s, v) of Hermite index h, packed
-            int N = 0;
-            while (qc_nherm(N) <= h) ++N;
-            const int r = h - (N ? qc_nherm(N - 1) : 0);
-            const int sv = (int)((sqrtf(8.0f * r + 1.0f) - 1.0f) * 0.5f + 1e-3f);
-            tab[h] = N | (sv << 8) | ((r - sv * (sv + 1) / 2) << 16);
-        }
-        __syncthreads();
-    }
-
 #ifdef QC_PHASE_TIMING
     long long tph[8] = {};
 #define QC_T(i) do { const long long t_ = wall_clock64(); tph[i] += t_ - tlast; tlast = t_; } while (0)
@@ -383,65 +373,59 @@ __device__ __forceinline__ void qc_fock_body(const QcKernelArgs &a, const QcSlot
           typedef double qc_d4 __attribute__((ext_vector_type(4)));
           constexpr int MT = (HAB + 15) / 16, KS = (HCD + 3) / 4;
           const int i16 = lane & 15, q4 = lane >> 4;
-          int *const tab = reinterpret_cast<int *>(Rw + slot_words - 48);   // (N, s = u+v, v) of every Hermite index
-          int n1[MT], s1[MT], v1[MT];
-#pragma unroll
-          for (int mt = 0; mt < MT; ++mt) {
-              const int t = tab[min(16 * mt + i16, HAB - 1)];
-              n1[mt] = t & 255; s1[mt] = (t >> 8) & 255; v1[mt] = t >> 16;
-          }
+          const uint4 *__restrict__ gi = a.gidx + qc_gidx_off(LAB, LCD) + lane;         // this lane's gather records, one per k-step
+          const char *const Rb = reinterpret_cast<const char *>(Rw);
           const double *__restrict__ pdT = a.pairdataT;
-          for (int col0 = cbeg; col0 < cend; col0 += 64) {       // this slot's ket columns, 64 at a time
-            const int NT = min(4, (cend - col0 + 15) / 16);
-            qc_d4 Wacc[MT][4];
+          const int K_cd = pk.K;
+          // One pass over the slot's primitive quartets for the column tiles [col0, col0 + 16 NT); NT is a compile-time constant of the
+          // instance (a run-time bound put a branch around every matrix instruction)
+          auto tile = [&](auto ntc, const int col0) {
+            constexpr int NT = decltype(ntc)::value;
+            constexpr bool AHEAD = MT * NT <= 12;           // registers for a second set of step-3 A fragments
+            qc_d4 Wacc[MT][NT];
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-                for (int nt = 0; nt < 4; ++nt) Wacc[mt][nt] = qc_d4{0.0, 0.0, 0.0, 0.0};
-            int cur_ij = -1;
-            auto flush = [&](int ij) {
-                const double *__restrict__ Et = pdT + pb.doff + (size_t)ij * strideB + 4;     // [ab][h]
+                for (int nt = 0; nt < NT; ++nt) Wacc[mt][nt] = qc_d4{0.0, 0.0, 0.0, 0.0};
+            // A fragments of step 3, row tile `it`: Et[ab][h1], shared by the column tiles (clamped loads, masked to zero outside the block)
+            auto load_e = [&](const double *__restrict__ Et, int it, double (&av)[MT][4]) {
+                const int ab = 16 * it + i16;
+                const double *row = Et + (size_t)min(ab, nab - 1) * HAB;
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int h1 = 16 * mt + 4 * r + q4;
+                        const double v = row[min(h1, HAB - 1)];
+                        av[mt][r] = (ab < nab && h1 < HAB) ? v : 0.0;
+                    }
+            };
+            // step 3 for the bra primitive pair whose expansion block is Et; avE = the fragments of row tile 0 (requested by the caller
+            // before the Boys function of the pair's last primitive quartet); with registers to spare the next tile's travel one ahead
+            auto flush = [&](const double *__restrict__ Et, double (&avE)[MT][4]) {
                 const int MI = (nab + 15) / 16;
-                // A fragments of row tile `it`: Et[ab][h1], shared by the column tiles (clamped loads, masked to zero
-                // outside the block); the next tile's are requested before this tile's MFMAs
-                auto load_e = [&](int it, double (&av)[MT][4]) {
-                    const int ab = 16 * it + i16;
-                    const double *row = Et + (size_t)min(ab, nab - 1) * HAB;
-#pragma unroll
-                    for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) {
-                            const int h1 = 16 * mt + 4 * r + q4;
-                            const double v = row[min(h1, HAB - 1)];
-                            av[mt][r] = (ab < nab && h1 < HAB) ? v : 0.0;
-                        }
-                };
-                constexpr bool AHEAD = MT <= 4;               // (six row tiles of W leave no registers for a second fragment set)
-                double avE[MT][4];
-                if constexpr (AHEAD) load_e(0, avE);
                 for (int it = 0; it < MI; ++it) {
                     double avN[AHEAD ? MT : 1][4];
-                    if constexpr (AHEAD) load_e(min(it + 1, MI - 1), avN);
-                    else load_e(it, avE);
+                    if constexpr (AHEAD) load_e(Et, min(it + 1, MI - 1), avN);
+                    else { if (it > 0) load_e(Et, it, avE); }
                     __builtin_amdgcn_sched_barrier(0);
-                    qc_d4 acc[4];
+                    qc_d4 acc[NT][2];                       // two accumulators per column tile: consecutive matrix instructions are independent
 #pragma unroll
-                    for (int nt = 0; nt < 4; ++nt) acc[nt] = qc_d4{0.0, 0.0, 0.0, 0.0};
+                    for (int nt = 0; nt < NT; ++nt) acc[nt][0] = acc[nt][1] = qc_d4{0.0, 0.0, 0.0, 0.0};
 #pragma unroll
                     for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
                         for (int r = 0; r < 4; ++r)
 #pragma unroll
-                            for (int nt = 0; nt < 4; ++nt)
-                                if (nt < NT) acc[nt] = __builtin_amdgcn_mfma_f64_16x16x4f64(avE[mt][r], Wacc[mt][nt][r], acc[nt], 0, 0, 0);
+                            for (int nt = 0; nt < NT; ++nt)
+                                acc[nt][r & 1] = __builtin_amdgcn_mfma_f64_16x16x4f64(avE[mt][r], Wacc[mt][nt][r], acc[nt][r & 1], 0, 0, 0);
 #pragma unroll
-                    for (int nt = 0; nt < 4; ++nt) {
-                        if (nt >= NT) break;
+                    for (int nt = 0; nt < NT; ++nt) {
                         const int c = col0 + 16 * nt + i16;
 #pragma unroll
                         for (int r = 0; r < 4; ++r) {
                             const int abr = 16 * it + q4 + 4 * r;
-                            if (abr < nab && c < cend) Iblk[abr * ncd + c] += acc[nt][r];     // this lane alone owns the element
+                            if (abr < nab && c < cend) Iblk[abr * ncd + c] += acc[nt][0][r] + acc[nt][1][r];     // this lane alone owns the element
                         }
                     }
                     if constexpr (AHEAD) {
@@ -454,84 +438,95 @@ __device__ __forceinline__ void qc_fock_body(const QcKernelArgs &a, const QcSlot
 #pragma unroll
                 for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-                    for (int nt = 0; nt < 4; ++nt) Wacc[mt][nt] = qc_d4{0.0, 0.0, 0.0, 0.0};
+                    for (int nt = 0; nt < NT; ++nt) Wacc[mt][nt] = qc_d4{0.0, 0.0, 0.0, 0.0};
             };
-            const int K_cd = pk.K;
             int ij = sl.lo / K_cd, kl = sl.lo - ij * K_cd;
             for (int itq = 0; itq < len; ++itq) {
-                QC_T(1);
-                if (ij != cur_ij) {
-                    if (cur_ij >= 0) flush(cur_ij);
-                    cur_ij = ij;
-                }
                 QC_T(4);
+                const bool last = kl == K_cd - 1 || itq == len - 1;      // of this bra primitive pair: step 3 follows
+                const double *__restrict__ Et = pdT + pb.doff + (size_t)ij * strideB + 4;     // [ab][h]
                 const double4 cb = *reinterpret_cast<const double4 *>(braBase + (size_t)ij * strideB);
                 const double *ket = ketBase + (size_t)kl * strideK;
                 const double4 ck = *reinterpret_cast<const double4 *>(ket);
+                double avE[MT][4];
+                if (last) load_e(Et, 0, avE);
                 const double p = cb.x, q = ck.x;
                 const double X = cb.y - ck.y, Y = cb.z - ck.z, Z = cb.w - ck.w;
                 const double pref = rsqrt(p + q);
                 const double alpha = p * q * (pref * pref);
-                // Operand fragments of k-step ks.  B = four column tiles of the ket block (plain loads, clamped: rows past
-                // HCD meet a zero A value, columns past ncd are never read back); A = the gathered, signed R values.
-                // Both are requested one k-step ahead of the MFMAs that consume them, the first B before the R table is built.
+                // Operand fragments of k-step ks.  B = the column tiles of the ket block (plain loads, clamped: rows past HCD meet a zero
+                // A value, columns past ncd are never read back); A = the gathered, signed R values: which LDS word lane l reads for row
+                // tile mt comes from a host-built record (qc_build_gidx), eight u16 per k-step and lane.
                 const double *Ecd = ket + 4;
-                auto load_b = [&](int ks, double (&bv)[4]) {
+                auto load_b = [&](int ks, double (&bv)[NT]) {
                     const int h2 = min(4 * ks + q4, HCD - 1);
 #pragma unroll
-                    for (int nt = 0; nt < 4; ++nt) bv[nt] = Ecd[(size_t)h2 * ncd + min(col0 + 16 * nt + i16, ncd - 1)];
+                    for (int nt = 0; nt < NT; ++nt) bv[nt] = Ecd[(size_t)h2 * ncd + min(col0 + 16 * nt + i16, ncd - 1)];
                 };
-                auto load_a = [&](int ks, double (&av)[MT]) {
-                    const int h2 = 4 * ks + q4;
-                    const bool h2ok = h2 < HCD;
-                    const int t2 = tab[h2ok ? h2 : 0];
-                    const int n2 = t2 & 255, s2 = (t2 >> 8) & 255, v2 = t2 >> 16;
-                    const double sg = h2ok ? ((n2 & 1) ? -pref : pref) : 0.0;      // sign of the ket order, scale, validity
+                auto gather = [&](const uint4 rec, double (&raw)[MT]) {
+                    const unsigned w[3] = {rec.x, rec.y, rec.z};
 #pragma unroll
                     for (int mt = 0; mt < MT; ++mt) {
-                        const int N = n1[mt] + n2, ss = s1[mt] + s2;
-                        av[mt] = sg * Rw[N * (N + 1) * (N + 2) / 6 + ss * (ss + 1) / 2 + v1[mt] + v2];
+                        const unsigned off = (mt & 1) ? (w[mt >> 1] >> 16) : (w[mt >> 1] & 0xffffu);
+                        raw[mt] = *reinterpret_cast<const double *>(Rb + off);
                     }
                 };
-                // B fragments travel PD k-steps ahead of their MFMAs (a k-step is 4 MT NT matrix instructions, ~400-800 cycles for a lone
-                // wave; a ket block comes from the L2 / the memory-side cache in 500-1200): the first PD are requested before the Boys
-                // function and the R table, a buffer is refilled as soon as its MFMAs have issued.  A fragments (LDS) one step ahead.
-                constexpr int PD = MT >= 5 ? 3 : (MT >= 3 ? 5 : 6);
-                double bv[PD][4], avA[MT];
+                auto scale = [&](const unsigned recw, const double (&raw)[MT], double (&av)[MT]) {
+                    const unsigned fl = recw >> 16;
+                    const double sg = (fl & 2u) ? ((fl & 1u) ? -pref : pref) : 0.0;          // sign of the ket order, scale, validity
 #pragma unroll
-                for (int d = 0; d < PD; ++d) load_b(min(d, KS - 1), bv[d]);
+                    for (int mt = 0; mt < MT; ++mt) av[mt] = sg * raw[mt];
+                };
+                // B fragments and gather records travel PD k-steps ahead of their matrix instructions (a k-step is MT NT of them, 64 cycles
+                // each; a ket block comes from the L2 / the memory-side cache in 500-1200): the first PD are requested before the Boys
+                // function and the R table, a buffer is refilled as soon as its instructions have issued.  The R values of step ks + 1
+                // are read from LDS before the instructions of step ks and scaled after them.
+                constexpr int PD = MT * NT >= 12 ? 3 : (MT * NT >= 6 ? 4 : 6);
+                double bv[PD][NT], avA[MT];
+                uint4 gr[PD];
+#pragma unroll
+                for (int d = 0; d < PD; ++d) { load_b(min(d, KS - 1), bv[d]); gr[d] = gi[64 * min(d + 1, KS - 1)]; }
+                const uint4 gr0 = gi[0];
                 double F[L + 1];
                 qc_boys<L>(alpha * (X * X + Y * Y + Z * Z), a.boys, F);
                 __syncthreads();                  // previous iteration's readers of Rw are done
                 QC_T(1);
                 qc_build_r<L, 64>(Rw, plan, lane, alpha, X, Y, Z, F);
                 QC_T(2);
-                load_a(0, avA);
+                { double raw[MT]; gather(gr0, raw); scale(gr0.w, raw, avA); }
                 for (int ks0 = 0; ks0 < KS; ks0 += PD) {
 #pragma unroll
                     for (int d = 0; d < PD; ++d) {
                         const int ks = ks0 + d;
                         if (ks >= KS) break;
-                        double avB[MT];
-                        load_a(min(ks + 1, KS - 1), avB);
+                        double raw[MT];
+                        const unsigned recw = gr[d].w;
+                        gather(gr[d], raw);       // (k-step ks + 1; past the end: the last one again, unused)
                         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                         for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-                            for (int nt = 0; nt < 4; ++nt)
-                                if (nt < NT) Wacc[mt][nt] = __builtin_amdgcn_mfma_f64_16x16x4f64(avA[mt], bv[d][nt], Wacc[mt][nt], 0, 0, 0);
+                            for (int nt = 0; nt < NT; ++nt)
+                                Wacc[mt][nt] = __builtin_amdgcn_mfma_f64_16x16x4f64(avA[mt], bv[d][nt], Wacc[mt][nt], 0, 0, 0);
                         __builtin_amdgcn_sched_barrier(0);
                         if (ks + PD < KS) load_b(ks + PD, bv[d]);
-#pragma unroll
-                        for (int mt = 0; mt < MT; ++mt) avA[mt] = avB[mt];
+                        gr[d] = gi[64 * min(ks + PD + 1, KS - 1)];
+                        scale(recw, raw, avA);
                     }
                 }
                 QC_T(3);
+                if (last) flush(Et, avE);
                 if (++kl == K_cd) { kl = 0; ++ij; }
             }
-            QC_T(1);
-            if (cur_ij >= 0) flush(cur_ij);
             QC_T(4);
+          };
+          for (int col0 = cbeg; col0 < cend; col0 += 64) {       // this slot's ket columns, 64 at a time
+              switch (min(4, (cend - col0 + 15) / 16)) {
+                  case 1: tile(std::integral_constant<int, 1>{}, col0); break;
+                  case 2: tile(std::integral_constant<int, 2>{}, col0); break;
+                  case 3: tile(std::integral_constant<int, 3>{}, col0); break;
+                  default: tile(std::integral_constant<int, 4>{}, col0); break;
+              }
           }
         } else {
         for (int pass = 0; pass < npass; ++pass) {

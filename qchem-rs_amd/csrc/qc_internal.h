@@ -39,6 +39,15 @@ __host__ __device__ constexpr int qc_nherm(int L) { return (L + 1) * (L + 2) * (
 // enough Hermite functions to fill 16-row tiles.  Measured on H2O/cc-pVTZ and benzene/cc-pVDZ: below these bounds the
 // padded tiles and the lost second slot per wave cost more than the LDS reads they save.
 __host__ __device__ constexpr bool qc_use_mfma(int LAB, int LCD) { return LCD >= 5 && LAB >= 3; }
+// Gather records of the matrix-core classes' step 2 (A operand = R values at h1 + h2): per class (LAB 3..6, LCD 5..6) one 16-byte record
+// per (k-step, lane); classes concatenated in (LAB, LCD) order, class (LAB, LCD) starts at record qc_gidx_off(LAB, LCD)
+__host__ __device__ constexpr int qc_gidx_ksteps(int LCD) { return ((LCD + 1) * (LCD + 2) * (LCD + 3) / 6 + 3) / 4; }
+__host__ __device__ constexpr int qc_gidx_off(int LAB, int LCD) {
+    int o = 0;
+    for (int a = 3; a <= 6; ++a)
+        for (int c = 5; c <= 6; ++c) { if (a == LAB && c == LCD) return o; o += 64 * qc_gidx_ksteps(c); }
+    return o;
+}
 __host__ __device__ constexpr int qc_ncart(int L) { return (L + 1) * (L + 2) / 2; }
 // Hermite index of (t,u,v): grouped by total order N = t+u+v, then t descending, then u descending.
 __host__ __device__ constexpr int qc_hidx(int t, int u, int v) {
@@ -128,7 +137,8 @@ struct qc_system {
     size_t shell_blob_off[5] = {};
     QcPairDesc *d_pairs = nullptr;
     double *d_boys = nullptr;
-    int *d_rplan = nullptr;       // recurrence plans of the Hermite-Coulomb tables (qc_build_rplan)
+    int *d_rplan = nullptr;
+    unsigned *d_gidx = nullptr;   // gather records of the matrix-core classes (qc_build_gidx)       // recurrence plans of the Hermite-Coulomb tables (qc_build_rplan)
     double *d_D = nullptr, *d_G = nullptr;   // 2 * n*n each (alpha/beta or Dj/Dk)
     double *d_Gtmp = nullptr;                // accumulation target: [plane (hi, lo)][replica][spin][n*n]
     double *d_Gred = nullptr;                // replicas folded: [plane][spin][n*n]

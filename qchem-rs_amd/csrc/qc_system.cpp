@@ -412,9 +412,8 @@ void qc_build_shards(qc_system *S) {
                            2.0 * ca * cb * cc * cd * hcd + 12.0 * na * nb * nc * nd;
             // LDS doubles one lane group needs for this quartet (layout in qc_fock_kernel.h)
             const int ncd = k.na * k.nb, nab = b.na * b.nb;
-            // (the bra block is read straight from memory; the matrix-core classes keep a 48-double Hermite index table)
-            const int w = qc_region0(b.L + k.L, c.LGC) + nab * ncd + nab + ncd + 2 * (b.na * k.na + b.na * k.nb + b.nb * k.na + b.nb * k.nb) +
-                          (qc_use_mfma(c.LAB, c.LCD) ? 48 : 0);
+            // (the bra block is read straight from memory)
+            const int w = qc_region0(b.L + k.L, c.LGC) + nab * ncd + nab + ncd + 2 * (b.na * k.na + b.na * k.nb + b.nb * k.na + b.nb * k.nb);
             words = std::max(words, w);
         }
         c.slot_words = words;

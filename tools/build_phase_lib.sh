@@ -5,7 +5,7 @@
 #   QCHEM_HIP_LIB=$PWD/qchem-rs_amd/libqchem_hip_dbg.so python tools/class_profile.py h2o_ccpvtz 1
 set -e
 cd "$(dirname "$0")/../qchem-rs_amd/csrc"
-make -s
+make -s -j6
 objs=""
 for l in 0 1 2; do objs="$objs gen/qc_fock_lab$l.o"; done
 for l in 3 4 5 6; do
