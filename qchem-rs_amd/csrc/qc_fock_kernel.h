@@ -131,6 +131,10 @@ __device__ __forceinline__ void qc_step2_dpp_row(double (&W)[qc_nherm(LAB)], con
                                                  std::integer_sequence<int, H1...>) {
     (qc_fmac_bc<(qc_ridx<H1, H2>() & 15)>(W[H1], Rd[qc_ridx<H1, H2>() >> 4], e), ...);
 }
+typedef __attribute__((address_space(3))) double qc_lds_f64;
+// (adds of ONE wave to its own LDS words: the DS unit serves the lanes of an instruction in a fixed order, instructions in program order,
+// so such sums do not depend on timing)
+__device__ __forceinline__ void qc_ds_add(double *p, double v) { (void)__builtin_amdgcn_ds_atomic_fadd_f64((qc_lds_f64 *)p, v); }
 // floor(x / d) for 0 <= x < 2^16, d <= 128 from inv = 1 / d (1 ulp): three instructions instead of the ~35 of a u32 division
 __device__ __forceinline__ int qc_fdiv(int x, float inv) { return (int)(((float)x + 0.5f) * inv); }
 // acc[j] += sum_h E_j[h] W[h] for four rows at once; row j's coefficients sit in the lanes of each 16-lane row (Er[j][h >> 4], lane h & 15)
@@ -336,9 +340,12 @@ __device__ __forceinline__ void qc_fock_body(const QcKernelArgs &a, const QcSlot
         double *tDj_ab = Iblk + nab * ncd, *tDj_cd = tDj_ab + nab;
         double *tK = tDj_cd + ncd;   // per spin: Dk_ac, Dk_ad, Dk_bc, Dk_bd
         const int ktile = na * nc + na * nd + nb * nc + nb * nd;
+        // 64-lane groups digest through LDS accumulators of the six target blocks (see the digestion below)
+        double *const aJcd = tK + 2 * ktile, *const aK = aJcd + ncd;
 
         if (active) {
             for (int i = li; i < nab * ncd; i += C) Iblk[i] = 0.0;
+            if constexpr (LGC == 6) { if (digest) for (int i = li; i < ncd + 2 * ktile; i += C) aJcd[i] = 0.0; }
             if (digest) {   // stage the density tiles this quartet touches
                 for (int i = li; i < nab; i += C) { const int r = qc_fdiv(i, inb); tDj_ab[i] = a.Dj[(size_t)(pb.offa + r) * n + pb.offb + i - r * nb]; }
                 for (int i = li; i < ncd; i += C) { const int r = qc_fdiv(i, ind); tDj_cd[i] = a.Dj[(size_t)(pk.offa + r) * n + pk.offb + i - r * nd]; }
@@ -720,8 +727,76 @@ __device__ __forceinline__ void qc_fock_body(const QcKernelArgs &a, const QcSlot
                 }
             } else {
                 double *G0 = a.G0 + rep, *G1 = a.G1 + rep;
+                const double fj = 2.0 * f, fk = -a.cK * f;
+                if (LGC == 6 && nab >= 16) {
+                    // One wave, one slot, a bra with enough function pairs to occupy the lanes.  A lane owns a bra function pair (i,j) and walks along the slot's ket columns (k,l), the same
+                    // column in every lane: J_ab and, between two changes of k, K_ac and K_bc accumulate in registers; K_ad and K_bd go to
+                    // LDS accumulators per column (lanes sharing i or j meet there: na- or nb-way), J_cd is a second, column-owned pass.
+                    // Afterwards every touched accumulator leaves as one global atomic.  (The per-target loops of the narrow groups
+                    // below are chains of dependent FMAs with most lanes idle at these block shapes: 14 us for a 49 x 13 block, more
+                    // than its two contractions; one LDS atomic per product, tried first, queues up to 32 lanes on one word: 8 us.)
+                    const double *t_ac = tK, *t_ad = t_ac + na * nc, *t_bc = t_ad + na * nd, *t_bd = t_bc + nb * nc;
+                    double *k_ac = aK, *k_ad = k_ac + na * nc, *k_bc = k_ad + na * nd, *k_bd = k_bc + nb * nc;
+                    const int k0 = qc_fdiv(cbeg, ind), l0 = cbeg - k0 * nd;
+                    for (int ab = lane; ab < nab; ab += 64) {
+                        const int i = qc_fdiv(ab, inb), j = ab - i * nb;
+                        const double *Irow = Iblk + ab * ncd;
+                        double jab = 0.0, aik[2] = {0.0, 0.0}, ajk[2] = {0.0, 0.0};
+                        int k = k0, l = l0;
+                        for (int c = cbeg; c < cend; ++c) {
+                            const double v = Irow[c];
+                            jab = fma(v, tDj_cd[c], jab);
+                            aik[0] = fma(v, t_bd[j * nd + l], aik[0]);
+                            ajk[0] = fma(v, t_ad[i * nd + l], ajk[0]);
+                            qc_ds_add(&k_ad[i * nd + l], v * t_bc[j * nc + k]);
+                            qc_ds_add(&k_bd[j * nd + l], v * t_ac[i * nc + k]);
+                            if (uhf) {
+                                aik[1] = fma(v, t_bd[ktile + j * nd + l], aik[1]);
+                                ajk[1] = fma(v, t_ad[ktile + i * nd + l], ajk[1]);
+                                qc_ds_add(&k_ad[ktile + i * nd + l], v * t_bc[ktile + j * nc + k]);
+                                qc_ds_add(&k_bd[ktile + j * nd + l], v * t_ac[ktile + i * nc + k]);
+                            }
+                            if (++l == nd || c + 1 == cend) {
+                                qc_ds_add(&k_ac[i * nc + k], aik[0]); qc_ds_add(&k_bc[j * nc + k], ajk[0]);
+                                if (uhf) { qc_ds_add(&k_ac[ktile + i * nc + k], aik[1]); qc_ds_add(&k_bc[ktile + j * nc + k], ajk[1]); }
+                                aik[0] = aik[1] = ajk[0] = ajk[1] = 0.0;
+                                l = 0; ++k;
+                            }
+                        }
+                        const size_t o = (size_t)(pb.offa + i) * n + pb.offb + j;
+                        qc_gadd2(&G0[o], &G1[o], uhf, fj * jab, fxscale, a.fx_lo);
+                    }
+                    {   // J_cd: lane = (part of the bra range, column)
+                        const int wc = cend - cbeg, parts = wc >= 64 ? 1 : 64 / wc, chunk = (nab + parts - 1) / parts;
+                        const float iwc = __builtin_amdgcn_rcpf((float)wc);
+                        for (int y = lane; y < wc * parts; y += 64) {
+                            const int part = qc_fdiv(y, iwc), c = cbeg + y - part * wc;
+                            const int ab1 = min(nab, (part + 1) * chunk);
+                            double s0 = 0.0, s1 = 0.0;
+                            int ab = part * chunk;
+                            for (; ab + 1 < ab1; ab += 2) { s0 = fma(Iblk[ab * ncd + c], tDj_ab[ab], s0); s1 = fma(Iblk[(ab + 1) * ncd + c], tDj_ab[ab + 1], s1); }
+                            if (ab < ab1) s0 = fma(Iblk[ab * ncd + c], tDj_ab[ab], s0);
+                            qc_ds_add(&aJcd[c], s0 + s1);
+                        }
+                    }
+                    __syncthreads();
+                    QC_T(7);
+                    for (int cd = cbeg + lane; cd < cend; cd += 64) {
+                        const int r = qc_fdiv(cd, ind);
+                        const size_t o = (size_t)(pk.offa + r) * n + pk.offb + cd - r * nd;
+                        qc_gadd2(&G0[o], &G1[o], uhf, fj * aJcd[cd], fxscale, a.fx_lo);
+                    }
+                    for (int s = 0; s < (uhf ? 2 : 1); ++s) {
+                        double *Gs = s ? G1 : G0;
+                        const double *w_ac = aK + s * ktile, *w_ad = w_ac + na * nc, *w_bc = w_ad + na * nd, *w_bd = w_bc + nb * nc;
+                        // (a column split leaves most exchange targets of a slot untouched: exact zeros stay home)
+                        for (int x = lane; x < na * nc; x += 64) { const int i = qc_fdiv(x, inc); const double v = w_ac[x]; if (v != 0.0) qc_gadd(&Gs[(size_t)(pb.offa + i) * n + pk.offa + x - i * nc], fk * v, fxscale, a.fx_lo); }
+                        for (int x = lane; x < na * nd; x += 64) { const int i = qc_fdiv(x, ind); const double v = w_ad[x]; if (v != 0.0) qc_gadd(&Gs[(size_t)(pb.offa + i) * n + pk.offb + x - i * nd], fk * v, fxscale, a.fx_lo); }
+                        for (int x = lane; x < nb * nc; x += 64) { const int j = qc_fdiv(x, inc); const double v = w_bc[x]; if (v != 0.0) qc_gadd(&Gs[(size_t)(pb.offb + j) * n + pk.offa + x - j * nc], fk * v, fxscale, a.fx_lo); }
+                        for (int x = lane; x < nb * nd; x += 64) { const int j = qc_fdiv(x, ind); const double v = w_bd[x]; if (v != 0.0) qc_gadd(&Gs[(size_t)(pb.offb + j) * n + pk.offb + x - j * nd], fk * v, fxscale, a.fx_lo); }
+                    }
+                } else {
                 // J blocks: Gt_ab += 2f sum_cd I D_cd ; Gt_cd += 2f sum_ab I D_ab   (final G = Gt + Gt^T)
-                const double fj = 2.0 * f;
                 // (integrals outside [cbeg, cend) are not this slot's: the loops run over its columns only)
                 for (int ab = li; ab < nab; ab += C) {
                     double s = 0.0;
@@ -740,7 +815,6 @@ __device__ __forceinline__ void qc_fock_body(const QcKernelArgs &a, const QcSlot
                     qc_gadd2(&G0[o], &G1[o], uhf, fj * s, fxscale, a.fx_lo);
                 }
                 // K blocks: Gt_ac -= cK f sum_bd I D_bd, and the ad / bc / bd images
-                const double fk = -a.cK * f;
                 for (int s = 0; s < (uhf ? 2 : 1); ++s) {
                     double *Gs = s ? G1 : G0;
                     const double *t_ac = tK + s * ktile, *t_ad = t_ac + na * nc, *t_bc = t_ad + na * nd, *t_bd = t_bc + nb * nc;
@@ -781,6 +855,7 @@ __device__ __forceinline__ void qc_fock_body(const QcKernelArgs &a, const QcSlot
                         qc_gadd(&Gs[(size_t)(pb.offb + j) * n + pk.offb + l], fk * acc, fxscale, a.fx_lo);
                     }
                 }
+                }
             }
         }
         __syncthreads();   // the slot regions are reused by the next batch of slots
@@ -788,8 +863,8 @@ __device__ __forceinline__ void qc_fock_body(const QcKernelArgs &a, const QcSlot
     }
 #ifdef QC_PHASE_TIMING
     if (MFMA && lane == 0 && blk < 2 && digest)
-        printf("[phase] <%d,%d,%d> blk %d/%d nslots %d: setup %lld  boys+hdr %lld  rtab %lld  kloop %lld  flush %lld  tail %lld  digest %lld  (10 ns units)\n", LAB, LCD, LGC, blk, nblk, nslots,
-               tph[0], tph[1], tph[2], tph[3], tph[4], tph[5], tph[6]);
+        printf("[phase] <%d,%d,%d> blk %d/%d nslots %d: setup %lld  boys+hdr %lld  rtab %lld  kloop %lld  flush %lld  tail %lld  products %lld  atomics %lld  (10 ns units)\n", LAB, LCD, LGC, blk, nblk, nslots,
+               tph[0], tph[1], tph[2], tph[3], tph[4], tph[5], tph[7], tph[6]);
 #endif
 #undef QC_T
 }

@@ -413,7 +413,9 @@ void qc_build_shards(qc_system *S) {
             // LDS doubles one lane group needs for this quartet (layout in qc_fock_kernel.h)
             const int ncd = k.na * k.nb, nab = b.na * b.nb;
             // (the bra block is read straight from memory)
-            const int w = qc_region0(b.L + k.L, c.LGC) + nab * ncd + nab + ncd + 2 * (b.na * k.na + b.na * k.nb + b.nb * k.na + b.nb * k.nb);
+            const int kt = b.na * k.na + b.na * k.nb + b.nb * k.na + b.nb * k.nb;
+            // (I block, density tiles; 64-lane groups: + accumulators of the six target blocks)
+            const int w = qc_region0(b.L + k.L, c.LGC) + nab * ncd + nab + ncd + 2 * kt + (c.LGC == 6 ? ncd + 2 * kt : 0);
             words = std::max(words, w);
         }
         c.slot_words = words;
