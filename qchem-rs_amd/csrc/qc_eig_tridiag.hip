@@ -183,8 +183,10 @@ __global__ __launch_bounds__(TRI_THREADS) void qc_tridiag_kernel(int n, int ld, 
 // buffered so that two barriers per step suffice), and the two O(n^2) phases are unpredicated FMAs on registers: columns that
 // are already finished meet v_j = 0 (their stale register contents stay finite - each step adds a bounded multiple of p_j).
 // What limits a step is the instruction count of the 16 waves on the CU's four SIMDs, hence the bare loops.
-constexpr int TR_U = 8;                                  // column pairs per lane: 8 lanes * 2 * 8 = 128
-__global__ __launch_bounds__(TRI_THREADS) void qc_tridiag_reg_kernel(int n, const double *__restrict__ Ain, double rel_pert, double *__restrict__ Vr,
+// TR_U column pairs per lane: 8 lanes * 2 * TR_U columns, as many rows, 128 TR_U threads (TR_U = 8: n <= 128 on 16 waves; TR_U = 4: n <= 64
+// on 8 waves - half the FMAs of a step and half the waves at its two barriers; H2O/cc-pVTZ, n = 58, is such a matrix)
+template <int TR_U>
+__global__ __launch_bounds__(128 * TR_U) void qc_tridiag_reg_kernel(int n, const double *__restrict__ Ain, double rel_pert, double *__restrict__ Vr,
                                                                       double *__restrict__ tri) {
     __shared__ double2 vbuf[2][64], pbuf[2][64];
     __shared__ double rowbuf[128], sc[2][4], red[16];
@@ -206,7 +208,7 @@ __global__ __launch_bounds__(TRI_THREADS) void qc_tridiag_reg_kernel(int n, cons
     if (tid < 64) { vbuf[0][tid] = vbuf[1][tid] = pbuf[0][tid] = pbuf[1][tid] = make_double2(0.0, 0.0); }
     __syncthreads();
     amax = 0.0;
-    for (int k = 0; k < TRI_THREADS / 64; ++k) amax = fmax(amax, red[k]);
+    for (int k = 0; k < 2 * TR_U; ++k) amax = fmax(amax, red[k]);
     const double pert = rel_pert * amax * pert_unit;
 #pragma unroll
     for (int u = 0; u < TR_U; ++u) {
@@ -226,7 +228,7 @@ __global__ __launch_bounds__(TRI_THREADS) void qc_tridiag_reg_kernel(int n, cons
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");      // same wave: the DS unit serves its operations in order
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-            const double xa = rowbuf[lane], xb = rowbuf[lane + 64];
+            const double xa = rowbuf[lane], xb = TR_U > 4 ? rowbuf[lane + 64] : 0.0;
             const double s2 = wave_sum((lane > k + 1 ? xa * xa : 0.0) + (lane + 64 > k + 1 ? xb * xb : 0.0));
             const double x0 = rowbuf[k + 1], dk = rowbuf[k];
             double beta = x0, t = 0.0, inv = 0.0;
@@ -487,8 +489,10 @@ int qc_eig_tridiag_start(hipStream_t st, int n, const double *dA, double *dX0, d
     if ((size_t)n * ld * sizeof(double) + small > (size_t)QC_LDS_MAX - 1024) ld = n;
     const size_t lds_a = (size_t)n * ld * sizeof(double) + small;
     static const bool no_reg = getenv("QC_TRI_LDS") != nullptr;       // A/B switch
-    if (n <= TRI_TEAM * 2 * TR_U && !no_reg)
-        hipLaunchKernelGGL(qc_tridiag_reg_kernel, dim3(1), dim3(TRI_THREADS), 0, st, n, dA, rel_pert, Vr, tri);
+    if (n <= 64 && !no_reg)
+        hipLaunchKernelGGL(qc_tridiag_reg_kernel<4>, dim3(1), dim3(512), 0, st, n, dA, rel_pert, Vr, tri);
+    else if (n <= 128 && !no_reg)
+        hipLaunchKernelGGL(qc_tridiag_reg_kernel<8>, dim3(1), dim3(1024), 0, st, n, dA, rel_pert, Vr, tri);
     else if (lds_a <= (size_t)QC_LDS_MAX - 1024)
         hipLaunchKernelGGL(qc_tridiag_kernel<true>, dim3(1), dim3(TRI_THREADS), lds_a, st, n, ld, dA, rel_pert, (double *)nullptr, Vr, tri);
     else        // matrix in global memory (Zg's storage is free until the next kernel)
