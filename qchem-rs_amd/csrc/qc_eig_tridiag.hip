@@ -177,42 +177,52 @@ __global__ __launch_bounds__(TRI_THREADS) void qc_tridiag_kernel(int n, int ld, 
     }
 }
 
-// ---- 1b. the same for n <= 128 with the matrix in REGISTERS: team r (8 lanes) owns row r, lane l of it the column pairs
-// (2 l, 2 l + 1) + 16 u.  The LDS kernel above moves the trailing block through the LDS port three times per step (48 m^2 bytes)
-// and waits for every one of those loads; here a step touches LDS only for vectors (the row being eliminated, v, p; double-
-// buffered so that two barriers per step suffice), and the two O(n^2) phases are unpredicated FMAs on registers: columns that
-// are already finished meet v_j = 0 (their stale register contents stay finite - each step adds a bounded multiple of p_j).
-// What limits a step is the instruction count of the 16 waves on the CU's four SIMDs, hence the bare loops.
-// TR_U column pairs per lane: 8 lanes * 2 * TR_U columns, as many rows, 128 TR_U threads (TR_U = 8: n <= 128 on 16 waves; TR_U = 4: n <= 64
-// on 8 waves - half the FMAs of a step and half the waves at its two barriers; H2O/cc-pVTZ, n = 58, is such a matrix)
-template <int TR_U>
-__global__ __launch_bounds__(128 * TR_U) void qc_tridiag_reg_kernel(int n, const double *__restrict__ Ain, double rel_pert, double *__restrict__ Vr,
-                                                                      double *__restrict__ tri) {
-    __shared__ double2 vbuf[2][64], pbuf[2][64];
-    __shared__ double rowbuf[128], sc[2][4], red[16];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, tl = tid & (TRI_TEAM - 1), row = tid / TRI_TEAM;
+// ---- 1b. the same with the matrix in REGISTERS: team r (TEAM lanes) owns row r, lane l of it the column pairs (2 l, 2 l + 1) + 2 TEAM u,
+// u < TR_U.  The LDS kernel above moves the trailing block through the LDS port three times per step (48 m^2 bytes) and waits for every one
+// of those loads; here a step touches LDS only for vectors (the row being eliminated, v, p; double-buffered so that two barriers per step
+// suffice), and the two O(n^2) phases are unpredicated FMAs on registers: columns that are already finished meet v_j = 0 (their stale
+// register contents stay finite - each step adds a bounded multiple of p_j).  What limits a step is the instruction count of the waves on
+// the CU's four SIMDs, hence the bare loops.  Instances (2 TEAM TR_U columns, as many rows, TEAM threads each):
+//   <8, 4>  n <=  64,  512 threads: half the FMAs of a step and half the waves at its two barriers (H2O/cc-pVTZ, n = 58)
+//   <8, 8>  n <= 128, 1024 threads
+//   <4, 24> n <= 192,  768 threads, 48 matrix elements per lane (these sizes ran from global memory before: 2.2 ms at n = 174)
+template <int TEAM> __device__ __forceinline__ double team_sum_t(double v);
+template <> __device__ __forceinline__ double team_sum_t<8>(double v) { return team_sum(v); }
+template <> __device__ __forceinline__ double team_sum_t<4>(double v) {
+    v += dpp_move<DPP_XOR1>(v);
+    v += dpp_move<DPP_XOR2>(v);
+    return v;
+}
+template <int TEAM, int TR_U>
+__global__ __launch_bounds__(2 * TEAM * TR_U * TEAM) void qc_tridiag_reg_kernel(int n, const double *__restrict__ Ain, double rel_pert, double *__restrict__ Vr,
+                                                                                 double *__restrict__ tri) {
+    constexpr int NCOL = 2 * TEAM * TR_U, THREADS = NCOL * TEAM, RPW = 64 / TEAM, NCH = (NCOL + 63) / 64;   // rows per wave; 64-column chunks of a row
+    __shared__ double2 vbuf[2][NCH * 32], pbuf[2][NCH * 32];
+    __shared__ double rowbuf[NCH * 64], sc[2][4], red[16];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, tl = tid & (TEAM - 1), row = tid / TEAM;
     double *d = tri, *e = tri + n, *tau = tri + 2 * n;
     double2 a[TR_U];
     double amax = 0.0;
     const double pert_unit = hash_unit((unsigned long long)row);
 #pragma unroll
     for (int u = 0; u < TR_U; ++u) {
-        const int j = 2 * tl + 16 * u;
+        const int j = 2 * tl + 2 * TEAM * u;
         a[u].x = (row < n && j < n) ? 0.5 * (Ain[(size_t)row * n + j] + Ain[(size_t)j * n + row]) : 0.0;
         a[u].y = (row < n && j + 1 < n) ? 0.5 * (Ain[(size_t)row * n + j + 1] + Ain[(size_t)(j + 1) * n + row]) : 0.0;
         amax = fmax(amax, fmax(fabs(a[u].x), fabs(a[u].y)));
+        if constexpr (TR_U > 8) { if (u % 4 == 3) __builtin_amdgcn_sched_barrier(0); }      // (four loads per pair: not all 96 at once)
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) amax = fmax(amax, __shfl_xor(amax, o, 64));
     if (lane == 0) red[wave] = amax;
-    if (tid < 64) { vbuf[0][tid] = vbuf[1][tid] = pbuf[0][tid] = pbuf[1][tid] = make_double2(0.0, 0.0); }
+    for (int i = tid; i < NCH * 32; i += THREADS) { vbuf[0][i] = vbuf[1][i] = pbuf[0][i] = pbuf[1][i] = make_double2(0.0, 0.0); }
     __syncthreads();
     amax = 0.0;
-    for (int k = 0; k < 2 * TR_U; ++k) amax = fmax(amax, red[k]);
+    for (int k = 0; k < THREADS / 64; ++k) amax = fmax(amax, red[k]);
     const double pert = rel_pert * amax * pert_unit;
 #pragma unroll
     for (int u = 0; u < TR_U; ++u) {
-        const int j = 2 * tl + 16 * u;
+        const int j = 2 * tl + 2 * TEAM * u;
         a[u].x += j == row ? pert : 0.0;
         a[u].y += j + 1 == row ? pert : 0.0;
     }
@@ -220,16 +230,18 @@ __global__ __launch_bounds__(128 * TR_U) void qc_tridiag_reg_kernel(int n, const
     for (int k = 0; k + 2 < n; ++k) {
         double2 *vb = vbuf[k & 1], *pb = pbuf[k & 1];
         double *scb = sc[k & 1];
-        if (wave == (k >> 3)) {                          // (wave-uniform) the wave that holds row k builds the Householder vector
+        if (wave == k / RPW) {                           // (wave-uniform) the wave that holds row k builds the Householder vector
             if (row == k) {
 #pragma unroll
-                for (int u = 0; u < TR_U; ++u) reinterpret_cast<double2 *>(rowbuf)[tl + 8 * u] = a[u];
+                for (int u = 0; u < TR_U; ++u) reinterpret_cast<double2 *>(rowbuf)[tl + TEAM * u] = a[u];
             }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");      // same wave: the DS unit serves its operations in order
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-            const double xa = rowbuf[lane], xb = TR_U > 4 ? rowbuf[lane + 64] : 0.0;
-            const double s2 = wave_sum((lane > k + 1 ? xa * xa : 0.0) + (lane + 64 > k + 1 ? xb * xb : 0.0));
+            double x[NCH], part = 0.0;
+#pragma unroll
+            for (int c = 0; c < NCH; ++c) { x[c] = rowbuf[lane + 64 * c]; part += lane + 64 * c > k + 1 ? x[c] * x[c] : 0.0; }
+            const double s2 = wave_sum(part);
             const double x0 = rowbuf[k + 1], dk = rowbuf[k];
             double beta = x0, t = 0.0, inv = 0.0;
             if (s2 > 0.0) {
@@ -242,27 +254,33 @@ __global__ __launch_bounds__(128 * TR_U) void qc_tridiag_reg_kernel(int n, const
                 t = (beta - x0) * (x0 <= 0.0 ? r : -r);             // (beta - x0) / beta
                 inv = fast_rcp(x0 - beta);
             }
-            const double va = lane <= k ? 0.0 : (lane == k + 1 ? 1.0 : xa * inv);
-            const double vb1 = lane + 64 <= k ? 0.0 : (lane + 64 == k + 1 ? 1.0 : xb * inv);
-            reinterpret_cast<double *>(vb)[lane] = va;
-            reinterpret_cast<double *>(vb)[lane + 64] = vb1;
-            if (lane == 0) { scb[0] = t; d[k] = dk; e[k] = beta; tau[k] = t; tri[3 * n + k] = beta * beta; }
             double *vrow = Vr + (size_t)k * n;           // (for the back-transformation kernel; nothing here waits for these stores)
-            if (lane < n) vrow[lane] = va;
-            if (lane + 64 < n) vrow[lane + 64] = vb1;
+#pragma unroll
+            for (int c = 0; c < NCH; ++c) {
+                const int i = lane + 64 * c;
+                const double vv = i <= k ? 0.0 : (i == k + 1 ? 1.0 : x[c] * inv);
+                reinterpret_cast<double *>(vb)[i] = vv;
+                if (i < n) vrow[i] = vv;
+            }
+            if (lane == 0) { scb[0] = t; d[k] = dk; e[k] = beta; tau[k] = t; tri[3 * n + k] = beta * beta; }
         }
         lds_barrier();
         const double t = scb[0];
-        const bool busy = t != 0.0 && 8 * wave + 7 > k;   // (wave-uniform: some row of this wave is still in the trailing block)
-        double2 v[TR_U];
+        const bool busy = t != 0.0 && RPW * wave + RPW - 1 > k;   // (wave-uniform: some row of this wave is still in the trailing block)
+        constexpr bool KEEPV = TR_U <= 8;                 // v_j stays in registers between the phases, or is read again (registers)
+        double2 v[KEEPV ? TR_U : 1];
         double y = 0.0;
         if (busy) {
 #pragma unroll
             for (int u = 0; u < TR_U; ++u) {
-                if (16 * u + 15 > k) { v[u] = vb[tl + 8 * u]; y = fma(a[u].x, v[u].x, fma(a[u].y, v[u].y, y)); }     // (uniform skip of finished columns)
-                else v[u] = make_double2(0.0, 0.0);
+                if (2 * TEAM * u + 2 * TEAM - 1 > k) {        // (uniform skip of finished columns)
+                    const double2 vv = vb[tl + TEAM * u];
+                    if constexpr (KEEPV) v[u] = vv;
+                    y = fma(a[u].x, vv.x, fma(a[u].y, vv.y, y));
+                } else if constexpr (KEEPV) v[u] = make_double2(0.0, 0.0);
+                if constexpr (!KEEPV) { if (u % 6 == 5) __builtin_amdgcn_sched_barrier(0); }   // (keeps the loads of 24 column pairs from being hoisted into 96 more registers)
             }
-            y = t * team_sum(y);
+            y = t * team_sum_t<TEAM>(y);
             if (tl == 0 && row > k) reinterpret_cast<double *>(pb)[row] = y;
         }
         lds_barrier();
@@ -270,16 +288,21 @@ __global__ __launch_bounds__(128 * TR_U) void qc_tridiag_reg_kernel(int n, const
             double pv = 0.0;
 #pragma unroll
             for (int u = 0; u < TR_U; ++u)
-                if (16 * u + 15 > k) { const double2 p2 = pb[tl + 8 * u]; pv = fma(p2.x, v[u].x, fma(p2.y, v[u].y, pv)); }
-            const double K = 0.5 * t * team_sum(pv);
+                if (2 * TEAM * u + 2 * TEAM - 1 > k) {
+                    const double2 p2 = pb[tl + TEAM * u], vv = KEEPV ? v[KEEPV ? u : 0] : vb[tl + TEAM * u];
+                    pv = fma(p2.x, vv.x, fma(p2.y, vv.y, pv));
+                    if constexpr (!KEEPV) { if (u % 6 == 5) __builtin_amdgcn_sched_barrier(0); }
+                }
+            const double K = 0.5 * t * team_sum_t<TEAM>(pv);
             const double vi = reinterpret_cast<double *>(vb)[row], wi = fma(-K, vi, y);
             if (row > k) {
 #pragma unroll
                 for (int u = 0; u < TR_U; ++u)
-                    if (16 * u + 15 > k) {                // (p_j is read a second time rather than kept: registers)
-                        const double2 p2 = pb[tl + 8 * u];
-                        a[u].x -= fma(vi, fma(-K, v[u].x, p2.x), wi * v[u].x);
-                        a[u].y -= fma(vi, fma(-K, v[u].y, p2.y), wi * v[u].y);
+                    if (2 * TEAM * u + 2 * TEAM - 1 > k) {                // (p_j is read a second time rather than kept: registers)
+                        const double2 p2 = pb[tl + TEAM * u], vv = KEEPV ? v[KEEPV ? u : 0] : vb[tl + TEAM * u];
+                        a[u].x -= fma(vi, fma(-K, vv.x, p2.x), wi * vv.x);
+                        a[u].y -= fma(vi, fma(-K, vv.y, p2.y), wi * vv.y);
+                        if constexpr (!KEEPV) { if (u % 6 == 5) __builtin_amdgcn_sched_barrier(0); }
                     }
             }
         }
@@ -289,11 +312,11 @@ __global__ __launch_bounds__(128 * TR_U) void qc_tridiag_reg_kernel(int n, const
         double dk = 0.0, ek = 0.0;
 #pragma unroll
         for (int u = 0; u < TR_U; ++u) {
-            const int j = 2 * tl + 16 * u;
+            const int j = 2 * tl + 2 * TEAM * u;
             dk += (j == row ? a[u].x : 0.0) + (j + 1 == row ? a[u].y : 0.0);
             ek += (j == row + 1 ? a[u].x : 0.0) + (j + 1 == row + 1 ? a[u].y : 0.0);
         }
-        dk = team_sum(dk); ek = team_sum(ek);
+        dk = team_sum_t<TEAM>(dk); ek = team_sum_t<TEAM>(ek);
         if (tl == 0) { d[row] = dk; e[row] = row == n - 1 ? 0.0 : ek; tau[row] = 0.0; tri[3 * n + row] = row == n - 1 ? 0.0 : ek * ek; }
     }
 }
@@ -490,9 +513,11 @@ int qc_eig_tridiag_start(hipStream_t st, int n, const double *dA, double *dX0, d
     const size_t lds_a = (size_t)n * ld * sizeof(double) + small;
     static const bool no_reg = getenv("QC_TRI_LDS") != nullptr;       // A/B switch
     if (n <= 64 && !no_reg)
-        hipLaunchKernelGGL(qc_tridiag_reg_kernel<4>, dim3(1), dim3(512), 0, st, n, dA, rel_pert, Vr, tri);
+        hipLaunchKernelGGL((qc_tridiag_reg_kernel<8, 4>), dim3(1), dim3(512), 0, st, n, dA, rel_pert, Vr, tri);
     else if (n <= 128 && !no_reg)
-        hipLaunchKernelGGL(qc_tridiag_reg_kernel<8>, dim3(1), dim3(1024), 0, st, n, dA, rel_pert, Vr, tri);
+        hipLaunchKernelGGL((qc_tridiag_reg_kernel<8, 8>), dim3(1), dim3(1024), 0, st, n, dA, rel_pert, Vr, tri);
+    else if (n <= 192 && !no_reg)
+        hipLaunchKernelGGL((qc_tridiag_reg_kernel<4, 24>), dim3(1), dim3(768), 0, st, n, dA, rel_pert, Vr, tri);
     else if (lds_a <= (size_t)QC_LDS_MAX - 1024)
         hipLaunchKernelGGL(qc_tridiag_kernel<true>, dim3(1), dim3(TRI_THREADS), lds_a, st, n, ld, dA, rel_pert, (double *)nullptr, Vr, tri);
     else        // matrix in global memory (Zg's storage is free until the next kernel)
