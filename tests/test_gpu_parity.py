@@ -575,3 +575,26 @@ def test_cli_rhf_and_uhf_end_to_end(capsys):
     assert lines[-2].startswith("<S^2>: 2.0") and abs(doc["total_energy"] - ref["total_energy"]) < 1e-4
     assert abs(doc["iterations"] - ref["iterations"]) <= 3
     assert cli.main(["rhf", "-b", b("STO-3G"), "-m", m("water"), "--max-iterations", "1", "--epsilon", "1e-14"]) == 101
+
+
+def test_fock_cartesian_f_shells_wide_ket_blocks():
+    """Every shell of water/cc-pVTZ taken as Cartesian (n = 65): f.f pairs have 100 function pairs - more than the 64 lanes of a
+    group, so the matrix-core classes run their second column pass and the 64-lane digestion its wide-block branches - and d.d
+    pairs 36.  G (RHF and UHF) against the dense contraction of the oracle's tensor for the same shells."""
+    import qchem_rs_amd as q
+    from oracle.oracle import Oracle
+    m = load_system("water", "cc-pVTZ")
+    m.shell_pure[:] = 0
+    s, o = q.System(m), Oracle(m)
+    assert s.n == 65
+    I = o.eri()
+    D = _rand_sym(s.n, 5)
+    G_ref = o.g_rhf(D, I)
+    scale = max(1.0, np.abs(G_ref).max())
+    assert np.abs(s.fock_rhf(D) - G_ref).max() < TOL_INT * scale
+    Da, Db = _rand_sym(s.n, 6), _rand_sym(s.n, 7)
+    Ga, Gb = s.fock_uhf(Da, Db)
+    assert np.abs(Ga - o.g_uhf(Da, Db, I)).max() < TOL_INT * scale
+    assert np.abs(Gb - o.g_uhf(Db, Da, I)).max() < TOL_INT * scale
+    assert np.abs(s.eri() - I).max() < TOL_INT
+    s.close()
