@@ -36,7 +36,7 @@ __device__ __forceinline__ void qc_boys_lds(double x, const double *__restrict__
     if (x < QC_BOYS_XMAX) {
         const int k = (int)(x * (1.0 / QC_BOYS_DX) + 0.5);
         const double d = k * QC_BOYS_DX - x;
-        const double *__restrict__ r = T + k * QC_BM_TROW;
+        const double *__restrict__ r = T + __umul24(k, QC_BM_TROW);   // (24-bit multiply: full rate, the 32-bit one a quarter)
         double f = r[7];
         f = fma(f, d, r[6]);
         f = fma(f, d, r[5]);
@@ -61,7 +61,7 @@ __device__ __forceinline__ void qc_boys_lds(double x, const double *__restrict__
             for (int n = L; n > 0; --n) F[n - 1] = fma(x2, F[n], ex) * (1.0 / (2 * n - 1));
         }
     } else {
-        const double t = rsqrt(x);
+        const double t = qc_rsqrt(x);
         F[0] = (0.5 * 1.7724538509055160273) * t;
         if constexpr (L > 0) {
             const double hr = 0.5 * (t * t);
@@ -130,7 +130,7 @@ __device__ __forceinline__ void qc_bm_pass(const double *__restrict__ pd, const 
 #pragma unroll
         for (int u = 0; u < NIJ; ++u) {
             const double X = Px[u] - ck.y, Y = Py[u] - ck.z, Z = Pz[u] - ck.w;
-            const double pref = rsqrt(p[u] + q);
+            const double pref = qc_rsqrt(p[u] + q);
             const double alpha = p[u] * q * (pref * pref);
             double F[L + 1], Rr[qc_nherm(L)];
             qc_boys_lds<L>(alpha * (X * X + Y * Y + Z * Z), Tb, F);

@@ -131,6 +131,13 @@ __device__ __forceinline__ void qc_step2_dpp_row(double (&W)[qc_nherm(LAB)], con
                                                  std::integer_sequence<int, H1...>) {
     (qc_fmac_bc<(qc_ridx<H1, H2>() & 15)>(W[H1], Rd[qc_ridx<H1, H2>() >> 4], e), ...);
 }
+// 1 / sqrt(x) for finite x > 0: hardware estimate + one third-order correction (the library's rsqrt without its class check and selects:
+// 6 instructions instead of 10, once or twice per primitive quartet in every kernel)
+__device__ __forceinline__ double qc_rsqrt(double x) {
+    const double y = __builtin_amdgcn_rsq(x);
+    const double e = fma(-(x * y), y, 1.0);
+    return fma(y * e, fma(e, 0.375, 0.5), y);
+}
 typedef __attribute__((address_space(3))) double qc_lds_f64;
 // (adds of ONE wave to its own LDS words: the DS unit serves the lanes of an instruction in a fixed order, instructions in program order,
 // so such sums do not depend on timing)
@@ -232,7 +239,7 @@ __device__ __forceinline__ void qc_boys(double x, const double *__restrict__ tab
             for (int n = L; n > 0; --n) F[n - 1] = fma(x2, F[n], ex) * (1.0 / (2 * n - 1));
         }
     } else {
-        const double t = rsqrt(x);
+        const double t = qc_rsqrt(x);
         F[0] = (0.5 * 1.7724538509055160273) * t;
         if constexpr (L > 0) {
             const double hr = 0.5 * (t * t);
@@ -459,7 +466,7 @@ __device__ __forceinline__ void qc_fock_body(const QcKernelArgs &a, const QcSlot
                 if (last) load_e(Et, 0, avE);
                 const double p = cb.x, q = ck.x;
                 const double X = cb.y - ck.y, Y = cb.z - ck.z, Z = cb.w - ck.w;
-                const double pref = rsqrt(p + q);
+                const double pref = qc_rsqrt(p + q);
                 const double alpha = p * q * (pref * pref);
                 // Operand fragments of k-step ks.  B = the column tiles of the ket block (plain loads, clamped: rows past HCD meet a zero
                 // A value, columns past ncd are never read back); A = the gathered, signed R values: which LDS word lane l reads for row
@@ -598,7 +605,7 @@ __device__ __forceinline__ void qc_fock_body(const QcKernelArgs &a, const QcSlot
                         const double4 ck = *reinterpret_cast<const double4 *>(ketBase + (size_t)klC * strideK);
                         const double p = cb.x, q = ck.x;
                         const double X = cb.y - ck.y, Y = cb.z - ck.z, Z = cb.w - ck.w;
-                        const double pref = rsqrt(p + q);
+                        const double pref = qc_rsqrt(p + q);
                         const double alpha = p * q * (pref * pref);
                         double F[L + 1], Rr[qc_nherm(L)];
                         qc_boys<L>(alpha * (X * X + Y * Y + Z * Z), a.boys, F);
@@ -684,7 +691,7 @@ __device__ __forceinline__ void qc_fock_body(const QcKernelArgs &a, const QcSlot
                 const double p = cb.x, q = ck.x;
                 const double X = cb.y - ck.y, Y = cb.z - ck.z, Z = cb.w - ck.w;
                 const double pq_sum = p + q;
-                const double pref = rsqrt(pq_sum);                 // 1 / sqrt(p + q)
+                const double pref = qc_rsqrt(pq_sum);                 // 1 / sqrt(p + q)
                 const double alpha = p * q * (pref * pref);
                 double F[L + 1];
                 qc_boys<L>(alpha * (X * X + Y * Y + Z * Z), a.boys, F);
