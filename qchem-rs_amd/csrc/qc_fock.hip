@@ -250,7 +250,8 @@ static int launch_segments(qc_system *S, int unit, const std::vector<Seg> &segs,
         int grid = 0, k = 0;
         for (const Seg &sg : segs) {
             // persistent workgroups of `nw` waves: at most ~12 waves per CU, each wave strides through the bundle list
-            grid += std::min((sg.nslots + nw - 1) / nw, 256 * 12 / nw);
+            static const int capw = getenv("QC_BM_WAVES_PER_CU") ? std::max(4, atoi(getenv("QC_BM_WAVES_PER_CU"))) : 12;   // (A/B switch)
+            grid += std::min((sg.nslots + nw - 1) / nw, 256 * capw / nw);
             t.seg_end[k] = grid; t.seg_lab[k] = sg.c->LAB; t.seg_bundles[k] = sg.d_bundles; t.seg_ketlist[k] = sg.d_ketlist;
             t.seg_nbundles[k] = sg.nslots; t.seg_iwords[k] = sg.lds / 8;
             t.seg_rows[k] = rows;
