@@ -16,6 +16,7 @@
 //     answer); the refinement then works on the unperturbed matrix and treats what is left as its "strong pairs";
 //   * a start that is not good enough (orthogonality > 1e-3, clusters the refinement cannot rotate) is detected by the
 //     refinement's control word and answered with the Jacobi kernels - correctness never rests on this file.
+#include <algorithm>
 #include <atomic>
 #include <cstdlib>
 
@@ -454,41 +455,64 @@ __global__ __launch_bounds__(TE_WAVES * 64) void qc_tri_eig_kernel(int n, const 
     if (lane == 0) { out[j] = l; out[n + j] = rsqrt(nrm); }
 }
 
-// ---- 3. X0 = Q Z, Q = H_0 H_1 ... H_{n-3}: one wave per eigenvector, its components in registers (NPL per lane), reflectors from L2
+// ---- 3. X0 = Q Z, Q = H_0 H_1 ... H_{n-3}: one wave per eigenvector, its components in registers (NPL per lane).  The reflector rows come
+// through LDS: the workgroup (BT_WAVES eigenvectors) loads a chunk of rows with all its threads, eight loads in flight per thread, and
+// every wave then walks through the chunk.  (With the rows read from L2 one step ahead, a step - a dot product, a wave reduction, an
+// axpy - waited ~0.4 us for its reflector: 24 / 34 us at n = 58 / 114.)
+constexpr int BT_WAVES = 8;
+constexpr int BT_LDS_BYTES = 120 * 1024;
 template <int NPL>
-__global__ __launch_bounds__(256) void qc_backtransform_kernel(int n, const double *__restrict__ Zg, const double *__restrict__ Vr, const double *__restrict__ tri,
-                                                               const double *__restrict__ evn, double *__restrict__ X0) {
-    const int lane = threadIdx.x & 63, j = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (j >= n) return;
+__global__ __launch_bounds__(BT_WAVES * 64) void qc_backtransform_kernel(int n, int rows_per_chunk, const double *__restrict__ Zg, const double *__restrict__ Vr,
+                                                                         const double *__restrict__ tri, const double *__restrict__ evn, double *__restrict__ X0) {
+    extern __shared__ double bt_sh[];                      // [rows_per_chunk][n] reflector rows, then [rows_per_chunk] tau
+    constexpr int NT = BT_WAVES * 64;
+    const int tid = threadIdx.x, lane = tid & 63, j = blockIdx.x * BT_WAVES + (tid >> 6);
+    const bool act = j < n;                                // (no early exit: the chunk loop has barriers)
     const double *tau = tri + 2 * n;
-    const double sc = evn[n + j];
+    double *const sh_tau = bt_sh + (size_t)rows_per_chunk * n;
+    const double sc = act ? evn[n + j] : 0.0;
     double x[NPL];
 #pragma unroll
-    for (int u = 0; u < NPL; ++u) { const int i = lane + 64 * u; x[u] = i < n ? Zg[(size_t)i * n + j] * sc : 0.0; }
-    double vn[NPL];
-    int k = n - 3;
-    if (k >= 0) {
+    for (int u = 0; u < NPL; ++u) { const int i = lane + 64 * u; x[u] = (act && i < n) ? Zg[(size_t)i * n + j] * sc : 0.0; }
+    for (int khi = n - 3; khi >= 0; khi -= rows_per_chunk) {
+        const int klo = max(0, khi - rows_per_chunk + 1), cnt = khi - klo + 1, total = cnt * n;
+        const double *__restrict__ src = Vr + (size_t)klo * n;
+        __syncthreads();                                   // the previous chunk's readers are done
+        for (int base = 0; base < total; base += 8 * NT) {
+            double tmp[8];
 #pragma unroll
-        for (int u = 0; u < NPL; ++u) { const int i = lane + 64 * u; vn[u] = i < n ? Vr[(size_t)k * n + i] : 0.0; }
-    }
-    for (; k >= 0; --k) {
-        double vv[NPL];
+            for (int b = 0; b < 8; ++b) { const int i = base + b * NT + tid; tmp[b] = i < total ? src[i] : 0.0; }
 #pragma unroll
-        for (int u = 0; u < NPL; ++u) vv[u] = vn[u];
-        if (k > 0) {
-#pragma unroll
-            for (int u = 0; u < NPL; ++u) { const int i = lane + 64 * u; vn[u] = i < n ? Vr[(size_t)(k - 1) * n + i] : 0.0; }   // next reflector, one step ahead
+            for (int b = 0; b < 8; ++b) { const int i = base + b * NT + tid; if (i < total) bt_sh[i] = tmp[b]; }
         }
-        const double t = tau[k];
-        double s = 0.0;
+        for (int i = tid; i < cnt; i += NT) sh_tau[i] = tau[klo + i];
+        __syncthreads();
+        if (act) {
+            double vn[NPL];
 #pragma unroll
-        for (int u = 0; u < NPL; ++u) s = fma(vv[u], x[u], s);
-        s = t * wave_sum(s);
+            for (int u = 0; u < NPL; ++u) { const int i = lane + 64 * u; vn[u] = i < n ? bt_sh[(size_t)(khi - klo) * n + i] : 0.0; }
+            for (int k = khi; k >= klo; --k) {
+                double vv[NPL];
 #pragma unroll
-        for (int u = 0; u < NPL; ++u) x[u] = fma(-s, vv[u], x[u]);
+                for (int u = 0; u < NPL; ++u) vv[u] = vn[u];
+                if (k > klo) {
+#pragma unroll
+                    for (int u = 0; u < NPL; ++u) { const int i = lane + 64 * u; vn[u] = i < n ? bt_sh[(size_t)(k - 1 - klo) * n + i] : 0.0; }   // next reflector, one step ahead
+                }
+                const double t = sh_tau[k - klo];
+                double s = 0.0;
+#pragma unroll
+                for (int u = 0; u < NPL; ++u) s = fma(vv[u], x[u], s);
+                s = t * wave_sum(s);
+#pragma unroll
+                for (int u = 0; u < NPL; ++u) x[u] = fma(-s, vv[u], x[u]);
+            }
+        }
     }
+    if (act) {
 #pragma unroll
-    for (int u = 0; u < NPL; ++u) { const int i = lane + 64 * u; if (i < n) X0[(size_t)i * n + j] = x[u]; }
+        for (int u = 0; u < NPL; ++u) { const int i = lane + 64 * u; if (i < n) X0[(size_t)i * n + j] = x[u]; }
+    }
 }
 
 }  // namespace
@@ -524,8 +548,19 @@ int qc_eig_tridiag_start(hipStream_t st, int n, const double *dA, double *dX0, d
         hipLaunchKernelGGL(qc_tridiag_kernel<false>, dim3(1), dim3(TRI_THREADS), small, st, n, n, dA, rel_pert, Zg, Vr, tri);
     hipLaunchKernelGGL(qc_tri_eig_kernel, dim3((n + TE_WAVES - 1) / TE_WAVES), dim3(TE_WAVES * 64), (size_t)(TE_WAVES * 2 + 3) * n * sizeof(double), st, n, tri, Zg, evn);
     const int npl = (n + 63) / 64;
-    const dim3 grid((n + 3) / 4), block(256);
-#define QC_BT_CASE(N) case N: hipLaunchKernelGGL(qc_backtransform_kernel<N>, grid, block, 0, st, n, Zg, Vr, tri, evn, dX0); break;
+    const dim3 grid((n + BT_WAVES - 1) / BT_WAVES), block(BT_WAVES * 64);
+    const int rpc = std::max(1, std::min(n - 2, (int)((BT_LDS_BYTES - 8 * n) / (8 * (size_t)n + 8))));     // reflector rows per LDS chunk
+    const size_t bt_lds = ((size_t)rpc * n + rpc) * sizeof(double);
+    {
+        static std::atomic<bool> raised{false};             // (process-wide attribute; the flag only saves the repeated call)
+        if (!raised.load(std::memory_order_acquire)) {
+#define QC_BT_ATTR(N) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(qc_backtransform_kernel<N>), hipFuncAttributeMaxDynamicSharedMemorySize, BT_LDS_BYTES);
+            QC_BT_ATTR(1) QC_BT_ATTR(2) QC_BT_ATTR(3) QC_BT_ATTR(4) QC_BT_ATTR(5) QC_BT_ATTR(6) QC_BT_ATTR(7) QC_BT_ATTR(8)
+#undef QC_BT_ATTR
+            raised.store(true, std::memory_order_release);
+        }
+    }
+#define QC_BT_CASE(N) case N: hipLaunchKernelGGL(qc_backtransform_kernel<N>, grid, block, bt_lds, st, n, rpc, Zg, Vr, tri, evn, dX0); break;
     switch (npl) { QC_BT_CASE(1) QC_BT_CASE(2) QC_BT_CASE(3) QC_BT_CASE(4) QC_BT_CASE(5) QC_BT_CASE(6) QC_BT_CASE(7) QC_BT_CASE(8) default: return QC_ERR_UNSUPPORTED; }
 #undef QC_BT_CASE
     return hipGetLastError() == hipSuccess ? QC_OK : QC_ERR_HIP;
