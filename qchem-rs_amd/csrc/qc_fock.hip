@@ -435,6 +435,56 @@ int qc_launch_fock_classes(qc_system *S, const QcFockArgs &fa, float *class_ms, 
             static const int widths[QC_TUNE_ROUNDS] = {QC_NSTREAMS, QC_NSTREAMS, 5, 4, 6, QC_NSTREAMS};   // of the *next* candidate
             lpt(dur, widths[round]);
         }
+        // local search around the fastest candidate: move one launch to another stream or swap two launches, keep what makes the build
+        // faster (steady-state form of the build, best of two; which kernels disturb each other is not something the longest-first rule
+        // sees).  A fixed pseudo-random sequence; at most QC_TUNE_LOCAL steps of two builds each, and no more than ~0.1 s of them, once
+        // per geometry.
+        {
+            size_t b = 0;
+            for (size_t i = 1; i < total.size(); ++i) if (total[i] < total[b]) b = i;
+            std::vector<int> cur = cand[b];
+            const std::vector<float> w = weight[b];
+            auto measure = [&](const std::vector<int> &assign, float &t) -> int {
+                S->unit_stream = assign; S->unit_weight = w;
+                t = 1e30f;
+                for (int rep = 0; rep < 2; ++rep) {
+                    if (fa.G0) QC_HIP_CHECK(hipMemsetAsync(fa.G0, 0, gbytes, S->stream));
+                    int r = launch_concurrent(ev.data(), false);
+                    if (r != QC_OK) return r;
+                    QC_HIP_CHECK(hipEventSynchronize(ev[1]));
+                    float x = 0.f;
+                    QC_HIP_CHECK(hipEventElapsedTime(&x, ev[0], ev[1]));
+                    t = std::min(t, x);
+                }
+                return QC_OK;
+            };
+            std::vector<int> act;
+            for (size_t u = 0; u < units.size(); ++u) if (!units[u].empty()) act.push_back((int)u);
+            float tcur = 0.f;
+            if ((rc = measure(cur, tcur)) != QC_OK) return rc;
+            unsigned rng = 2463534242u;
+            auto next = [&]() { rng ^= rng << 13; rng ^= rng >> 17; rng ^= rng << 5; return rng >> 4; };
+            float spent = 0.f;
+            for (int step = 0; step < QC_TUNE_LOCAL && act.size() > 1 && (step < 8 || spent < 100.f); ++step) {
+                std::vector<int> trial = cur;
+                const int u = act[next() % act.size()];
+                if (next() & 1) {
+                    const int k = (int)(next() % QC_NSTREAMS);
+                    if (k == trial[u]) continue;
+                    trial[u] = k;
+                } else {
+                    const int v = act[next() % act.size()];
+                    if (trial[v] == trial[u]) continue;
+                    std::swap(trial[u], trial[v]);
+                }
+                float t = 0.f;
+                if ((rc = measure(trial, t)) != QC_OK) return rc;
+                spent += 2.f * t;
+                if (dbg) fprintf(stderr, "[tune] local step %d: %.3f ms (current %.3f)\n", step, t, tcur);
+                if (t < 0.985f * tcur) { cur = trial; tcur = t; }
+            }
+            cand.push_back(cur); weight.push_back(w); total.push_back(tcur);
+        }
         // final: the three fastest candidates again, now as the steady state runs them (no events around the launches),
         // three builds each, best of the three
         std::vector<size_t> rank(total.size());
