@@ -493,6 +493,8 @@ int qc_launch_fock_classes(qc_system *S, const QcFockArgs &fa, float *class_ms, 
         size_t best = rank[0];
         float best_t = 1e30f;
         S->cand_stream.clear(); S->cand_weight.clear(); S->cand_ms.clear(); S->cand_n.clear();
+        std::vector<float> fin_t;
+        std::vector<size_t> fin_c;
         for (size_t r = 0; r < std::min<size_t>(3, rank.size()); ++r) {
             S->unit_stream = cand[rank[r]]; S->unit_weight = weight[rank[r]];
             float tmin = 1e30f;
@@ -506,9 +508,14 @@ int qc_launch_fock_classes(qc_system *S, const QcFockArgs &fa, float *class_ms, 
             }
             if (dbg) fprintf(stderr, "[tune] final cand %zu: %.3f ms\n", rank[r], tmin);
             if (tmin < best_t) { best_t = tmin; best = rank[r]; }
-            // the finalists stay available: inside SCF runs the passes themselves decide between them (qc_fock_feedback)
-            S->cand_stream.push_back(cand[rank[r]]); S->cand_weight.push_back(weight[rank[r]]); S->cand_ms.push_back(0.0); S->cand_n.push_back(0);
-            if (rank[r] == best) S->cand_cur = (int)S->cand_stream.size() - 1;
+            fin_t.push_back(tmin); fin_c.push_back(rank[r]);
+        }
+        // the finalists stay available: inside SCF runs the passes themselves decide between them (qc_fock_feedback) - those within
+        // 10 % of the best, that is: sampling a clearly slower one costs more passes than it can win
+        for (size_t r = 0; r < fin_c.size(); ++r) {
+            if (fin_t[r] > 1.10f * best_t) continue;
+            S->cand_stream.push_back(cand[fin_c[r]]); S->cand_weight.push_back(weight[fin_c[r]]); S->cand_ms.push_back(0.0); S->cand_n.push_back(0);
+            if (fin_c[r] == best) S->cand_cur = (int)S->cand_stream.size() - 1;
         }
         S->unit_stream = cand[best]; S->unit_weight = weight[best];
         S->cand_skip = true;                             // (the time of THIS build contains the tuning)
