@@ -230,8 +230,11 @@ def test_step_api_matches_driver():
     st.close()
 
 
-@pytest.mark.parametrize("n", [2, 7, 24, 58, 114, 150])
+@pytest.mark.parametrize("n", [2, 7, 24, 58, 64, 65, 114, 128, 129, 150, 174, 192, 193, 230])
 def test_sym_eig(n):
+    """utils.rs:15-36 through qc_sym_eig.  The sizes sit on both sides of every kernel switch of the cold path: rotations below 24, the
+    register Householder kernels for n <= 64 / 128 / 192, the LDS- or memory-resident one above; back-transformation in one or several
+    LDS chunks of reflector rows."""
     import qchem_rs_amd as q
     s = q.System(load_system("hydrogen", "STO-3G"))
     A = _rand_sym(n, n)
