@@ -274,7 +274,14 @@ static int launch_segments(qc_system *S, int unit, const std::vector<Seg> &segs,
         ++k;
     }
     t.nseg = k;
-    return launch_tier(unit / 2, unit % 2, grid, (size_t)lds, st, t);
+    // a wide-ket launch made of d.d / f.p-ket buckets only (no basis function above d): the kernel variant without the f-ket bodies
+    int tier = unit % 2;
+    if (tier == 1) {
+        bool only4 = true;
+        for (const Seg &sg : segs) only4 = only4 && sg.c->LCD == 4;
+        if (only4) tier = 2;
+    }
+    return launch_tier(unit / 2, tier, grid, (size_t)lds, st, t);
 }
 
 // Launch units of one build: per bra class LAB, tier 0 (LCD <= 3) and tier 1 (LCD >= 4) of the column kernels, plus

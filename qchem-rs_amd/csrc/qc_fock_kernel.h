@@ -891,12 +891,15 @@ struct QcTierArgs {
     const QcSlot *seg_slots[QC_MAXSEG];
 };
 
+// (TIER 2 = the tier-1 launch of a build without f-ket classes - every segment an LCD = 4 bucket, any basis without f functions: the same
+// launch unit, but a kernel that does not carry the register footprint of the matrix-core bodies and so keeps two waves per SIMD:
+// (ps|dd) of benzene/cc-pVDZ 0.142 -> 0.108 ms, (pp|dd) 0.099 -> 0.081 alone)
 template <int LAB, int TIER>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu((TIER == 0 && LAB <= 2) ? 2 : 1)))
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(((TIER == 0 && LAB <= 2) || TIER == 2) ? 2 : 1)))
 void qc_fock_tier_kernel(const QcTierArgs a) {
     // the high-L tiers are few, long, latency-bound waves: let them win issue arbitration against the many short
     // low-L waves they share a SIMD with
-    if constexpr (TIER == 1) __builtin_amdgcn_s_setprio(3);
+    if constexpr (TIER >= 1) __builtin_amdgcn_s_setprio(3);
     int s = 0;
     while (s + 1 < a.nseg && (int)blockIdx.x >= a.seg_end[s]) ++s;
     const int b0 = s ? a.seg_end[s - 1] : 0;
@@ -906,8 +909,10 @@ void qc_fock_tier_kernel(const QcTierArgs a) {
 #define QC_CASE(LCD, LGC) case ((LCD) << 4 | (LGC)): qc_fock_body<LAB, LCD, LGC>(a.base, slots, nslots, words, blk, nblk); break;
     if constexpr (TIER == 0) {
         switch (a.seg_code[s]) { QC_CASE(2, 4) QC_CASE(3, 4) QC_CASE(3, 5) default: break; }
-    } else {
+    } else if constexpr (TIER == 1) {
         switch (a.seg_code[s]) { QC_CASE(4, 5) QC_CASE(4, 6) QC_CASE(5, 6) QC_CASE(6, 6) default: break; }
+    } else {
+        switch (a.seg_code[s]) { QC_CASE(4, 5) QC_CASE(4, 6) default: break; }
     }
 #undef QC_CASE
 }
