@@ -43,7 +43,7 @@ WORKLOADS = {
 HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.3 TB/s achievable)
 FP64_PEAK_TF = 78.6         # MI355X FP64 vector peak = FP64 matrix (MFMA) peak (MI355X_MICROARCH.md)
 EPS = 1e-10                 # stopping rule of the timed SCF runs (the parity tests' epsilon)
-PROFILE_ROUND = "r02"
+PROFILE_ROUND = "r03"
 
 
 def load(q, key):
@@ -222,18 +222,91 @@ def measure(torch, q, host, key, steps, warmup, world, rank, uid=None, with_unit
     if with_units:
         up = unit_profile(torch, q, sysh, D, reps=3)      # collective when sharded: every rank calls it
         res["roofline"]["kernel"] = "qc_fock_tier_kernel<LAB, TIER> + qc_fock_bm_kernel<LCD, HI>: %d concurrent launches = one Fock build" % len(up["units_alone"])
+        res["roofline"]["n_launches"] = len(up["units_alone"])
         res["roofline"]["fock_build"] = up
     else:
         res["roofline"]["kernel"] = "qc_fock_tier_kernel<LAB, TIER> + qc_fock_bm_kernel<LCD, HI>: the concurrent launches of one Fock build"
     res["roofline"]["shard"] = "rank 0's shard of %d" % world if world > 1 else "all quartets"
     pmc = committed_counters(key)
     if pmc and world == 1:
+        # PMC passes cannot run inside this process: these are the COMMITTED counters of the same workload (separate rocprofv3
+        # --pmc runs, tools/run_profiles.sh), quoted with their source - not a measurement of this run
+        src = "profiles/%s_pmc_%s.json (committed rocprofv3 --pmc passes, not this run)" % (PROFILE_ROUND, key)
         res["roofline"]["traffic"] = pmc.get("fock_build_hbm_bytes")
-        res["roofline"]["traffic_detail"] = pmc.get("fock_build")
-        if "eigensolve" in pmc:
-            res["eigensolve_counters"] = pmc["eigensolve"]
+        res["roofline"]["traffic_source"] = src
+        res["committed_counters"] = {"source": src, "fock_build": pmc.get("fock_build"), "eigensolve": pmc.get("eigensolve")}
     sysh.close()
     return res, mol
+
+
+MAX_LINE_BYTES = 4096      # the driver keeps an ~8 KB tail of stdout: the record must fit with room to spare
+
+
+def _r(x, sig=6):
+    """Numbers on the compact line carry `sig` significant digits (the detail file keeps everything)."""
+    if isinstance(x, float):
+        return float("%.*g" % (sig, x))
+    return x
+
+
+def _compact_roofline(rf):
+    keep = ("bound", "achieved", "peak", "unit", "frac", "traffic", "traffic_source", "kernel_ms", "kernel_alg_bytes",
+            "kernel_alg_flops", "peak_measured", "frac_of_measured")
+    out = {k: _r(rf[k]) for k in keep if k in rf}
+    out["kernel"] = "qc_fock_tier_kernel+qc_fock_bm_kernel (%s launches = 1 Fock build)" % rf.get("n_launches", "all")
+    if "other_roof" in rf:
+        o = rf["other_roof"]
+        out["other_roof"] = {k: _r(o[k]) for k in ("bound", "achieved", "peak", "unit", "frac", "peak_measured", "frac_of_measured") if k in o}
+    return out
+
+
+def _compact_cpu(cb):
+    out = {k: _r(cb[k]) for k in ("value", "unit", "cores", "kind") if k in cb}
+    out["sample"] = cb.get("sample_short", cb.get("sample", ""))[:160]
+    if "one_thread" in cb:
+        out["one_thread_value"] = _r(cb["one_thread"]["value"])
+    if "scf_iter_ms" in cb:
+        out["scf_iter_ms"] = _r(cb["scf_iter_ms"])
+    return out
+
+
+def compact_line(full, detail_path=None):
+    """The ONE stdout line the driver parses: the contract's keys only, < MAX_LINE_BYTES.  Everything else `measure` collects
+    (launches timed alone, per-kernel counters, accumulation A/B, stored mode, the whole benzene block) is in the detail file."""
+    line = {k: _r(full[k]) for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better",
+                                     "scaling", "vs_baseline", "dtype", "data") if k in full}
+    cfg = full.get("config", {})
+    line["config"] = {k: cfg[k] for k in ("workload", "n_basis", "unique_quartets", "quartets_after_schwarz", "passes", "parallelism")
+                      if k in cfg}
+    if "iter_breakdown_ms" in full:
+        line["iter_breakdown_ms"] = {k: _r(v) for k, v in full["iter_breakdown_ms"].items()}
+    if "roofline" in full:
+        line["roofline"] = _compact_roofline(full["roofline"])
+    if "cpu_baseline" in full:
+        line["cpu_baseline"] = _compact_cpu(full["cpu_baseline"])
+    sr = full.get("scaling_reference")
+    if sr:
+        rf = sr.get("roofline", {})
+        line["scaling_reference"] = {
+            "workload": sr["workload"], "n_gpus": sr["n_gpus"], "value": _r(sr["value"]), "ms_per_step": _r(sr["ms_per_step"]),
+            "steps": sr["steps"], "converges_at_pass": sr.get("converges_at_pass"),
+            "fock_build_ms": _r(sr["iter_breakdown_ms"]["fock_build"]), "diis_eig_density_ms": _r(sr["iter_breakdown_ms"]["diis_eig_density"]),
+            "roofline_bound": rf.get("bound"), "roofline_frac": _r(rf.get("frac")),
+        }
+        if "cpu_baseline" in sr:
+            line["scaling_reference"]["cpu_value"] = _r(sr["cpu_baseline"]["value"])
+    if "stored_mode" in full:
+        sm = full["stored_mode"]
+        line["stored_mode"] = {"ms_per_step": _r(sm["ms_per_step"]), "gemv_GBs": _r(sm["gemv_GBs"])}
+    if "rccl" in full:
+        line["rccl"] = str(full["rccl"])[:120]
+    if detail_path:
+        line["detail"] = detail_path
+    n = len(json.dumps(line, separators=(",", ":")))
+    if n >= MAX_LINE_BYTES:                       # never hand the driver a line it cannot keep: shed the optional blocks
+        for k in ("stored_mode", "scaling_reference", "rccl"):
+            line.pop(k, None)
+    return line
 
 
 def self_launch(args):
@@ -344,8 +417,8 @@ def main():
         "iter_breakdown_ms": res["iter_breakdown_ms"],
         "roofline": res["roofline"],
     }
-    if "eigensolve_counters" in res:
-        line["eigensolve_counters"] = res["eigensolve_counters"]
+    if "committed_counters" in res:
+        line["committed_counters"] = res["committed_counters"]
     if world > 1 and rank == 0:
         line["rccl"] = q.rccl_info()
     if world == 1 and not args.no_extras:
@@ -355,12 +428,12 @@ def main():
             r2, m2 = measure(torch, q, host, "c6h6_ccpvdz", k2, 2, 1, 0, None, with_units=True)
             line["scaling_reference"] = {"workload": WORKLOADS["c6h6_ccpvdz"][2] + " direct-SCF iteration", "n_gpus": 1,
                                          "value": r2["value"], "ms_per_step": r2["ms_per_step"], "steps": k2,
-                                         "passes": r2["timed"]["passes_timed"],
+                                         "passes": r2["timed"]["passes_timed"], "converges_at_pass": r2["timed"]["converges_at_pass"],
                                          "iter_breakdown_ms": r2["iter_breakdown_ms"], "unique_quartets": r2["unique_quartets"],
                                          "quartets_after_schwarz": r2["quartets_after_schwarz"], "roofline": r2["roofline"],
                                          "accumulation": accumulation_ab(q, m2, passes=8)}
-            if "eigensolve_counters" in r2:
-                line["scaling_reference"]["eigensolve_counters"] = r2["eigensolve_counters"]
+            if "committed_counters" in r2:
+                line["scaling_reference"]["committed_counters"] = r2["committed_counters"]
             if not args.no_cpu_baseline:      # the oracle on a bounded sample of the same 1.1 M quartets
                 line["scaling_reference"]["cpu_baseline"] = cpu_baseline(m2, budget_s=6.0)
         if key in ("h2o_ccpvtz", "h2o_sto3g", "c6h6_ccpvdz"):
@@ -385,7 +458,14 @@ def main():
         if not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(mol)
     if rank == 0:
-        print(json.dumps(line), flush=True)
+        detail = os.environ.get("QC_BENCH_DETAIL", os.path.join(ROOT, "bench_detail.json"))
+        try:
+            with open(detail, "w") as f:
+                json.dump(line, f, indent=1)
+        except OSError as e:                      # read-only checkout: the compact line is what counts
+            print("bench.py: cannot write %s: %s" % (detail, e), file=sys.stderr)
+            detail = None
+        print(json.dumps(compact_line(line, os.path.relpath(detail, ROOT) if detail else None), separators=(",", ":")), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
