@@ -208,6 +208,11 @@ int qc_fock_profile(qc_system *sys, const double *dD, double *dG, int reps, floa
 int qc_fock_profile_tiers(qc_system *sys, const double *dD, double *dG, int reps, float *unit_ms, int64_t *unit_quartets,
                           double *unit_bytes, double *unit_flops, float *total_ms);
 
+/* Measured ceilings of the device the library runs on (bench.py quotes the roofline against them next to the datasheet peaks;
+ * SURVEY.md App. F): a register-resident v_fma_f64 loop over the whole chip (TFLOP/s) and a 1 GiB -> 1 GiB streaming copy with
+ * 16-byte accesses (GB/s, bytes read + bytes written).  Harness only: no reference counterpart. */
+int qc_measure_peaks(double *fp64_tflops, double *hbm_copy_gbs);
+
 #ifdef __cplusplus
 }
 #endif

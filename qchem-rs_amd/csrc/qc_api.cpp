@@ -343,6 +343,7 @@ int qc_one_electron_gpu(qc_system *S, int which, double *out) {
 int qc_set_stream(qc_system *S, void *hip_stream) {
     if (!S) return QC_ERR_INVALID;
     if (S->own_stream && S->stream) { (void)hipStreamDestroy(S->stream); S->own_stream = false; }
+    S->prepared = false;                    // (the preliminaries of a prepared build were enqueued on the old stream)
     S->stream = (hipStream_t)hip_stream;
     if (!S->stream && S->device_ready) { QC_HIP_CHECK(hipStreamCreateWithFlags(&S->stream, hipStreamNonBlocking)); S->own_stream = true; }
     return QC_OK;
@@ -659,11 +660,11 @@ static int scf_iterate(qc_scf_state *st, double *energy, double *rms_out) {
     const bool multi = S->comm != nullptr;
     double *scal_out = multi ? reinterpret_cast<double *>(W.d_sync) : W.h_scal;
     int *ctl_out = multi ? reinterpret_cast<int *>(W.d_sync + 4) : h_ctl;
-    auto density_and_scalars = [&](int s) -> int {
+    auto density_and_scalars = [&](int s, bool hand_over) -> int {
         if (st->nocc[s] > 0) qc_gemm(sm, n, n, st->nocc[s], st->uhf ? 1.0 : 2.0, st->Cs.p + s * nn, n, false, st->Cs.p + s * nn, n, true, 0.0, st->Dn[s].p, n);
         else QC_HIP_CHECK(hipMemsetAsync(st->Dn[s].p, 0, nn * sizeof(double), sm));
         // energy and rms straight into pinned host memory; the last spin's kernel also hands over and clears the control words
-        qc_energy_rms(sm, n, st->Dn[s].p, st->D[s].p, W.H.p, st->G.p + s * nn, scal_out + 2 * s, s == nspin - 1 ? W.ctl : nullptr, ctl_out);
+        qc_energy_rms(sm, n, st->Dn[s].p, st->D[s].p, W.H.p, st->G.p + s * nn, scal_out + 2 * s, hand_over ? W.ctl : nullptr, ctl_out);
         return QC_OK;
     };
     auto publish_scalars = [&]() -> int {
@@ -680,7 +681,7 @@ static int scf_iterate(qc_scf_state *st, double *energy, double *rms_out) {
         return true;
     };
     if (multi && nspin == 1) QC_HIP_CHECK(hipMemsetAsync(W.d_sync + 2, 0, 2 * sizeof(double), sm));       // unused spin slot
-    for (int s = 0; s < nspin; ++s) if ((rc = density_and_scalars(s)) != QC_OK) return rc;
+    for (int s = 0; s < nspin; ++s) if ((rc = density_and_scalars(s, s == nspin - 1)) != QC_OK) return rc;
     if ((rc = publish_scalars()) != QC_OK) return rc;
     // the next pass's build starts from Dn: its density-only preliminaries run while the host turns around
     auto prepare_next = [&]() -> int { return st->stored ? QC_OK : qc_fock_prepare_device(S, st->Dn[0].p, st->uhf ? st->Dn[1].p : nullptr, st->uhf, st); };
@@ -694,6 +695,14 @@ static int scf_iterate(qc_scf_state *st, double *energy, double *rms_out) {
     if (h_ctl[9] != 0) return QC_EIG_NOT_CONVERGED;
     static const bool dbg = getenv("QC_SCF_DEBUG") != nullptr;
     if (dbg) fprintf(stderr, "[scf] ctl a: %d %d %d %d  b: %d %d %d %d  npass %d %d have_prev %d mode %d cold %d | host enqueue %.0f us, then waited %.0f us\n", h_ctl[0], h_ctl[1], h_ctl[2], h_ctl[3], h_ctl[4], h_ctl[5], h_ctl[6], h_ctl[7], W.npass[0], W.npass[1], (int)W.have_prev[0], W.mode[0], (int)W.cold[0], (th1 - th0) * 1e3, (th2 - th1) * 1e3);
+    if (dbg) {   // the pass's DIIS coefficients (diis.rs:50-51), newest sample first
+        double c[12] = {0};
+        const int m = (int)st->diis[0]->slots.size();
+        (void)hipMemcpy(c, st->diis[0]->d_c, m * sizeof(double), hipMemcpyDeviceToHost);
+        fprintf(stderr, "[scf] diis c:");
+        for (int j = 0; j < m; ++j) fprintf(stderr, " %.3e", c[j]);
+        fprintf(stderr, "\n");
+    }
     float ms_f = 0, ms_l = 0;
     (void)hipEventElapsedTime(&ms_f, st->ev0, st->ev1);
     (void)hipEventElapsedTime(&ms_l, st->ev1, st->ev2);
@@ -707,15 +716,20 @@ static int scf_iterate(qc_scf_state *st, double *energy, double *rms_out) {
         // the refinement wanted rotations (large step, or a degenerate cluster): repeat this spin's eigensolve the careful way
         if (!redo) QC_HIP_CHECK(hipEventRecord(st->ev1, sm));
         if ((rc = roothaan_redo_eig(S, W, st->ws.p + s * n, st->Cs.p + s * nn, s)) != QC_OK) return rc;
-        if ((rc = density_and_scalars(s)) != QC_OK) return rc;
+        if ((rc = density_and_scalars(s, false)) != QC_OK) return rc;
         redo = true;
     }
     if (redo) {
+        // the repeated eigensolves report through the same control words (Jacobi sweeps exhausted: ctl[9]): hand them over again,
+        // whichever spin was repeated, and clear them for the next pass
+        QC_HIP_CHECK(hipMemcpyAsync(ctl_out, W.ctl, 16 * sizeof(int), hipMemcpyDefault, sm));
+        QC_HIP_CHECK(hipMemsetAsync(W.ctl, 0, 16 * sizeof(int), sm));
         if ((rc = publish_scalars()) != QC_OK) return rc;
         if ((rc = prepare_next()) != QC_OK) return rc;                    // (the density changed)
         QC_HIP_CHECK(hipEventRecord(st->ev2, sm));
         QC_HIP_CHECK(wait_event(st->ev2));
         if (!ranks_agree()) return QC_ERR_RCCL;
+        if (h_ctl[9] != 0) return QC_EIG_NOT_CONVERGED;                  // the repeat ran out of sweeps: no vectors to go on with
         float ms_r = 0;
         (void)hipEventElapsedTime(&ms_r, st->ev1, st->ev2);
         ms_l += ms_r;
@@ -824,6 +838,7 @@ int qc_scf_spin_square(qc_scf_state *st, double *s2) {
 int qc_set_accumulation(qc_system *S, int fixed_point) {
     if (!S || (fixed_point != 0 && fixed_point != 1)) return QC_ERR_INVALID;
     S->accum_fx = fixed_point;
+    S->prepared = false;                    // (a prepared build zeroed the planes of the other mode)
     return QC_OK;
 }
 

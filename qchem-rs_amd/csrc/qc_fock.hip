@@ -65,6 +65,7 @@ static int upload_slots(qc_system *S) {
 }
 
 int qc_device_reshard(qc_system *S) {
+    S->prepared = false;                    // a build prepared for the old work lists must not skip the fork of the next one
     S->unit_ms.clear(); S->unit_stream.clear();
     S->cand_stream.clear(); S->cand_weight.clear(); S->cand_ms.clear(); S->cand_n.clear(); S->cand_frozen = false; S->cand_skip = false; S->cand_cur = 0;
     qc_build_shards(S);
@@ -527,6 +528,7 @@ int qc_launch_fock_classes(qc_system *S, const QcFockArgs &fa, float *class_ms, 
         S->unit_stream = cand[best]; S->unit_weight = weight[best];
         S->cand_skip = true;                             // (the time of THIS build contains the tuning)
         if (fa.G0) QC_HIP_CHECK(hipMemsetAsync(fa.G0, 0, gbytes, S->stream));
+        nofork = false;                                  // the side streams must see that memset (and the tuner's builds) finished
     }
     return launch_concurrent(nullptr, false);
 }
@@ -556,13 +558,20 @@ void qc_fock_feedback(qc_system *S, float build_ms) {
     if (next != c) { S->cand_cur = next; S->unit_stream = S->cand_stream[next]; S->unit_weight = S->cand_weight[next]; S->cand_skip = true; }
 }
 
+// temporary device buffer of the two set-up passes below: released on every return path
+template <class T> struct QcTmpDev {
+    T *p = nullptr;
+    ~QcTmpDev() { if (p) (void)hipFree(p); }
+    hipError_t alloc(size_t count) { return hipMalloc(&p, count * sizeof(T)); }
+};
+
 // Schwarz pass (the reference's own TODO at uhf.rs:49-50): the (P|P) quartet of every stored pair through the
 // class kernels in their `schwarz_out` mode - unsplit slots / one-ket bundles, serial launches, once per geometry.
 int qc_schwarz_device(qc_system *S) {
     const size_t np = S->pairs.size();
-    double *d_q = nullptr;
-    QC_HIP_CHECK(hipMalloc(&d_q, np * sizeof(double)));
-    struct Free { double *p; ~Free() { (void)hipFree(p); } } guard{d_q};
+    QcTmpDev<double> dq;
+    QC_HIP_CHECK(dq.alloc(np));
+    double *const d_q = dq.p;
     QC_HIP_CHECK(hipMemsetAsync(d_q, 0, np * sizeof(double), S->stream));
     QcFockArgs fa{};
     fa.schwarz_out = d_q;
@@ -576,26 +585,24 @@ int qc_schwarz_device(qc_system *S) {
         if (diag.empty()) continue;
         if (c.bm) {
             qc_make_bundles(S, diag, 0, bundles, ketlist);
-            QcBundle *db = nullptr; int *dk = nullptr;
-            QC_HIP_CHECK(hipMalloc(&db, bundles.size() * sizeof(QcBundle)));
-            QC_HIP_CHECK(hipMalloc(&dk, ketlist.size() * sizeof(int)));
-            QC_HIP_CHECK(hipMemcpyAsync(db, bundles.data(), bundles.size() * sizeof(QcBundle), hipMemcpyHostToDevice, S->stream));
-            QC_HIP_CHECK(hipMemcpyAsync(dk, ketlist.data(), ketlist.size() * sizeof(int), hipMemcpyHostToDevice, S->stream));
+            QcTmpDev<QcBundle> db; QcTmpDev<int> dk;
+            QC_HIP_CHECK(db.alloc(bundles.size()));
+            QC_HIP_CHECK(dk.alloc(ketlist.size()));
+            QC_HIP_CHECK(hipMemcpyAsync(db.p, bundles.data(), bundles.size() * sizeof(QcBundle), hipMemcpyHostToDevice, S->stream));
+            QC_HIP_CHECK(hipMemcpyAsync(dk.p, ketlist.data(), ketlist.size() * sizeof(int), hipMemcpyHostToDevice, S->stream));
             int mx = 0;
             for (const auto &t : diag) mx = std::max(mx, S->pairs[t.bra].na * S->pairs[t.bra].nb * S->pairs[t.ket].na * S->pairs[t.ket].nb);
-            int rc = launch_segments(S, qc_unit_of(c.LAB, c.LCD, true), {Seg{&c, nullptr, (int)bundles.size(), db, dk, mx * 65 * 8}}, S->stream, a);
+            int rc = launch_segments(S, qc_unit_of(c.LAB, c.LCD, true), {Seg{&c, nullptr, (int)bundles.size(), db.p, dk.p, mx * 65 * 8}}, S->stream, a);
             QC_HIP_CHECK(hipStreamSynchronize(S->stream));
-            (void)hipFree(db); (void)hipFree(dk);
             if (rc != QC_OK) return rc;
             continue;
         }
         qc_make_slots(S, diag, 0, false, slots);
-        QcSlot *d = nullptr;
-        QC_HIP_CHECK(hipMalloc(&d, slots.size() * sizeof(QcSlot)));
-        QC_HIP_CHECK(hipMemcpyAsync(d, slots.data(), slots.size() * sizeof(QcSlot), hipMemcpyHostToDevice, S->stream));
-        int rc = launch_segments(S, qc_unit_of(c.LAB, c.LCD, false), {Seg{&c, d, (int)slots.size()}}, S->stream, a);
+        QcTmpDev<QcSlot> d;
+        QC_HIP_CHECK(d.alloc(slots.size()));
+        QC_HIP_CHECK(hipMemcpyAsync(d.p, slots.data(), slots.size() * sizeof(QcSlot), hipMemcpyHostToDevice, S->stream));
+        int rc = launch_segments(S, qc_unit_of(c.LAB, c.LCD, false), {Seg{&c, d.p, (int)slots.size()}}, S->stream, a);
         QC_HIP_CHECK(hipStreamSynchronize(S->stream));
-        (void)hipFree(d);
         if (rc != QC_OK) return rc;
     }
     S->pairQ.assign(np, 0.0);
@@ -616,27 +623,25 @@ int qc_launch_eri_full(qc_system *S, double *d_out) {
         if (c.bm) {
             qc_make_bundles(S, c.tasks, 0, bundles, ketlist);
             if (bundles.empty()) continue;
-            QcBundle *db = nullptr; int *dk = nullptr;
-            QC_HIP_CHECK(hipMalloc(&db, bundles.size() * sizeof(QcBundle)));
-            QC_HIP_CHECK(hipMalloc(&dk, ketlist.size() * sizeof(int)));
-            QC_HIP_CHECK(hipMemcpyAsync(db, bundles.data(), bundles.size() * sizeof(QcBundle), hipMemcpyHostToDevice, S->stream));
-            QC_HIP_CHECK(hipMemcpyAsync(dk, ketlist.data(), ketlist.size() * sizeof(int), hipMemcpyHostToDevice, S->stream));
+            QcTmpDev<QcBundle> db; QcTmpDev<int> dk;
+            QC_HIP_CHECK(db.alloc(bundles.size()));
+            QC_HIP_CHECK(dk.alloc(ketlist.size()));
+            QC_HIP_CHECK(hipMemcpyAsync(db.p, bundles.data(), bundles.size() * sizeof(QcBundle), hipMemcpyHostToDevice, S->stream));
+            QC_HIP_CHECK(hipMemcpyAsync(dk.p, ketlist.data(), ketlist.size() * sizeof(int), hipMemcpyHostToDevice, S->stream));
             int mx = 0;
             for (const auto &t : c.tasks) mx = std::max(mx, S->pairs[t.bra].na * S->pairs[t.bra].nb * S->pairs[t.ket].na * S->pairs[t.ket].nb);
-            int rc = launch_segments(S, qc_unit_of(c.LAB, c.LCD, true), {Seg{&c, nullptr, (int)bundles.size(), db, dk, mx * 65 * 8}}, S->stream, a);
+            int rc = launch_segments(S, qc_unit_of(c.LAB, c.LCD, true), {Seg{&c, nullptr, (int)bundles.size(), db.p, dk.p, mx * 65 * 8}}, S->stream, a);
             QC_HIP_CHECK(hipStreamSynchronize(S->stream));
-            (void)hipFree(db); (void)hipFree(dk);
             if (rc != QC_OK) return rc;
             continue;
         }
         qc_make_slots(S, c.tasks, 0, false, slots);
         if (slots.empty()) continue;
-        QcSlot *d = nullptr;
-        QC_HIP_CHECK(hipMalloc(&d, slots.size() * sizeof(QcSlot)));
-        QC_HIP_CHECK(hipMemcpyAsync(d, slots.data(), slots.size() * sizeof(QcSlot), hipMemcpyHostToDevice, S->stream));
-        int rc = launch_segments(S, qc_unit_of(c.LAB, c.LCD, false), {Seg{&c, d, (int)slots.size()}}, S->stream, a);
+        QcTmpDev<QcSlot> d;
+        QC_HIP_CHECK(d.alloc(slots.size()));
+        QC_HIP_CHECK(hipMemcpyAsync(d.p, slots.data(), slots.size() * sizeof(QcSlot), hipMemcpyHostToDevice, S->stream));
+        int rc = launch_segments(S, qc_unit_of(c.LAB, c.LCD, false), {Seg{&c, d.p, (int)slots.size()}}, S->stream, a);
         QC_HIP_CHECK(hipStreamSynchronize(S->stream));
-        (void)hipFree(d);
         if (rc != QC_OK) return rc;
     }
     return QC_OK;

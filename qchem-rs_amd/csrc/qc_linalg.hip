@@ -896,7 +896,9 @@ __global__ __launch_bounds__(1024) void qc_fx_scale_kernel(int nn, const double 
         else if (!(bound < 1e300)) e = 1100;                              // inf / nan densities: coarsest scale
         int S = 60 - e;
         S = S > QC_FX_MAXBITS ? QC_FX_MAXBITS : (S < -900 ? -900 : S);
-        out[0] = ldexp(1.0, S); out[1] = ldexp(1.0, -S);
+        // non-finite densities must stay visible: integers cannot carry a NaN, so the unit that turns the sums back into doubles
+        // (qc_symmetrize_add_kernel) becomes NaN and every element of G with it - what f64 accumulation would have produced
+        out[0] = ldexp(1.0, S); out[1] = (bound < 1e300) ? ldexp(1.0, -S) : __builtin_nan("");
     }
 }
 void qc_fx_scale(hipStream_t st, int n, const double *Da, const double *Db, double imax, double *out) {

@@ -41,7 +41,7 @@ EXPORTS = ["qc_system_create", "qc_system_destroy", "qc_nbasis", "qc_nelectrons"
            "qc_fock_rhf_device", "qc_fock_uhf_device", "qc_sym_eig", "qc_scf_rhf", "qc_scf_uhf", "qc_comm_unique_id",
            "qc_comm_init", "qc_set_shard", "qc_plan_shard", "qc_set_stream", "qc_device_ready", "qc_work_stats_get",
            "qc_fock_profile", "qc_plan_shard_quartets", "qc_scf_begin_rhf", "qc_scf_begin_uhf", "qc_scf_iterate",
-           "qc_scf_orbital_energies", "qc_scf_density", "qc_scf_spin_square", "qc_scf_timings", "qc_scf_end", "qc_fock_profile_tiers", "qc_sym_eig_warm", "qc_set_fock_mode", "qc_scf_tensor_ms", "qc_set_accumulation", "qc_set_schwarz", "qc_scf_matrix", "qc_rccl_info"]
+           "qc_scf_orbital_energies", "qc_scf_density", "qc_scf_spin_square", "qc_scf_timings", "qc_scf_end", "qc_fock_profile_tiers", "qc_sym_eig_warm", "qc_set_fock_mode", "qc_scf_tensor_ms", "qc_set_accumulation", "qc_set_schwarz", "qc_scf_matrix", "qc_rccl_info", "qc_measure_peaks"]
 
 
 class QcError(RuntimeError):
@@ -334,6 +334,13 @@ def rccl_info() -> str:
     buf = C.create_string_buffer(512)
     lib().qc_rccl_info(buf, 512)
     return buf.value.decode()
+
+
+def measure_peaks():
+    """(FP64 TFLOP/s of a register-resident v_fma_f64 loop, GB/s of a 1 GiB streaming copy) measured on the current device."""
+    f, b = C.c_double(0.0), C.c_double(0.0)
+    _check(lib().qc_measure_peaks(C.byref(f), C.byref(b)), "qc_measure_peaks")
+    return f.value, b.value
 
 
 def comm_unique_id() -> bytes:

@@ -310,13 +310,22 @@ def test_rhf_energy_matches_oracle(mol, basis):
 
 
 def test_rhf_literature_energies():
-    """Literature pins reproduced on the GPU: PySCF-documented H2O/cc-pVDZ and Szabo-Ostlund H2/STO-3G."""
+    """Literature pins reproduced on the GPU: PySCF-documented H2O/cc-pVDZ, Szabo-Ostlund H2/STO-3G, H2O/cc-pVTZ to the four
+    published decimals and the hydrogen atom in cc-pVTZ (one-electron matrices from qc_one_electron.hip)."""
     q, s, o = _sys("water_eq", "cc-pVDZ")
     out = q.restricted_hartree_fock(s, q.HartreeFockConfig(100, 1e-10))
     assert abs(out.total_energy() - (-76.0267656731)) < 2e-9
     q, s, o = _sys("hydrogen", "STO-3G")
     out = q.restricted_hartree_fock(s, q.HartreeFockConfig(100, 1e-12))
     assert abs(out.total_energy() - (-1.1167)) < 5e-5
+    # the headline basis (tests/test_oracle_known_answers.py has the provenance of both numbers)
+    q, s, o = _sys("water_eq", "cc-pVTZ")
+    out = q.restricted_hartree_fock(s, q.HartreeFockConfig(100, 1e-10))
+    assert abs(out.total_energy() - (-76.0571)) < 1.5e-4
+    import scipy.linalg as sl
+    q, s, o = _sys("h_atom", "cc-pVTZ")
+    w = sl.eigh(s.one_electron_gpu(1) + s.one_electron_gpu(2), s.one_electron_gpu(0), eigvals_only=True)
+    assert abs(w[0] - (-0.49980981)) < 1e-8
 
 
 @pytest.mark.parametrize("mol,basis", [("water", "STO-3G"), ("oxygen", "cc-pVDZ")])
