@@ -112,6 +112,10 @@ struct DeviceDiis {
         int sl[12];
         for (int j = 0; j < m; ++j) { sl[j] = slots[j]; ys[j] = pool[2 * slots[j]]; fs[j] = pool[2 * slots[j] + 1]; }
         qc_dots(st, n, ys[0], ys, m, d_dots);                                         // <e_0, e_j>, diis.rs:43-45
+        // (sensitivity probe, QC_DIIS_PERTURB: one dot product moved by one unit in the last place - what a different summation
+        // order does - to see how far a run's trajectory depends on such bits)
+        static const bool perturb = getenv("QC_DIIS_PERTURB") != nullptr;
+        if (perturb && m > 1) qc_axpby(st, 1, 1.0 + 0x1p-52, d_dots + 1, 0.0, nullptr, d_dots + 1);
         qc_diis_solve(st, m, minlen, maxlen, sl, d_dots, d_B, d_c, d_flag);           // (1, 0, ...) while m < minlen
         qc_lincomb_dev(st, n, fs, d_c, m, d_out);                                     // diis.rs:52-58
         return hipGetLastError() == hipSuccess ? QC_OK : QC_ERR_HIP;
@@ -131,6 +135,7 @@ struct ScfWork {
     // reflectors mix everything and seed the unstable direction with rounding noise (measured: the run then leaves the saddle
     // for the 0.024 Eh lower broken-symmetry determinant after ~60 passes).
     bool rotations_only = false;
+    bool small_fused = false;              // n <= QC_SMALL_MAXN: the Roothaan step runs as one workgroup with its matrices in LDS (qc_scf_small.hip)
     bool cold[2] = {false, false};         // this pass's eigensolve of the spin started from the tridiagonal path (no previous vectors involved)
     int npass[2] = {3, 3};                 // refinement passes enqueued per eigensolve (follows what the last one needed)
     int mode[2] = {2, 2};                  // eigensolve of the next pass: 0 refinement, 1 two Jacobi sweeps + refinement, 2 Jacobi
@@ -242,6 +247,48 @@ int roothaan_enqueue(qc_system *S, ScfWork &W, DeviceDiis &diis, const double *d
     if (rc != QC_OK) return rc;
     qc_gemm(st, n, n, n, 1.0, W.X.p, n, false, W.CpNew[spin].p, n, false, 0.0, dC, n);   // C = X C'
     return QC_OK;
+}
+
+// The same step for n <= QC_SMALL_MAXN, density / energy / rms of rhf.rs:78-88 included: one launch when the eigensolve is a refinement from
+// the previous vectors, pre | tridiagonal start | refine + post when it starts cold, pre | Jacobi kernel | post for the rotation-only runs.
+struct SmallTail { int nocc; double dfac; double *Dn; const double *Dold; double *scal_out; int *ctl_all, *ctl_out; };
+int roothaan_small(qc_system *S, ScfWork &W, DeviceDiis &diis, const double *dG, const double *dD, double *dw_out, double *dC, int spin,
+                   double *dE, double *dF, bool have_F, const SmallTail &tl) {
+    const int n = S->nbasis;
+    hipStream_t st = S->stream;
+    QcSmallArgs a{};
+    a.n = n;
+    a.F = have_F ? dF : nullptr; a.F_out = dF;
+    a.D = dD; a.S = W.S.p; a.X = W.X.p; a.H = W.H.p; a.G = dG;
+    a.E_out = dE;
+    a.m = (int)diis.slots.size(); a.minlen = diis.minlen; a.maxlen = diis.maxlen;
+    for (int j = 0; j < a.m; ++j) { a.slot[j] = diis.slots[j]; a.errs[j] = diis.pool[2 * diis.slots[j]]; a.focks[j] = diis.pool[2 * diis.slots[j] + 1]; }
+    a.Bmat = diis.d_B; a.c_out = diis.d_c; a.diis_flag = W.ctl + 8;
+    a.Fp = W.Fps[spin].p;
+    a.ctl = W.ctl + 4 * spin;
+    a.Cp_out = W.CpNew[spin].p; a.w_out = dw_out; a.C_out = dC; a.Dn = tl.Dn; a.Dold = tl.Dold; a.nocc = tl.nocc; a.dfac = tl.dfac;
+    a.scal_out = tl.scal_out; a.ctl_all = tl.ctl_all; a.ctl_out = tl.ctl_out;
+    W.cold[spin] = false;
+    static const bool force_jacobi = getenv("QC_EIG_JACOBI") != nullptr;
+    int rc;
+    if (W.have_prev[spin] && W.mode[spin] == 0) {
+        a.phases = 7; a.V0 = W.CpPrev[spin].p; a.npass = W.npass[spin];
+        return qc_scf_small_launch(st, a);
+    }
+    QcSmallArgs pre = a;
+    pre.phases = 1; pre.ctl_all = nullptr;
+    if ((rc = qc_scf_small_launch(st, pre)) != QC_OK) return rc;
+    if (qc_tri_ok(n) && !force_jacobi && !W.rotations_only) {
+        W.cold[spin] = true;
+        if ((rc = qc_eig_tridiag_start(st, n, W.Fps[spin].p, W.X0.p, W.tri.p)) != QC_OK) return rc;
+        a.phases = 6; a.V0 = W.X0.p; a.npass = 3;
+        return qc_scf_small_launch(st, a);
+    }
+    if (W.have_prev[spin]) rc = qc_eig_device_warm(st, n, W.Fps[spin].p, W.CpPrev[spin].p, W.CpNew[spin].p, dw_out, W.ework.p, W.t1.p, W.t2.p, 40, 1e-9, W.ctl + 9);
+    else rc = qc_eig_device(st, n, W.Fps[spin].p, W.CpNew[spin].p, dw_out, W.ework.p, 40, 1e-9, W.ctl + 9);
+    if (rc != QC_OK) return rc;
+    a.phases = 4; a.Cp_in = W.CpNew[spin].p;
+    return qc_scf_small_launch(st, a);
 }
 
 // the rare repeat of a spin's eigensolve when the sync-free refinement asked for rotations (ctl = 2)
@@ -561,6 +608,9 @@ static int scf_begin(qc_system *S, bool uhf, int n_alpha, int n_beta, qc_scf_sta
     if (st->nocc[0] < 0 || st->nocc[1] < 0 || st->nocc[0] > n || st->nocc[1] > n) return QC_ERR_INVALID;
     const int nspin = uhf ? 2 : 1;
     st->W.rotations_only = uhf && st->nocc[0] != st->nocc[1];
+    // (not for open-shell runs: their saddle-point trajectories depend on every last bit - DESIGN.md 1 - and keep the arithmetic they were
+    // validated with; QC_NO_SMALL_FUSED: A/B switch, the generic launch sequence)
+    st->W.small_fused = n <= QC_SMALL_MAXN && !st->W.rotations_only && getenv("QC_NO_SMALL_FUSED") == nullptr;
     if ((rc = st->W.init(n)) != QC_OK) return rc;
     for (int s = 0; s < nspin; ++s) if (st->D[s].alloc(nn) != QC_OK || st->Dn[s].alloc(nn) != QC_OK) return QC_ERR_HIP;
     if (st->G.alloc(nspin * nn) != QC_OK || st->Cs.alloc(nspin * nn) != QC_OK || st->ws.alloc(nspin * n) != QC_OK) return QC_ERR_HIP;
@@ -649,8 +699,9 @@ static int scf_iterate(qc_scf_state *st, double *energy, double *rms_out) {
     // behind unsignalled barriers while the main queue still works, and with 8 hardware queues on 4 pipes the blocked
     // queues stall their pipe neighbours - 1.6 ms per pass instead of 0.6.)
     QC_HIP_CHECK(hipEventRecord(st->ev1, sm));
-    for (int s = 0; s < nspin; ++s)                                       // (the control words were cleared by the previous pass)
-        if ((rc = roothaan_enqueue(S, W, *st->diis[s], st->G.p + s * nn, st->D[s].p, st->ws.p + s * n, st->Cs.p + s * nn, s, dE[s], dF[s], have_F)) != QC_OK) return rc;
+    if (!W.small_fused)
+        for (int s = 0; s < nspin; ++s)                                   // (the control words were cleared by the previous pass)
+            if ((rc = roothaan_enqueue(S, W, *st->diis[s], st->G.p + s * nn, st->D[s].p, st->ws.p + s * n, st->Cs.p + s * nn, s, dE[s], dF[s], have_F)) != QC_OK) return rc;
     int *h_ctl = reinterpret_cast<int *>(W.h_scal + 4);
     // Multi-rank runs take every decision (convergence, DIIS failure, eigensolve mode, repeat) from the SAME numbers on every
     // rank: the pass scalars go to device memory, are all-reduced as bit patterns (max) together with their complements - so a
@@ -681,7 +732,13 @@ static int scf_iterate(qc_scf_state *st, double *energy, double *rms_out) {
         return true;
     };
     if (multi && nspin == 1) QC_HIP_CHECK(hipMemsetAsync(W.d_sync + 2, 0, 2 * sizeof(double), sm));       // unused spin slot
-    for (int s = 0; s < nspin; ++s) if ((rc = density_and_scalars(s, s == nspin - 1)) != QC_OK) return rc;
+    if (W.small_fused) {
+        for (int s = 0; s < nspin; ++s) {
+            const SmallTail tl{st->nocc[s], st->uhf ? 1.0 : 2.0, st->Dn[s].p, st->D[s].p, scal_out + 2 * s, s == nspin - 1 ? W.ctl : nullptr, ctl_out};
+            if ((rc = roothaan_small(S, W, *st->diis[s], st->G.p + s * nn, st->D[s].p, st->ws.p + s * n, st->Cs.p + s * nn, s, dE[s], dF[s], have_F, tl)) != QC_OK) return rc;
+        }
+    } else
+        for (int s = 0; s < nspin; ++s) if ((rc = density_and_scalars(s, s == nspin - 1)) != QC_OK) return rc;
     if ((rc = publish_scalars()) != QC_OK) return rc;
     // the next pass's build starts from Dn: its density-only preliminaries run while the host turns around
     auto prepare_next = [&]() -> int { return st->stored ? QC_OK : qc_fock_prepare_device(S, st->Dn[0].p, st->uhf ? st->Dn[1].p : nullptr, st->uhf, st); };

@@ -266,6 +266,36 @@ int qc_device_reshard(qc_system *S);
 void qc_energy_rms(hipStream_t st, int n, const double *Dnew, const double *Dold, const double *H, const double *G,
                    double *out2, int *ctl = nullptr, int *ctl_out = nullptr);  // out2[0] = 0.5 tr(Dnew (2H+G)), out2[1] = sum_i (Dnew-Dold)_ii^2
 
+// ---- the whole Roothaan step of one spin in one workgroup, matrices in LDS (qc_scf_small.hip): n <= QC_SMALL_MAXN
+constexpr int QC_SMALL_MAXN = 64;
+struct QcSmallArgs {
+    int n, phases;                 // phases: 1 pre, 2 refine, 4 post
+    // ---- pre
+    const double *F;               // this pass's Fock matrix (null: F = H + G is formed here and stored to F_out)
+    double *F_out;                 // the pass's DIIS Fock slot
+    const double *D, *S, *X, *H, *G;
+    double *E_out;                 // the pass's DIIS error slot
+    int m, minlen, maxlen;         // DIIS window length (newest first), Diis::new(minlen, maxlen)
+    int slot[12];
+    const double *errs[12], *focks[12];
+    double *Bmat, *c_out;          // B (slot-indexed, maxlen x maxlen) and the coefficients, in HBM
+    int *diis_flag;
+    double *Fp;                    // F' = X^T F_diis X (written by pre, read by a refine / post launch of its own)
+    // ---- refine
+    const double *V0;              // start vectors
+    int npass;
+    int *ctl;                      // ctl[0..3] of this spin (0 running / 1 done / 2 rotations needed; last; clean; passes used)
+    // ---- post
+    const double *Cp_in;           // eigenvectors of F' from another eigensolver (post without refine)
+    double *Cp_out, *w_out, *C_out, *Dn;
+    const double *Dold;
+    int nocc; double dfac;
+    double *scal_out;              // [0] 0.5 tr(Dn (2H + G)), [1] sum_i (Dn - Dold)_ii^2
+    int *ctl_all, *ctl_out;        // non-null: hand the 16 control words over to ctl_out and clear them
+};
+int qc_scf_small_launch(hipStream_t st, const QcSmallArgs &a);
+size_t qc_scf_small_lds_bytes(int n);
+
 #define QC_HIP_CHECK(expr)                                                                  \
     do {                                                                                    \
         hipError_t _e = (expr);                                                             \
