@@ -31,6 +31,7 @@ pub struct QcHfOutput {
 pub const QC_OK: c_int = 0;
 pub const QC_NOT_CONVERGED: c_int = 1;
 pub const QC_DIIS_SINGULAR: c_int = 2;
+pub const QC_EIG_NOT_CONVERGED: c_int = 3;   // the Jacobi sweeps of an eigensolve ran out: an error, not the reference's `None`
 
 extern "C" {
     pub fn qc_system_create(natoms: c_int, z: *const i32, xyz: *const f64, nshells: c_int, shell_atom: *const i32,

@@ -98,6 +98,7 @@ pub fn restricted_hartree_fock_stepwise(system: &FlatSystem, config: &HartreeFoc
         match unsafe { ffi::qc_scf_iterate(st, &mut e, &mut rms) } {
             ffi::QC_OK => {}
             ffi::QC_DIIS_SINGULAR => { unsafe { ffi::qc_scf_end(st) }; panic!("DIIS failed") }
+            ffi::QC_EIG_NOT_CONVERGED => { unsafe { ffi::qc_scf_end(st) }; panic!("eigensolve did not converge") }
             _ => break,
         }
         if rms < config.epsilon {                            // rhf.rs:94

@@ -151,8 +151,10 @@ double qc_scf_tensor_ms(qc_scf_state *st);   /* wall time of the tensor build of
 
 /* ---- accumulation of the direct Fock build.  1 (default): every contribution to G is rounded once to a multiple of
  * 2^-S Eh and added as a 64-bit integer - the sum does not depend on the order the GPU serves the adds in, so a build is
- * reproducible bit for bit (run to run, stream assignment, number of ranks) and both spins of a UHF build see identical
- * arithmetic, as in the reference (uhf.rs:80-108, 210-227).  S follows the density of the build (a bound on |G| keeps every
+ * reproducible bit for bit from run to run and under any stream assignment, and both spins of a UHF build see identical
+ * arithmetic, as in the reference (uhf.rs:80-108, 210-227).  (Across DIFFERENT shard layouts - numbers of ranks - the sum of the
+ * partial matrices agrees to ~1e-13, not bit for bit: the bra-major kernels first combine the exchange rows of a 64-ket bundle in
+ * an f64 LDS buffer, and which kets share a bundle depends on the shard.  Non-finite densities give a NaN matrix, as f64 would.)  S follows the density of the build (a bound on |G| keeps every
  * sum inside 64 bits): 2^-49 Eh = 1.8e-15 for benzene/cc-pVDZ.  0: f64 atomics (last-bit noise from the accumulation
  * order; kept for A/B measurements). */
 int qc_set_accumulation(qc_system *sys, int fixed_point);

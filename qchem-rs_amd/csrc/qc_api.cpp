@@ -476,6 +476,14 @@ int qc_fock_build_device(qc_system *S, const double *dDa, const double *dDb, dou
     a.G0 = S->d_Gtmp; a.G1 = S->d_Gtmp + nn;
     int rc = qc_launch_fock_classes(S, a, nullptr, nullptr, ready);
     if (rc != QC_OK) return rc;
+    if (fx && !S->comm && S->nranks == 1) {
+        // (one launch instead of fold + symmetrise: nothing needs the folded planes)
+        qc_fold_symmetrize(st, n, QC_NREP, nspin * nn, S->d_Gtmp, plane, dGa, dH, dH ? dFa : nullptr, fxs);
+        if (two) qc_fold_symmetrize(st, n, QC_NREP, nspin * nn, S->d_Gtmp + nn, plane, dGb, dH, dH ? dFb : nullptr, fxs);
+        else if (uhf) QC_HIP_CHECK(hipMemcpyAsync(dGb, dGa, nn * sizeof(double), hipMemcpyDeviceToDevice, st));
+        if (f_done) *f_done = dH != nullptr && dFa != nullptr && (!uhf || (two && dFb != nullptr));
+        return QC_OK;
+    }
     qc_reduce_replicas(st, nspin * nn, QC_NREP, nspin * nn, S->d_Gtmp, S->d_Gred, fx, plane);
     if (S->comm) {
         // partial Fock matrices -> full, one all-reduce per build ([Ga|Gb] concatenated for UHF; hi and lo planes back to

@@ -227,11 +227,14 @@ static QcKernelArgs base_args(qc_system *S, const QcFockArgs &fa) {
 }
 
 // segment of one launch: a class bucket with its slots (column kernels) or bundles (bra-major kernels)
-struct Seg { const QcClass *c; const QcSlot *d_slots; int nslots; const QcBundle *d_bundles = nullptr; const int *d_ketlist = nullptr; int lds = 0; };
+struct Seg { const QcClass *c; const QcSlot *d_slots; int nslots; const QcBundle *d_bundles = nullptr; const int *d_ketlist = nullptr; int lds = 0;
+             int run = 0, rb_rows = 0; };     // (bra-run mode of the class's own slot list; the set-up passes bring independent slots)
 
 static Seg seg_of(const QcClass &c) {
     if (c.bm) return Seg{&c, nullptr, (int)c.bundles.size(), c.d_bundles, c.d_ketlist, c.lds_bytes};
-    return Seg{&c, c.d_slots, (int)c.slots.size()};
+    Seg sg{&c, c.d_slots, (int)c.slots.size()};
+    sg.run = c.run; sg.rb_rows = c.rb_rows;
+    return sg;
 }
 
 static int launch_segments(qc_system *S, int unit, const std::vector<Seg> &segs, hipStream_t st, const QcKernelArgs &base) {
@@ -268,10 +271,18 @@ static int launch_segments(qc_system *S, int unit, const std::vector<Seg> &segs,
     for (const Seg &sg : segs) {
         const int G = 64 >> sg.c->LGC;
         const int waves = (sg.nslots + G - 1) / G;
-        grid += std::min(waves, 256 * 32);
+        int seg_lds = sg.c->lds_bytes;
+        t.seg_run[k] = sg.run; t.seg_rbrows[k] = 0;
+        if (sg.run > 0) {
+            grid += (waves + sg.run - 1) / sg.run;
+            // row buffer of the wave: exchange rows per spin + the J_ab block; only while it leaves the class its waves per CU
+            const int rb_bytes = ((base.Dk1 ? 2 : 1) * sg.rb_rows * S->nbasis + sg.rb_rows * sg.rb_rows) * 8;
+            static const bool no_rb = getenv("QC_NO_ROWBUF") != nullptr;             // (A/B switch)
+            if (!no_rb && base.eri_out == nullptr && base.schwarz_out == nullptr && rb_bytes <= 6 * 1024) { t.seg_rbrows[k] = sg.rb_rows; seg_lds += rb_bytes; }
+        } else grid += std::min(waves, 256 * 32);
         t.seg_end[k] = grid; t.seg_code[k] = (sg.c->LCD << 4) | sg.c->LGC;
         t.seg_nslots[k] = sg.nslots; t.seg_words[k] = sg.c->slot_words; t.seg_slots[k] = sg.d_slots;
-        lds = std::max(lds, sg.c->lds_bytes);
+        lds = std::max(lds, seg_lds);
         ++k;
     }
     t.nseg = k;

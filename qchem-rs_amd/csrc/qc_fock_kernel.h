@@ -300,9 +300,15 @@ __device__ __forceinline__ void qc_build_r(double *__restrict__ Rw, const int2 *
     }
 }
 
+// `run` > 0 (bra-run mode, low-L classes): the slot list is grouped by bra pair - every batch of G slots shares one bra, padded with
+// null slots (ket < 0) - and workgroup `blk` works through the `run` consecutive batches [blk run, (blk + 1) run).  With `rb_rows` > 0 the
+// wave keeps the targets that belong to the bra - J_ab and the exchange rows of the bra's functions, (na + nb) x n per spin - in an
+// LDS row buffer across the batches of one bra and flushes what is non-zero when the bra changes: one global atomic (pair) and one
+// fixed-point conversion per touched element and bra run instead of per slot (the memory-side atomics of these classes were a third
+// of a benzene build's; cf. the bra-major kernels).  run == 0: slots are independent, grid-stride over batches.
 template <int LAB, int LCD, int LGC>
 __device__ __forceinline__ void qc_fock_body(const QcKernelArgs &a, const QcSlot *__restrict__ slots, const int nslots, const int slot_words,
-                                             const int blk, const int nblk) {
+                                             const int blk, const int nblk, const int run = 0, const int rb_rows = 0) {
     constexpr int L = LAB + LCD, HAB = qc_nherm(LAB), HCD = qc_nherm(LCD);
     static_assert(LGC >= 4, "a lane group is made of whole 16-lane rows (DPP row broadcasts)");
     constexpr int C = 1 << LGC, G = 64 >> LGC;
@@ -333,14 +339,58 @@ __device__ __forceinline__ void qc_fock_body(const QcKernelArgs &a, const QcSlot
 #else
 #define QC_T(i) do {} while (0)
 #endif
-    for (int wave = blk; wave * G < nslots; wave += nblk) {
+    // bra-run mode: row buffer behind the groups' regions (and the plan): exchange rows [spin][na + nb][n], then J_ab[nab]
+    const bool use_rb = rb_rows > 0 && digest;
+    double *const rbK = lds + (size_t)G * slot_words + (HOIST ? 0 : qc_nplan(L));
+    double *const rbJ = rbK + (size_t)(uhf ? 2 : 1) * rb_rows * n;
+    if (use_rb) {
+        for (int i = lane; i < (uhf ? 2 : 1) * rb_rows * n + rb_rows * rb_rows; i += 64) rbK[i] = 0.0;
+        __syncthreads();
+    }
+    int rb_bra = -1;                                       // bra whose targets the row buffer holds (wave-uniform)
+    // what is non-zero in the row buffer goes to Gt: rows of the bra's functions (a first, then b), then the J_ab block
+    auto rb_flush = [&](const int bra) {
+        const QcPairDesc pf = a.pairs[bra];
+        const int na = pf.na, nb = pf.nb, rows = na + nb;
+        const float inn = __builtin_amdgcn_rcpf((float)n), inb = __builtin_amdgcn_rcpf((float)nb);
+        const size_t rep = (size_t)(blk % a.nrep) * a.rep_stride;
+        for (int s = 0; s < (uhf ? 2 : 1); ++s) {
+            double *Gs = (s ? a.G1 : a.G0) + rep;
+            double *Ks = rbK + (size_t)s * rb_rows * n;
+            for (int x = lane; x < rows * n; x += 64) {
+                const double v = Ks[x];
+                if (v != 0.0) {
+                    const int r = qc_fdiv(x, inn), col = x - r * n;
+                    qc_gadd(&Gs[(size_t)(r < na ? pf.offa + r : pf.offb + r - na) * n + col], v, fxscale, a.fx_lo);
+                    Ks[x] = 0.0;
+                }
+            }
+        }
+        for (int ab = lane; ab < na * nb; ab += 64) {
+            const double v = rbJ[ab];
+            if (v != 0.0) {
+                const int r = qc_fdiv(ab, inb);
+                const size_t o = (size_t)(pf.offa + r) * n + pf.offb + ab - r * nb;
+                qc_gadd2(&a.G0[rep + o], &a.G1[rep + o], uhf, v, fxscale, a.fx_lo);
+                rbJ[ab] = 0.0;
+            }
+        }
+        __syncthreads();
+    };
+    const int nbatch = (nslots + G - 1) / G;
+    const int w_begin = run > 0 ? blk * run : blk, w_end = run > 0 ? min(nbatch, (blk + 1) * run) : nbatch, w_step = run > 0 ? 1 : nblk;
+    for (int wave = w_begin; wave < w_end; wave += w_step) {
 #ifdef QC_PHASE_TIMING
         long long tlast = wall_clock64();
 #endif
         const int slot = wave * G + g;
-        const bool active = slot < nslots;
-        const QcSlot sl = slots[active ? slot : nslots - 1];
-        const QcPairDesc pb = a.pairs[sl.bra], pk = a.pairs[sl.ket];
+        const QcSlot sl = slots[min(slot, nslots - 1)];
+        const bool active = slot < nslots && sl.ket >= 0;  // (null slots pad the batches of the bra-run mode)
+        if (use_rb) {
+            const int bra0 = __builtin_amdgcn_readfirstlane(slots[min(wave * G, nslots - 1)].bra);
+            if (bra0 != rb_bra) { if (rb_bra >= 0) rb_flush(rb_bra); rb_bra = bra0; }
+        }
+        const QcPairDesc pb = a.pairs[sl.bra], pk = a.pairs[max(sl.ket, 0)];
         const int na = pb.na, nb = pb.nb, nc = pk.na, nd = pk.nb;
         const int nab = na * nb, ncd = nc * nd;
         const float inb = __builtin_amdgcn_rcpf((float)nb), inc = __builtin_amdgcn_rcpf((float)nc), ind = __builtin_amdgcn_rcpf((float)nd);
@@ -809,6 +859,7 @@ __device__ __forceinline__ void qc_fock_body(const QcKernelArgs &a, const QcSlot
                     double s = 0.0;
 #pragma unroll 4
                     for (int cd = cbeg; cd < cend; ++cd) s = fma(Iblk[ab * ncd + cd], tDj_cd[cd], s);
+                    if (use_rb) { qc_ds_add(&rbJ[ab], fj * s); continue; }
                     const int r = qc_fdiv(ab, inb);
                     const size_t o = (size_t)(pb.offa + r) * n + pb.offb + ab - r * nb;
                     qc_gadd2(&G0[o], &G1[o], uhf, fj * s, fxscale, a.fx_lo);
@@ -824,6 +875,7 @@ __device__ __forceinline__ void qc_fock_body(const QcKernelArgs &a, const QcSlot
                 // K blocks: Gt_ac -= cK f sum_bd I D_bd, and the ad / bc / bd images
                 for (int s = 0; s < (uhf ? 2 : 1); ++s) {
                     double *Gs = s ? G1 : G0;
+                    double *const Ks = rbK + (size_t)s * rb_rows * n;     // (row buffer: rows of a, then rows of b)
                     const double *t_ac = tK + s * ktile, *t_ad = t_ac + na * nc, *t_bc = t_ad + na * nd, *t_bd = t_bc + nb * nc;
                     for (int x = li; x < na * nc; x += C) {          // (i,k) <- sum_{j,l} I[ij,kl] D[j,l]
                         const int i = qc_fdiv(x, inc), k = x - i * nc;
@@ -832,7 +884,8 @@ __device__ __forceinline__ void qc_fock_body(const QcKernelArgs &a, const QcSlot
                         for (int j = 0; j < nb; ++j)
 #pragma unroll 3
                             for (int l = l0; l < l1; ++l) acc = fma(Iblk[(i * nb + j) * ncd + k * nd + l], t_bd[j * nd + l], acc);
-                        qc_gadd(&Gs[(size_t)(pb.offa + i) * n + pk.offa + k], fk * acc, fxscale, a.fx_lo);
+                        if (use_rb) qc_ds_add(&Ks[i * n + pk.offa + k], fk * acc);
+                        else qc_gadd(&Gs[(size_t)(pb.offa + i) * n + pk.offa + k], fk * acc, fxscale, a.fx_lo);
                     }
                     for (int x = li; x < na * nd; x += C) {          // (i,l) <- sum_{j,k} I[ij,kl] D[j,k]
                         const int i = qc_fdiv(x, ind), l = x - i * nd;
@@ -841,7 +894,8 @@ __device__ __forceinline__ void qc_fock_body(const QcKernelArgs &a, const QcSlot
                         for (int j = 0; j < nb; ++j)
 #pragma unroll 3
                             for (int k = k0; k < k1; ++k) acc = fma(Iblk[(i * nb + j) * ncd + k * nd + l], t_bc[j * nc + k], acc);
-                        qc_gadd(&Gs[(size_t)(pb.offa + i) * n + pk.offb + l], fk * acc, fxscale, a.fx_lo);
+                        if (use_rb) qc_ds_add(&Ks[i * n + pk.offb + l], fk * acc);
+                        else qc_gadd(&Gs[(size_t)(pb.offa + i) * n + pk.offb + l], fk * acc, fxscale, a.fx_lo);
                     }
                     for (int x = li; x < nb * nc; x += C) {          // (j,k) <- sum_{i,l} I[ij,kl] D[i,l]
                         const int j = qc_fdiv(x, inc), k = x - j * nc;
@@ -850,7 +904,8 @@ __device__ __forceinline__ void qc_fock_body(const QcKernelArgs &a, const QcSlot
                         for (int i = 0; i < na; ++i)
 #pragma unroll 3
                             for (int l = l0; l < l1; ++l) acc = fma(Iblk[(i * nb + j) * ncd + k * nd + l], t_ad[i * nd + l], acc);
-                        qc_gadd(&Gs[(size_t)(pb.offb + j) * n + pk.offa + k], fk * acc, fxscale, a.fx_lo);
+                        if (use_rb) qc_ds_add(&Ks[(na + j) * n + pk.offa + k], fk * acc);
+                        else qc_gadd(&Gs[(size_t)(pb.offb + j) * n + pk.offa + k], fk * acc, fxscale, a.fx_lo);
                     }
                     for (int x = li; x < nb * nd; x += C) {          // (j,l) <- sum_{i,k} I[ij,kl] D[i,k]
                         const int j = qc_fdiv(x, ind), l = x - j * nd;
@@ -859,7 +914,8 @@ __device__ __forceinline__ void qc_fock_body(const QcKernelArgs &a, const QcSlot
                         for (int i = 0; i < na; ++i)
 #pragma unroll 3
                             for (int k = k0; k < k1; ++k) acc = fma(Iblk[(i * nb + j) * ncd + k * nd + l], t_ac[i * nc + k], acc);
-                        qc_gadd(&Gs[(size_t)(pb.offb + j) * n + pk.offb + l], fk * acc, fxscale, a.fx_lo);
+                        if (use_rb) qc_ds_add(&Ks[(na + j) * n + pk.offb + l], fk * acc);
+                        else qc_gadd(&Gs[(size_t)(pb.offb + j) * n + pk.offb + l], fk * acc, fxscale, a.fx_lo);
                     }
                 }
                 }
@@ -868,6 +924,7 @@ __device__ __forceinline__ void qc_fock_body(const QcKernelArgs &a, const QcSlot
         __syncthreads();   // the slot regions are reused by the next batch of slots
         QC_T(6);
     }
+    if (use_rb && rb_bra >= 0) rb_flush(rb_bra);
 #ifdef QC_PHASE_TIMING
     if (MFMA && lane == 0 && blk < 2 && digest)
         printf("[phase] <%d,%d,%d> blk %d/%d nslots %d: setup %lld  boys+hdr %lld  rtab %lld  kloop %lld  flush %lld  tail %lld  products %lld  atomics %lld  (10 ns units)\n", LAB, LCD, LGC, blk, nblk, nslots,
@@ -888,6 +945,8 @@ struct QcTierArgs {
     int seg_code[QC_MAXSEG];       // (LCD << 4) | LGC
     int seg_nslots[QC_MAXSEG];
     int seg_words[QC_MAXSEG];
+    int seg_run[QC_MAXSEG];        // bra-run mode: batches per workgroup (0: independent slots, grid-stride)
+    int seg_rbrows[QC_MAXSEG];     // ... rows of the LDS row buffer (0: none)
     const QcSlot *seg_slots[QC_MAXSEG];
 };
 
@@ -906,7 +965,7 @@ void qc_fock_tier_kernel(const QcTierArgs a) {
     const int blk = blockIdx.x - b0, nblk = a.seg_end[s] - b0;
     const QcSlot *slots = a.seg_slots[s];
     const int nslots = a.seg_nslots[s], words = a.seg_words[s];
-#define QC_CASE(LCD, LGC) case ((LCD) << 4 | (LGC)): qc_fock_body<LAB, LCD, LGC>(a.base, slots, nslots, words, blk, nblk); break;
+#define QC_CASE(LCD, LGC) case ((LCD) << 4 | (LGC)): qc_fock_body<LAB, LCD, LGC>(a.base, slots, nslots, words, blk, nblk, a.seg_run[s], a.seg_rbrows[s]); break;
     if constexpr (TIER == 0) {
         switch (a.seg_code[s]) { QC_CASE(2, 4) QC_CASE(3, 4) QC_CASE(3, 5) default: break; }
     } else if constexpr (TIER == 1) {

@@ -96,6 +96,9 @@ struct QcClass {
     QcSlot *d_slots = nullptr;    // device copy of `slots`
     int slot_words = 0;           // LDS doubles per lane group
     int lds_bytes = 0;
+    // bra-run mode of the low-L column classes (qc_fock_body): slots grouped by bra, batches of G padded with null slots
+    int run = 0;                  // batches per workgroup (0: independent slots)
+    int rb_rows = 0;              // most bra functions (na + nb) of the class: rows of the LDS row buffer
     // bra-major classes (ket = ss or ps pair, LAB + LCD <= QC_LREG): `bundles` replace `slots`
     bool bm = false;
     int bm_rows = 0;              // most bra functions (na + nb) of a bundle: rows of the kernels' exchange buffer
@@ -244,6 +247,9 @@ void qc_axpby(hipStream_t st, int n, double a, const double *x, double b, const 
 void qc_sub_transpose(hipStream_t st, int n, const double *M, double *out);              // out = M - M^T
 // (fxs non-null: Gt = [hi | lo] planes of 64-bit fixed-point integers, lo_off doubles apart, units fxs[1] = 2^-S and 2^-(S+32))
 void qc_symmetrize_add(hipStream_t st, int n, const double *Gt, size_t lo_off, double *G, const double *H, double *F, const double *fxs);   // G = Gt + Gt^T (and F = H + G)
+// fixed-point builds on one rank: replica fold + symmetrisation (+ F = H + G) in one launch
+void qc_fold_symmetrize(hipStream_t st, int n, int nrep, size_t rep_stride, const double *Gt, size_t lo_off, double *G, const double *H, double *F,
+                        const double *fxs);
 // out[p * count + x] = sum_r Gt[p * plane_stride + r * stride + x], p < (fx ? 2 : 1)
 void qc_reduce_replicas(hipStream_t st, size_t count, int nrep, size_t stride, const double *Gt, double *out, bool fx, size_t plane_stride);
 void qc_count_diff(hipStream_t st, size_t count, const double *a, const double *b, int *flag);

@@ -11,6 +11,8 @@
 #include <cstring>
 #include <numeric>
 
+#include <cstdlib>
+
 #include "qc_internal.h"
 
 namespace {
@@ -394,6 +396,38 @@ void qc_build_shards(qc_system *S) {
             qc_make_slots(S, c.shard, itmax, false, c.slots);
             // a matrix-core class (one slot per wave) with fewer slots than the chip has SIMDs: one wave per 16-column tile
             if (qc_use_mfma(c.LAB, c.LCD) && c.LGC == 6 && c.slots.size() * 4 <= 1024) qc_make_slots(S, c.shard, itmax, true, c.slots);
+            // Low-L classes (16- / 32-lane groups: several slots per wave): bra-run mode.  Slots are grouped by bra pair - heavy bras
+            // first, inside a bra the longest slots first - every batch of G slots gets one bra (null slots pad), and a workgroup takes
+            // `run` consecutive batches, so that the targets that belong to the bra stay in its LDS row buffer across them.
+            c.run = 0; c.rb_rows = 0;
+            // MEASURED AND NOT THE DEFAULT (round 3, benzene/cc-pVDZ, classes alone): (pp|pp)-type bucket 0.274 ms with independent slots,
+            // 0.65 ms in bra runs of 7-8 batches WITH OR WITHOUT the row buffer - removing most of the class's global atomics changes
+            // nothing (they are not what its waves wait for), while equal-length runs of one bra lose the load balance of the
+            // length-sorted grid-stride list (a heavy bra's run is 5x the average).  QC_BRA_RUN=<batches> switches it on for A/B and
+            // for counting atomic requests (tools/run_pmc.sh).
+            static const int run_env = getenv("QC_BRA_RUN") ? atoi(getenv("QC_BRA_RUN")) : 0;
+            if (c.LGC <= 5 && c.LCD <= 3 && S->nbasis <= 128 && run_env > 0 && !c.slots.empty()) {
+                const int G = 64 >> c.LGC;
+                std::vector<int> order;                      // bras by first appearance in the cost-sorted slot list
+                std::vector<std::vector<QcSlot>> by;
+                std::vector<int> where(S->pairs.size(), -1);
+                for (const auto &sl : c.slots) {
+                    if (where[sl.bra] < 0) { where[sl.bra] = (int)by.size(); by.emplace_back(); }
+                    by[where[sl.bra]].push_back(sl);
+                }
+                std::vector<QcSlot> grouped;
+                for (auto &v : by) {
+                    std::stable_sort(v.begin(), v.end(), [](const QcSlot &x, const QcSlot &y) { return x.hi - x.lo > y.hi - y.lo; });
+                    for (const auto &sl : v) grouped.push_back(sl);
+                    while (grouped.size() % G) grouped.push_back(QcSlot{v[0].bra, -1, 0, 0, 0, 0});
+                    c.rb_rows = std::max(c.rb_rows, S->pairs[v[0].bra].na + S->pairs[v[0].bra].nb);
+                }
+                c.slots.swap(grouped);
+                const int64_t nbatch = (int64_t)c.slots.size() / G;
+                // enough workgroups for two per SIMD-pair of the chip, at most 16 batches per run
+                (void)nbatch;
+                c.run = run_env;
+            }
         }
         c.prim_quartets = 0; c.bytes_alg = 0; c.flops_alg = 0;
         int words = 0;
