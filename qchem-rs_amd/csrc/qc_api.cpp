@@ -251,7 +251,7 @@ int roothaan_enqueue(qc_system *S, ScfWork &W, DeviceDiis &diis, const double *d
 
 // The same step for n <= QC_SMALL_MAXN, density / energy / rms of rhf.rs:78-88 included: one launch when the eigensolve is a refinement from
 // the previous vectors, pre | tridiagonal start | refine + post when it starts cold, pre | Jacobi kernel | post for the rotation-only runs.
-struct SmallTail { int nocc; double dfac; double *Dn; const double *Dold; double *scal_out; int *ctl_all, *ctl_out; };
+struct SmallTail { int nocc; double dfac; double *Dn; const double *Dold; double *scal_out; int *ctl_all, *ctl_out; double *fxs_out; };
 int roothaan_small(qc_system *S, ScfWork &W, DeviceDiis &diis, const double *dG, const double *dD, double *dw_out, double *dC, int spin,
                    double *dE, double *dF, bool have_F, const SmallTail &tl) {
     const int n = S->nbasis;
@@ -267,7 +267,7 @@ int roothaan_small(qc_system *S, ScfWork &W, DeviceDiis &diis, const double *dG,
     a.Fp = W.Fps[spin].p;
     a.ctl = W.ctl + 4 * spin;
     a.Cp_out = W.CpNew[spin].p; a.w_out = dw_out; a.C_out = dC; a.Dn = tl.Dn; a.Dold = tl.Dold; a.nocc = tl.nocc; a.dfac = tl.dfac;
-    a.scal_out = tl.scal_out; a.ctl_all = tl.ctl_all; a.ctl_out = tl.ctl_out;
+    a.scal_out = tl.scal_out; a.ctl_all = tl.ctl_all; a.ctl_out = tl.ctl_out; a.fxs_out = tl.fxs_out; a.imax = S->imax;
     W.cold[spin] = false;
     static const bool force_jacobi = getenv("QC_EIG_JACOBI") != nullptr;
     int rc;
@@ -390,7 +390,7 @@ int qc_one_electron_gpu(qc_system *S, int which, double *out) {
 int qc_set_stream(qc_system *S, void *hip_stream) {
     if (!S) return QC_ERR_INVALID;
     if (S->own_stream && S->stream) { (void)hipStreamDestroy(S->stream); S->own_stream = false; }
-    S->prepared = false;                    // (the preliminaries of a prepared build were enqueued on the old stream)
+    S->prepared = false; S->gt_clean = false;                    // (the preliminaries of a prepared build were enqueued on the old stream)
     S->stream = (hipStream_t)hip_stream;
     if (!S->stream && S->device_ready) { QC_HIP_CHECK(hipStreamCreateWithFlags(&S->stream, hipStreamNonBlocking)); S->own_stream = true; }
     return QC_OK;
@@ -417,13 +417,15 @@ int qc_eri_full(qc_system *S, double *out) {
 // Everything of a fixed-point build that depends on the densities alone, enqueued ahead of time (the SCF pass does this as soon as
 // its new density exists, so that it runs while the host turns around): zeroed accumulator planes, this build's fixed-point unit,
 // the UHF density sum.  qc_fock_build_device recognises the densities and then goes straight to the class kernels.
-int qc_fock_prepare_device(qc_system *S, const double *dDa, const double *dDb, bool uhf, const void *owner) {
+int qc_fock_prepare_device(qc_system *S, const double *dDa, const double *dDb, bool uhf, const void *owner, bool scale_done) {
     S->prepared = false;
     if (!S->accum_fx) return QC_OK;
     const int n = S->nbasis;
     const size_t nn = (size_t)n * n, plane = (size_t)QC_NREP * (uhf ? 2 : 1) * nn;
-    QC_HIP_CHECK(hipMemsetAsync(S->d_Gtmp, 0, 2 * plane * sizeof(double), S->stream));
-    qc_fx_scale(S->stream, n, dDa, uhf ? dDb : nullptr, S->imax, S->d_fxs);
+    // (the closing fold of the last build zeroes the replicas it reads: no memset then)
+    if (!(S->gt_clean && S->gt_clean_nspin == (uhf ? 2 : 1))) QC_HIP_CHECK(hipMemsetAsync(S->d_Gtmp, 0, 2 * plane * sizeof(double), S->stream));
+    S->gt_clean = true; S->gt_clean_nspin = uhf ? 2 : 1;
+    if (!scale_done) qc_fx_scale(S->stream, n, dDa, uhf ? dDb : nullptr, S->imax, S->d_fxs);
     if (uhf) qc_axpby(S->stream, n, 1.0, dDa, 1.0, dDb, S->d_Dj);
     S->prepared = true; S->prep_Da = dDa; S->prep_Db = uhf ? dDb : nullptr; S->prep_owner = owner;
     return QC_OK;
@@ -467,6 +469,7 @@ int qc_fock_build_device(qc_system *S, const double *dDa, const double *dDb, dou
         QC_HIP_CHECK(hipMemsetAsync(S->d_Gtmp, 0, (fx ? 2 : 1) * plane * sizeof(double), st));
         if (fx) qc_fx_scale(st, n, dDa, uhf ? dDb : nullptr, S->imax, S->d_fxs);      // this build's fixed-point unit, from its densities
     }
+    S->gt_clean = false;                                    // (the class kernels are about to accumulate into the planes)
     if (uhf) {
         if (!ready) qc_axpby(st, n, 1.0, dDa, 1.0, dDb, S->d_Dj);
         a.Dj = S->d_Dj; a.Dk0 = dDa; a.Dk1 = two ? dDb : nullptr; a.cK = 1.0;
@@ -481,6 +484,7 @@ int qc_fock_build_device(qc_system *S, const double *dDa, const double *dDb, dou
         qc_fold_symmetrize(st, n, QC_NREP, nspin * nn, S->d_Gtmp, plane, dGa, dH, dH ? dFa : nullptr, fxs);
         if (two) qc_fold_symmetrize(st, n, QC_NREP, nspin * nn, S->d_Gtmp + nn, plane, dGb, dH, dH ? dFb : nullptr, fxs);
         else if (uhf) QC_HIP_CHECK(hipMemcpyAsync(dGb, dGa, nn * sizeof(double), hipMemcpyDeviceToDevice, st));
+        S->gt_clean = true; S->gt_clean_nspin = nspin;      // every replica element of the planes in use was read and zeroed
         if (f_done) *f_done = dH != nullptr && dFa != nullptr && (!uhf || (two && dFb != nullptr));
         return QC_OK;
     }
@@ -740,16 +744,21 @@ static int scf_iterate(qc_scf_state *st, double *energy, double *rms_out) {
         return true;
     };
     if (multi && nspin == 1) QC_HIP_CHECK(hipMemsetAsync(W.d_sync + 2, 0, 2 * sizeof(double), sm));       // unused spin slot
+    bool scale_in_kernel = false;
     if (W.small_fused) {
         for (int s = 0; s < nspin; ++s) {
-            const SmallTail tl{st->nocc[s], st->uhf ? 1.0 : 2.0, st->Dn[s].p, st->D[s].p, scal_out + 2 * s, s == nspin - 1 ? W.ctl : nullptr, ctl_out};
+            // (RHF, direct fixed-point builds: the kernel that forms the new density also leaves the next build's fixed-point unit)
+            const bool scale_here = !st->uhf && !st->stored && S->accum_fx;
+            scale_in_kernel = scale_here;
+            const SmallTail tl{st->nocc[s], st->uhf ? 1.0 : 2.0, st->Dn[s].p, st->D[s].p, scal_out + 2 * s, s == nspin - 1 ? W.ctl : nullptr, ctl_out,
+                               scale_here ? S->d_fxs : nullptr};
             if ((rc = roothaan_small(S, W, *st->diis[s], st->G.p + s * nn, st->D[s].p, st->ws.p + s * n, st->Cs.p + s * nn, s, dE[s], dF[s], have_F, tl)) != QC_OK) return rc;
         }
     } else
         for (int s = 0; s < nspin; ++s) if ((rc = density_and_scalars(s, s == nspin - 1)) != QC_OK) return rc;
     if ((rc = publish_scalars()) != QC_OK) return rc;
     // the next pass's build starts from Dn: its density-only preliminaries run while the host turns around
-    auto prepare_next = [&]() -> int { return st->stored ? QC_OK : qc_fock_prepare_device(S, st->Dn[0].p, st->uhf ? st->Dn[1].p : nullptr, st->uhf, st); };
+    auto prepare_next = [&]() -> int { return st->stored ? QC_OK : qc_fock_prepare_device(S, st->Dn[0].p, st->uhf ? st->Dn[1].p : nullptr, st->uhf, st, scale_in_kernel); };
     if ((rc = prepare_next()) != QC_OK) return rc;
     QC_HIP_CHECK(hipEventRecord(st->ev2, sm));
     const double th1 = now_ms();
@@ -790,6 +799,7 @@ static int scf_iterate(qc_scf_state *st, double *energy, double *rms_out) {
         QC_HIP_CHECK(hipMemcpyAsync(ctl_out, W.ctl, 16 * sizeof(int), hipMemcpyDefault, sm));
         QC_HIP_CHECK(hipMemsetAsync(W.ctl, 0, 16 * sizeof(int), sm));
         if ((rc = publish_scalars()) != QC_OK) return rc;
+        scale_in_kernel = false;
         if ((rc = prepare_next()) != QC_OK) return rc;                    // (the density changed)
         QC_HIP_CHECK(hipEventRecord(st->ev2, sm));
         QC_HIP_CHECK(wait_event(st->ev2));
@@ -903,7 +913,7 @@ int qc_scf_spin_square(qc_scf_state *st, double *s2) {
 int qc_set_accumulation(qc_system *S, int fixed_point) {
     if (!S || (fixed_point != 0 && fixed_point != 1)) return QC_ERR_INVALID;
     S->accum_fx = fixed_point;
-    S->prepared = false;                    // (a prepared build zeroed the planes of the other mode)
+    S->prepared = false; S->gt_clean = false;                    // (a prepared build zeroed the planes of the other mode)
     return QC_OK;
 }
 
@@ -1054,7 +1064,7 @@ int qc_fock_profile(qc_system *S, const double *dD, double *dG, int reps, float 
     const size_t nn = (size_t)n * n;
     std::vector<float> acc(S->classes.size(), 0.f), one(S->classes.size(), 0.f);
     float tot = 0.f;
-    S->prepared = false;
+    S->prepared = false; S->gt_clean = false;
     if (S->accum_fx) qc_fx_scale(S->stream, n, dD, nullptr, S->imax, S->d_fxs);
     Event ev0, ev1;
     if (ev0.create() != QC_OK || ev1.create() != QC_OK) return QC_ERR_HIP;
@@ -1099,7 +1109,7 @@ int qc_fock_profile_tiers(qc_system *S, const double *dD, double *dG, int reps, 
     const int NU = QC_NUNITS;
     std::vector<float> acc(NU, 0.f), one(NU, 0.f);
     float tot = 0.f;
-    S->prepared = false;
+    S->prepared = false; S->gt_clean = false;
     if (S->accum_fx) qc_fx_scale(S->stream, S->nbasis, dD, nullptr, S->imax, S->d_fxs);
     Event ev0, ev1;
     if (ev0.create() != QC_OK || ev1.create() != QC_OK) return QC_ERR_HIP;

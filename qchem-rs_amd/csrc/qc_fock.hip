@@ -65,7 +65,7 @@ static int upload_slots(qc_system *S) {
 }
 
 int qc_device_reshard(qc_system *S) {
-    S->prepared = false;                    // a build prepared for the old work lists must not skip the fork of the next one
+    S->prepared = false; S->gt_clean = false;                    // a build prepared for the old work lists must not skip the fork of the next one
     S->unit_ms.clear(); S->unit_stream.clear();
     S->cand_stream.clear(); S->cand_weight.clear(); S->cand_ms.clear(); S->cand_n.clear(); S->cand_frozen = false; S->cand_skip = false; S->cand_cur = 0;
     qc_build_shards(S);
@@ -279,7 +279,10 @@ static int launch_segments(qc_system *S, int unit, const std::vector<Seg> &segs,
             const int rb_bytes = ((base.Dk1 ? 2 : 1) * sg.rb_rows * S->nbasis + sg.rb_rows * sg.rb_rows) * 8;
             static const bool no_rb = getenv("QC_NO_ROWBUF") != nullptr;             // (A/B switch)
             if (!no_rb && base.eri_out == nullptr && base.schwarz_out == nullptr && rb_bytes <= 6 * 1024) { t.seg_rbrows[k] = sg.rb_rows; seg_lds += rb_bytes; }
-        } else grid += std::min(waves, 256 * 32);
+        } else {
+            static const int per_cu = getenv("QC_TIER_WG_PER_CU") ? std::max(1, atoi(getenv("QC_TIER_WG_PER_CU"))) : 32;     // (A/B switch)
+            grid += std::min(waves, 256 * per_cu);
+        }
         t.seg_end[k] = grid; t.seg_code[k] = (sg.c->LCD << 4) | sg.c->LGC;
         t.seg_nslots[k] = sg.nslots; t.seg_words[k] = sg.c->slot_words; t.seg_slots[k] = sg.d_slots;
         lds = std::max(lds, seg_lds);
@@ -374,7 +377,8 @@ int qc_launch_fock_classes(qc_system *S, const QcFockArgs &fa, float *class_ms, 
     auto launch_concurrent = [&](hipEvent_t *ev, bool per_unit) -> int {
         if (ev) QC_HIP_CHECK(hipEventRecord(ev[0], S->stream));
         // (nofork: everything the launches depend on has completed - the host waited for the handle's stream after it was enqueued)
-        const bool fork = ev != nullptr || !nofork;
+        static const bool force_fork = getenv("QC_FORCE_FORK") != nullptr;          // (A/B switch)
+        const bool fork = ev != nullptr || !nofork || force_fork;
         if (fork) QC_HIP_CHECK(hipEventRecord(S->ev_fork, S->stream));
         // Issue order (the host needs ~8 us per launch, so it matters): inside a stream heaviest first; across streams the
         // first launch of every stream before any second one, streams in the order of their total load - the chain that

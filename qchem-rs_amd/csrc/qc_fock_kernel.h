@@ -674,6 +674,7 @@ __device__ __forceinline__ void qc_fock_body(const QcKernelArgs &a, const QcSlot
                         klA += CH;
                         while (klA >= K_cd) { klA -= K_cd; ++ijA; }
                     }
+                    QC_T(1);
                     const int nB = min(CH, maxlen - it0);
                     {
                         // R values by row broadcasts out of registers; the operands of step s + 1 (its record, first ket
@@ -707,6 +708,7 @@ __device__ __forceinline__ void qc_fock_body(const QcKernelArgs &a, const QcSlot
                                                                Rw + sn * NHP, l16, eA, RdA);
                         }
                     }
+                    QC_T(3);
                 }
             } else {
             // primitive-quartet loop of this slot: (ij, kl) advances incrementally; the 32-byte headers [p, P] of the next
@@ -926,7 +928,11 @@ __device__ __forceinline__ void qc_fock_body(const QcKernelArgs &a, const QcSlot
     }
     if (use_rb && rb_bra >= 0) rb_flush(rb_bra);
 #ifdef QC_PHASE_TIMING
+#ifdef QC_PHASE_ALL
+    if (lane == 0 && blk < 2 && digest)
+#else
     if (MFMA && lane == 0 && blk < 2 && digest)
+#endif
         printf("[phase] <%d,%d,%d> blk %d/%d nslots %d: setup %lld  boys+hdr %lld  rtab %lld  kloop %lld  flush %lld  tail %lld  products %lld  atomics %lld  (10 ns units)\n", LAB, LCD, LGC, blk, nblk, nslots,
                tph[0], tph[1], tph[2], tph[3], tph[4], tph[5], tph[7], tph[6]);
 #endif

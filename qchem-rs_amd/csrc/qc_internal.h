@@ -163,6 +163,8 @@ struct qc_system {
     // accumulators zeroed, fixed-point scale (and the UHF density sum) already enqueued for a build from exactly these densities, and the host
     // has waited for the handle's stream since (qc_fock_prepare_device): the build then starts its side streams without a fork
     bool prepared = false;
+    bool gt_clean = false;                   // the accumulator planes (d_Gtmp) are known to be zero for the layout `gt_clean_nspin` (left so by the closing fold)
+    int gt_clean_nspin = 0;
     const double *prep_Da = nullptr, *prep_Db = nullptr;
     const void *prep_owner = nullptr;        // the qc_scf_state that enqueued them (addresses alone could be recycled by a later state)
     int live_states = 0;                     // qc_scf_state objects that still point at this handle
@@ -209,7 +211,8 @@ void qc_fx_scale(hipStream_t st, int n, const double *Da, const double *Db /*nul
 int qc_one_electron_device(qc_system *S, int which /* 0 S, 1 T, 2 V */, double *d_out);
 int qc_launch_fock_classes(qc_system *S, const QcFockArgs &a, float *class_ms /*nullable*/, float *unit_ms = nullptr /*nullable, 14*/, bool nofork = false);
 void qc_fock_feedback(qc_system *S, float build_ms);      // hipEvent time of a build inside an SCF pass (no-op once the choice is made)
-int qc_fock_prepare_device(qc_system *S, const double *dDa, const double *dDb, bool uhf, const void *owner);
+// (scale_done: the fixed-point unit of these densities is already in d_fxs - written by the kernel that produced them)
+int qc_fock_prepare_device(qc_system *S, const double *dDa, const double *dDb, bool uhf, const void *owner, bool scale_done = false);
 // (dH with dFa / dFb: the Fock matrices H + G are written by the closing kernel as well; *f_done tells whether both were)
 int qc_fock_build_device(qc_system *S, const double *dDa, const double *dDb, double *dGa, double *dGb, bool uhf, int *twin_cache = nullptr,
                          const double *dH = nullptr, double *dFa = nullptr, double *dFb = nullptr, bool *f_done = nullptr, const void *owner = nullptr);
@@ -248,7 +251,8 @@ void qc_sub_transpose(hipStream_t st, int n, const double *M, double *out);     
 // (fxs non-null: Gt = [hi | lo] planes of 64-bit fixed-point integers, lo_off doubles apart, units fxs[1] = 2^-S and 2^-(S+32))
 void qc_symmetrize_add(hipStream_t st, int n, const double *Gt, size_t lo_off, double *G, const double *H, double *F, const double *fxs);   // G = Gt + Gt^T (and F = H + G)
 // fixed-point builds on one rank: replica fold + symmetrisation (+ F = H + G) in one launch
-void qc_fold_symmetrize(hipStream_t st, int n, int nrep, size_t rep_stride, const double *Gt, size_t lo_off, double *G, const double *H, double *F,
+// (the replicas are zeroed as they are read: the accumulator planes are clean again when it returns)
+void qc_fold_symmetrize(hipStream_t st, int n, int nrep, size_t rep_stride, double *Gt, size_t lo_off, double *G, const double *H, double *F,
                         const double *fxs);
 // out[p * count + x] = sum_r Gt[p * plane_stride + r * stride + x], p < (fx ? 2 : 1)
 void qc_reduce_replicas(hipStream_t st, size_t count, int nrep, size_t stride, const double *Gt, double *out, bool fx, size_t plane_stride);
@@ -297,6 +301,7 @@ struct QcSmallArgs {
     const double *Dold;
     int nocc; double dfac;
     double *scal_out;              // [0] 0.5 tr(Dn (2H + G)), [1] sum_i (Dn - Dold)_ii^2
+    double *fxs_out; double imax;  // non-null (RHF): the fixed-point unit of the build that will digest Dn goes here (qc_fx_scale)
     int *ctl_all, *ctl_out;        // non-null: hand the 16 control words over to ctl_out and clear them
 };
 int qc_scf_small_launch(hipStream_t st, const QcSmallArgs &a);

@@ -873,7 +873,8 @@ __global__ void qc_symmetrize_add_kernel(int n, const double *Gt, size_t lo_off,
 // Replica fold and G = Gt + Gt^T (and F = H + G) of a fixed-point build in ONE launch (single-rank builds: the folded planes are not
 // needed for an all-reduce): thread (i <= j) sums the `nrep` replicas of the four integers hi[ij], hi[ji], lo[ij], lo[ji] - eight replicas
 // requested at a time - and writes the pair; integer sums are exact, so the result is the one of qc_reduce_replicas + qc_symmetrize_add.
-__global__ __launch_bounds__(64) void qc_fold_symmetrize_kernel(int n, int nrep, size_t rep_stride, const long long *__restrict__ Gh, size_t lo_off,
+// The replicas it has read are zeroed on the way: the next build finds clean accumulator planes without a 1.7 MB memset of its own.
+__global__ __launch_bounds__(64) void qc_fold_symmetrize_kernel(int n, int nrep, size_t rep_stride, long long *__restrict__ Gh, size_t lo_off,
                                                                 double *__restrict__ G, const double *__restrict__ H, double *__restrict__ F,
                                                                 const double *__restrict__ fxs) {
     const int x = blockIdx.x * 64 + threadIdx.x;
@@ -881,7 +882,7 @@ __global__ __launch_bounds__(64) void qc_fold_symmetrize_kernel(int n, int nrep,
     const int i = x / n, j = x - i * n;
     if (i > j) return;
     const int xt = j * n + i;
-    const long long *__restrict__ Gl = Gh + lo_off;
+    long long *__restrict__ Gl = Gh + lo_off;
     long long h = 0, l = 0;
     for (int r0 = 0; r0 < nrep; r0 += 8) {
         long long a[8], b[8], c[8], d[8];
@@ -891,17 +892,23 @@ __global__ __launch_bounds__(64) void qc_fold_symmetrize_kernel(int n, int nrep,
             a[u] = Gh[o + x]; b[u] = Gh[o + xt]; c[u] = Gl[o + x]; d[u] = Gl[o + xt];
         }
 #pragma unroll
-        for (int u = 0; u < 8; ++u) if (r0 + u < nrep) { h += a[u] + b[u]; l += c[u] + d[u]; }
+        for (int u = 0; u < 8; ++u)
+            if (r0 + u < nrep) {
+                h += a[u] + (i == j ? 0 : b[u]); l += c[u] + (i == j ? 0 : d[u]);
+                const size_t o = (size_t)(r0 + u) * rep_stride;
+                Gh[o + x] = 0; Gh[o + xt] = 0; Gl[o + x] = 0; Gl[o + xt] = 0;
+            }
     }
+    if (i == j) { h *= 2; l *= 2; }                       // (diagonal: Gt_ii + Gt_ii)
     const double u1 = fxs[1], u2 = u1 * 0x1p-32;
     const double g = fma((double)l, u2, (double)h * u1);
     G[x] = g; G[xt] = g;
     if (F) { F[x] = 1.0 * H[x] + 1.0 * g; F[xt] = 1.0 * H[xt] + 1.0 * g; }
 }
-void qc_fold_symmetrize(hipStream_t st, int n, int nrep, size_t rep_stride, const double *Gt, size_t lo_off, double *G, const double *H, double *F,
+void qc_fold_symmetrize(hipStream_t st, int n, int nrep, size_t rep_stride, double *Gt, size_t lo_off, double *G, const double *H, double *F,
                         const double *fxs) {
     hipLaunchKernelGGL(qc_fold_symmetrize_kernel, dim3((n * n + 63) / 64), dim3(64), 0, st, n, nrep, rep_stride,
-                       reinterpret_cast<const long long *>(Gt), lo_off, G, H, F, fxs);
+                       reinterpret_cast<long long *>(Gt), lo_off, G, H, F, fxs);
 }
 void qc_symmetrize_add(hipStream_t st, int n, const double *Gt, size_t lo_off, double *G, const double *H, double *F, const double *fxs) {
     if (fxs) hipLaunchKernelGGL(qc_symmetrize_add_kernel<true>, dim3((n * n + 255) / 256), dim3(256), 0, st, n, Gt, lo_off, G, H, F, fxs);

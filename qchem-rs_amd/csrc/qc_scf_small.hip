@@ -522,15 +522,28 @@ __global__ __launch_bounds__(QCS_T) void qc_scf_small_kernel(const QcSmallArgs a
         QCS_EACH(q, i) if (QCS_IN(i)) a.C_out[i * n + cc] = B2[i * ld + cc];
         __syncthreads();
         QCS_STAMP();
-        double part[2] = {0.0, 0.0};
+        double part[3] = {0.0, 0.0, 0.0};
         QCS_EACH(q, i) {
             const int ic = min(i, 63);
-            if (QCS_IN(i)) a.Dn[i * n + cc] = B3[ic * ld + cc];
+            const double dn = B3[ic * ld + cc];                                                  // (zero in the padding)
+            if (QCS_IN(i)) a.Dn[i * n + cc] = dn;
             part[0] = fma(QCS_IN(i) ? B3[cc * ld + ic] : 0.0, 2.0 * h[q] + g[q], part[0]);      // tr(Dn (2H + G)) = sum_ij Dn_ji (2H + G)_ij
+            part[2] += fabs(dn);
         }
         if (tid < n) { const double d = B3[tid * ld + tid] - dold; part[1] = d * d; }
-        qcs_block_sums<2>(part, 2, red, scal);
-        if (tid == 0) { a.scal_out[0] = 0.5 * scal[0]; a.scal_out[1] = scal[1]; }
+        qcs_block_sums<3>(part, 3, red, scal);
+        if (tid == 0) {
+            a.scal_out[0] = 0.5 * scal[0]; a.scal_out[1] = scal[1];
+            if (a.fxs_out) {     // fixed-point unit of the build that will digest Dn (qc_fx_scale_kernel, qc_linalg.hip): 2^S (4 imax sum|D|) <= 2^60
+                const double bound = 4.0 * a.imax * scal[2];
+                int e = 0;
+                if (bound > 0.0 && bound < 1e300) (void)frexp(bound, &e);
+                else if (!(bound < 1e300)) e = 1100;
+                int S = 60 - e;
+                S = S > QC_FX_MAXBITS ? QC_FX_MAXBITS : (S < -900 ? -900 : S);
+                a.fxs_out[0] = ldexp(1.0, S); a.fxs_out[1] = (bound < 1e300) ? ldexp(1.0, -S) : __builtin_nan("");
+            }
+        }
         QCS_STAMP();
     }
     if (a.ctl_all) {
