@@ -815,7 +815,11 @@ static int scf_iterate(qc_scf_state *st, double *energy, double *rms_out) {
         e_sum += W.h_scal[2 * s]; rms_sum += rms_s;
         // the refinement is perturbative: on its own once the density has nearly stopped moving, behind two Jacobi sweeps
         // while it still moves, not at all in the first wild passes
-        static const double warm_rms = getenv("QC_EIG_WARM_RMS") ? atof(getenv("QC_EIG_WARM_RMS")) : 1e-3;
+        // (the one-workgroup path of small matrices pays 150 us for a cold start and nothing extra for a refinement pass that turns out to
+        // be needed: it refines from the previous vectors one decade earlier - H2O/cc-pVTZ: one cold pass less per run, no repeats;
+        // benzene at 1e-2: two repeated eigensolves per run, slower than 1e-3)
+        static const double warm_env = getenv("QC_EIG_WARM_RMS") ? atof(getenv("QC_EIG_WARM_RMS")) : 0.0;
+        const double warm_rms = warm_env > 0.0 ? warm_env : (W.small_fused ? 1e-2 : 1e-3);
         W.mode[s] = rms_s >= 1.0 ? 2 : (rms_s >= warm_rms || redo) ? 1 : 0;
         std::swap(st->D[s].p, st->Dn[s].p);                              // D += 1.0 * dD
         std::swap(W.CpPrev[s].p, W.CpNew[s].p);

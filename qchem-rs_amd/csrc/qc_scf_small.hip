@@ -177,6 +177,7 @@ __global__ __launch_bounds__(QCS_T) void qc_scf_small_kernel(const QcSmallArgs a
     const int tid = threadIdx.x, rr = tid >> 6, cc = tid & 63;           // this thread's elements: rows rr + 4 q, column cc
     const bool cok = cc < n;
     bool ok = true;                                                      // (uniform) the eigenvectors for `post` exist
+    double *Cpv = B0;                                                    // ... and the block they are in
 #ifdef QC_SMALL_TIMING
     long long tph[40] = {}; int nph = 0;
 #define QCS_STAMP() do { if (tid == 0 && nph < 40) tph[nph++] = wall_clock64(); } while (0)
@@ -253,7 +254,14 @@ __global__ __launch_bounds__(QCS_T) void qc_scf_small_kernel(const QcSmallArgs a
             qcs_block_sums<12>(part, a.m, red, dots);
         }
         QCS_STAMP();
-        // ---- DIIS coefficients by wave 0; the other three waves fetch X meanwhile
+        // ---- DIIS coefficients by wave 0; the other three waves fetch X meanwhile.  The first three Fock matrices of the combination are
+        // requested before the solve (they do not depend on it) and arrive while it runs.
+        double fo0[3][QCS_E];
+#pragma unroll
+        for (int u = 0; u < 3; ++u) {
+            const double *__restrict__ src = a.focks[u < a.m ? u : 0];
+            QCS_EACH(q, i) fo0[u][q] = src[QCS_GX(i)];
+        }
         if (qcs_wave() == 0) {
             const int lane = tid, m = a.m, M = m + 1, ML = a.maxlen;
             if (lane < m) {
@@ -313,8 +321,11 @@ __global__ __launch_bounds__(QCS_T) void qc_scf_small_kernel(const QcSmallArgs a
                     double o[3][QCS_E];
 #pragma unroll
                     for (int u = 0; u < 3; ++u) {
-                        const double *__restrict__ src = a.focks[j0 + u < a.m ? j0 + u : 0];
-                        QCS_EACH(q, i) o[u][q] = src[QCS_GX(i)];
+                        if (j0 == 0) { QCS_EACH(q, i) o[u][q] = fo0[u][q]; }
+                        else {
+                            const double *__restrict__ src = a.focks[j0 + u < a.m ? j0 + u : 0];
+                            QCS_EACH(q, i) o[u][q] = src[QCS_GX(i)];
+                        }
                     }
 #pragma unroll
                     for (int u = 0; u < 3; ++u) {
@@ -376,14 +387,15 @@ __global__ __launch_bounds__(QCS_T) void qc_scf_small_kernel(const QcSmallArgs a
                 for (int o = 32; o > 0; o >>= 1) amax = fmax(amax, __shfl_down(amax, o, 64));
                 qcs_block_sums<2>(part, 2, red, scal);                   // scal[0] = ||off S||^2, scal[1] = ||R||^2
                 if ((tid & 63) == 0) red[tid >> 6] = amax;
-                if (tid == 0) { flg[4] = 0; flg[5] = 0; }                // multi, nstrong
+                if (tid == 0) { flg[4] = 0; flg[5] = 0; flg[6] = 0; flg[7] = 0; }      // multi, nstrong, big update, not the last update
                 __syncthreads();
                 if (tid == 0) { double c = 0.0; for (int k = 0; k < QCS_W; ++k) c = fmax(c, red[k]); scal[2] = c; }
                 __syncthreads();
             }
             const double scale = scal[2], tiny = QCS_REF_TINY * scale, gfloor = QCS_REF_GFLOOR * scale;
             {
-                double cmax = 0.0, emax = 0.0;
+                double cmax = 0.0;
+                int big = 0, notlast = 0;                                // some regular pair has |a| > 0.1 g / > 1e-7 g (update size, without the division)
 #pragma unroll
                 for (int ii = 0; ii < 4; ++ii) {                         // one row per team of 16 lanes
                     const int i = (tid >> 4) + 16 * ii;
@@ -402,7 +414,9 @@ __global__ __launch_bounds__(QCS_T) void qc_scf_small_kernel(const QcSmallArgs a
                         who = strong ? j : who;
                         const bool weak = valid && !strong;
                         cmax = (weak && g <= gfloor) ? fmax(cmax, av) : cmax;
-                        emax = (weak && g > gfloor) ? fmax(emax, av / g) : emax;
+                        const bool reg = weak && g > gfloor;
+                        big |= (reg && !(av <= 0.1 * g)) ? 1 : 0;
+                        notlast |= (reg && !(av <= 1e-7 * g)) ? 1 : 0;
                     }
 #pragma unroll
                     for (int o = 8; o > 0; o >>= 1) { cnt += __shfl_xor(cnt, o, 16); who = max(who, __shfl_xor(who, o, 16)); }
@@ -413,19 +427,21 @@ __global__ __launch_bounds__(QCS_T) void qc_scf_small_kernel(const QcSmallArgs a
                     }
                 }
 #pragma unroll
-                for (int o = 32; o > 0; o >>= 1) { cmax = fmax(cmax, __shfl_down(cmax, o, 64)); emax = fmax(emax, __shfl_down(emax, o, 64)); }
+                for (int o = 32; o > 0; o >>= 1) cmax = fmax(cmax, __shfl_down(cmax, o, 64));
+                if (big) flg[6] = 1;
+                if (notlast) flg[7] = 1;
                 __syncthreads();
-                if ((tid & 63) == 0) { red[tid >> 6] = cmax; red[QCS_W + (tid >> 6)] = emax; }
+                if ((tid & 63) == 0) red[tid >> 6] = cmax;
                 if (tid < n) { const int pj = partner[tid]; if (pj >= 0 && partner[pj] != tid) flg[4] = 1; }     // a strong pair must be mutual
                 __syncthreads();
                 if (tid == 0) {
-                    double ca = 0.0, eb = 0.0;
-                    for (int k = 0; k < QCS_W; ++k) { ca = fmax(ca, red[k]); eb = fmax(eb, red[QCS_W + k]); }
+                    double ca = 0.0;
+                    for (int k = 0; k < QCS_W; ++k) ca = fmax(ca, red[k]);
                     const double orth = sqrt(scal[1]), scl = fmax(scale, 1e-300);
                     const int multi = flg[4];
-                    if (!(eb <= 0.1) || !(orth <= 1e-3) || multi) flg[0] = 2;                    // not perturbative: rotations needed
+                    if (flg[6] || !(orth <= 1e-3) || multi) flg[0] = 2;                          // not perturbative: rotations needed
                     else {
-                        flg[1] = (eb <= 1e-7 && orth <= 1e-7 && flg[5] == 0) ? 1 : 0;            // one more update finishes
+                        flg[1] = (!flg[7] && orth <= 1e-7 && flg[5] == 0) ? 1 : 0;               // one more update finishes
                         flg[2] = (ca <= 1e-12 * scl) ? 1 : 0;                                    // no coupling left inside degenerate pairs
                     }
                 }
@@ -491,7 +507,8 @@ __global__ __launch_bounds__(QCS_T) void qc_scf_small_kernel(const QcSmallArgs a
         if (tid < 4) a.ctl[tid] = flg[tid];
         ok = flg[0] == 1;
         if (ok) {
-            QCS_EACH(q, i) if (QCS_IN(i)) { const double v = X[i * ld + cc]; a.Cp_out[i * n + cc] = v; if (X != B0) B0[i * ld + cc] = v; }
+            QCS_EACH(q, i) if (QCS_IN(i)) a.Cp_out[i * n + cc] = X[i * ld + cc];
+            Cpv = X;
         }
         __syncthreads();
         QCS_STAMP();
@@ -515,11 +532,12 @@ __global__ __launch_bounds__(QCS_T) void qc_scf_small_kernel(const QcSmallArgs a
         }
         __syncthreads();
         QCS_STAMP();
-        qcs_gemm<false, false>(B1, B0, B2, n, n, 1.0);                   // C
+        double *const Cm = Cpv == B2 ? B0 : B2;                          // (the block the eigenvectors are not in)
+        qcs_gemm<false, false>(B1, Cpv, Cm, n, n, 1.0);                  // C
         __syncthreads();
-        if (a.nocc > 0) qcs_gemm<false, true, true>(B2, B2, B3, n, a.nocc, a.dfac);         // C_occ C_occ^T
+        if (a.nocc > 0) qcs_gemm<false, true, true>(Cm, Cm, B3, n, a.nocc, a.dfac);         // C_occ C_occ^T
         else QCS_EACH(q, i) if (QCS_IN(i)) B3[i * ld + cc] = 0.0;
-        QCS_EACH(q, i) if (QCS_IN(i)) a.C_out[i * n + cc] = B2[i * ld + cc];
+        QCS_EACH(q, i) if (QCS_IN(i)) a.C_out[i * n + cc] = Cm[i * ld + cc];
         __syncthreads();
         QCS_STAMP();
         double part[3] = {0.0, 0.0, 0.0};

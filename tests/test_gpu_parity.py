@@ -551,6 +551,33 @@ def test_stored_tensor_mode_uhf_triplet():
     st.close(); st2.close()
 
 
+@pytest.mark.parametrize("mol,basis,uhf", [("water", "cc-pVTZ", False), ("ethylene", "cc-pVDZ", False), ("water", "6-31G_st_st", True),
+                                           ("hydrogen", "STO-3G", False), ("oxygen", "cc-pVDZ", True)])
+def test_fused_small_roothaan_step_equals_the_generic_launch_sequence(mol, basis, uhf, monkeypatch):
+    """qc_scf_small.hip (n <= 64: the whole Roothaan step of rhf.rs:70-88 in one workgroup, matrices in LDS) against the generic
+    sequence of launches it replaces (QC_NO_SMALL_FUSED=1): same passes, same energies, both against the oracle.  Covers the
+    one-tile-per-wave form (n <= 32), the 2 x 2 form (n = 48, 58), the DIIS windows of RHF (4, 6) and UHF (2, 8), and the cold
+    (tridiagonal / Jacobi start) and warm (refinement) eigensolves."""
+    q, s, o = _sys(mol, basis)
+    run = q.unrestricted_hartree_fock if uhf else q.restricted_hartree_fock
+    cfg = q.HartreeFockConfig(100, 1e-10)
+    fused = run(s, cfg)
+    monkeypatch.setenv("QC_NO_SMALL_FUSED", "1")
+    generic = run(s, cfg)
+    monkeypatch.delenv("QC_NO_SMALL_FUSED")
+    ref = (o.uhf if uhf else o.rhf)(100, 1e-10)
+    assert fused is not None and generic is not None and ref["status"] == 0
+    assert abs(fused.total_energy() - generic.total_energy()) < 1e-10
+    assert abs(fused.total_energy() - ref["total_energy"]) < TOL_E
+    assert abs(fused.iterations - generic.iterations) <= 1
+    wa = fused.orbital_energies_alpha if uhf else fused.orbital_energies
+    wb = generic.orbital_energies_alpha if uhf else generic.orbital_energies
+    assert np.abs(np.array(wa) - np.array(wb)).max() < 1e-8
+    # the fused path is deterministic: a second run repeats the first bit for bit
+    again = run(s, cfg)
+    assert again.electronic_energy == fused.electronic_energy and again.iterations == fused.iterations
+
+
 def test_not_converged_returns_none():
     q, s, o = _sys("water", "STO-3G")
     assert q.restricted_hartree_fock(s, q.HartreeFockConfig(max_iterations=1, epsilon=1e-14)) is None
