@@ -153,7 +153,7 @@ struct ScfWork {
         DevBuf *all[] = {&H, &S, &X, &t1, &t2, &t3, &t4, &Fp, &Cp, &C, &ework, &Fd, &CpPrev[0], &CpPrev[1], &CpNew[0], &CpNew[1], &Fps[0], &Fps[1], &X0};
         for (auto b : all) if (b->alloc(nn) != QC_OK) return QC_ERR_HIP;
         if (tri.alloc(qc_eig_tridiag_work_doubles(n)) != QC_OK) return QC_ERR_HIP;
-        if (w.alloc(n) != QC_OK || scal.alloc(16) != QC_OK || small.alloc(2 * n + 16) != QC_OK) return QC_ERR_HIP;
+        if (w.alloc(n) != QC_OK || scal.alloc(16) != QC_OK || small.alloc(qc_eig_small_doubles(n)) != QC_OK) return QC_ERR_HIP;
         if (hipMalloc(&ctl, 16 * sizeof(int)) != hipSuccess || hipMemset(ctl, 0, 16 * sizeof(int)) != hipSuccess) return QC_ERR_HIP;
         if (hipHostMalloc(&h_scal, 2 * QC_SYNC_WORDS * sizeof(double)) != hipSuccess) return QC_ERR_HIP;
         if (hipMalloc(&d_sync, 2 * QC_SYNC_WORDS * sizeof(unsigned long long)) != hipSuccess) return QC_ERR_HIP;
@@ -553,7 +553,7 @@ int qc_sym_eig(qc_system *S, int n, const double *A, double *V, double *w) {
     DevBuf dA, dV, dw, dwork, x0, tri, t1, t2, t3, t4, sm;
     DevBuf *all[] = {&dA, &dV, &dwork, &x0, &t1, &t2, &t3, &t4};
     for (auto b : all) if (b->alloc(nn) != QC_OK) return QC_ERR_HIP;
-    if (dw.alloc(n) != QC_OK || sm.alloc(2 * n + 16) != QC_OK || tri.alloc(qc_eig_tridiag_work_doubles(n)) != QC_OK) return QC_ERR_HIP;
+    if (dw.alloc(n) != QC_OK || sm.alloc(qc_eig_small_doubles(n)) != QC_OK || tri.alloc(qc_eig_tridiag_work_doubles(n)) != QC_OK) return QC_ERR_HIP;
     QC_HIP_CHECK(hipMemcpyAsync(dA.p, A, nn * sizeof(double), hipMemcpyHostToDevice, S->stream));
     int flag = 0;
     QC_HIP_CHECK(hipMemsetAsync(S->d_flag, 0, 4 * sizeof(int), S->stream));
@@ -951,7 +951,7 @@ int qc_sym_eig_warm(qc_system *S, int n, const double *A, const double *V0, doub
     DevBuf dA, dV0, dV, dw, wk, t1, t2, t3, t4, sm;
     DevBuf *all[] = {&dA, &dV0, &dV, &wk, &t1, &t2, &t3, &t4};
     for (auto b : all) if (b->alloc(nn) != QC_OK) return QC_ERR_HIP;
-    if (dw.alloc(n) != QC_OK || sm.alloc(2 * n + 16) != QC_OK) return QC_ERR_HIP;
+    if (dw.alloc(n) != QC_OK || sm.alloc(qc_eig_small_doubles(n)) != QC_OK) return QC_ERR_HIP;
     QC_HIP_CHECK(hipMemcpyAsync(dA.p, A, nn * sizeof(double), hipMemcpyHostToDevice, S->stream));
     QC_HIP_CHECK(hipMemcpyAsync(dV0.p, V0, nn * sizeof(double), hipMemcpyHostToDevice, S->stream));
     int flag = 0;

@@ -220,6 +220,8 @@ int qc_fock_build_device(qc_system *S, const double *dDa, const double *dDb, dou
 // dense linear algebra on the handle's stream (all row-major n x n, device pointers)
 void qc_gemm(hipStream_t st, int m, int n, int k, double alpha, const double *A, int lda, bool ta, const double *B,
              int ldb, bool tb, double beta, double *C, int ldc, const int *skip = nullptr /* device flag: non-zero = no-op */);
+// (`small`: qc_eig_small_doubles(n) doubles - Rayleigh quotients, statistics, partner list, per-workgroup partials)
+inline size_t qc_eig_small_doubles(int n) { return (size_t)3 * n + 32 + 8; }
 int qc_eig_refine_async(hipStream_t st, int n, double *dA, const double *dV0, double *dV, double *dw, double *d_work, double *t1, double *t2,
                         double *t3, double *t4, double *small, int *ctl, int npass);
 void qc_diis_solve(hipStream_t st, int m, int minlen, int maxlen, const int *slots, const double *dots, double *B, double *c, int *flag);

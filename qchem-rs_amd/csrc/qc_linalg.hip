@@ -556,6 +556,175 @@ __global__ __launch_bounds__(1024) void qc_refine_stats_kernel(int n, const doub
     }
 }
 
+// The statistics / decisions / update matrix of a refinement pass spread over the chip (round 3).  As one workgroup
+// (qc_refine_stats_kernel above, kept for the synchronous variant) this took 28 us per pass at n = 114 - 74 us of benzene's 340 us Roothaan
+// step: ~2000 f64-heavy instructions per wave for sixteen waves on ONE compute unit.  Now two launches of ceil(n / 8) workgroups of 256
+// threads, eight rows each (32 lanes per row, columns l + 32 q):
+//   A  every workgroup forms all n Rayleigh quotients itself (n loads: cheaper than a grid barrier), classifies the pairs of its rows,
+//      fixes their partner[] entries and leaves its partial sums / maxima / flags in `part` (8 doubles per workgroup);
+//   B  every workgroup folds the partials in a fixed order and takes the decisions itself (workgroup 0 publishes them), then writes
+//      its rows of M = I + E.
+// The size of the first-order update is tested as |a| <= tau g (no division; stats[5] reports the threshold exceeded).
+constexpr int QC_STATS_ROWS = 8;
+__global__ __launch_bounds__(256) void qc_refine_statsA_kernel(int n, const double *__restrict__ S, const double *__restrict__ XtX,
+                                                                double *__restrict__ lam, int *__restrict__ partner, double *__restrict__ part,
+                                                                const int *__restrict__ ctl) {
+    if (ctl && ctl[0] != 0) return;
+    extern __shared__ double sh_lam[];                       // n
+    __shared__ double red[3][4];
+    __shared__ double sh_scale;
+    __shared__ int sh_multi, sh_nstrong, sh_big, sh_notlast;
+    const int tid = threadIdx.x, r = tid >> 5, l = tid & 31;
+    double amax = 0.0;
+    for (int t = tid; t < n; t += 256) {
+        const double rr_ = 1.0 - XtX[(size_t)t * n + t], lv = S[(size_t)t * n + t] / (1.0 - rr_);
+        sh_lam[t] = lv; amax = fmax(amax, fabs(lv));
+        if (blockIdx.x == 0) lam[t] = lv;
+    }
+    for (int o = 32; o > 0; o >>= 1) amax = fmax(amax, __shfl_down(amax, o, 64));
+    if ((tid & 63) == 0) red[0][tid >> 6] = amax;
+    if (tid == 0) { sh_multi = 0; sh_nstrong = 0; sh_big = 0; sh_notlast = 0; }
+    __syncthreads();
+    if (tid == 0) sh_scale = fmax(fmax(red[0][0], red[0][1]), fmax(red[0][2], red[0][3]));
+    __syncthreads();
+    const double scale = sh_scale, tiny = QC_REF_TINY * scale, gfloor = QC_REF_GFLOOR * scale;
+    const int i = blockIdx.x * QC_STATS_ROWS + r;
+    const bool iok = i < n;
+    const double li = sh_lam[iok ? i : 0];
+    double off = 0.0, rsum = 0.0, cmax = 0.0;
+    int cnt = 0, who = -1, big = 0, notlast = 0;
+    for (int j0 = l; j0 < n; j0 += 128) {                    // four columns of the row at a time
+        double sij[4], sji[4], xij[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int j = j0 + 32 * u;
+            const bool ok = iok && j < n;
+            sij[u] = S[ok ? (size_t)i * n + j : 0]; sji[u] = S[ok ? (size_t)j * n + i : 0]; xij[u] = XtX[ok ? (size_t)i * n + j : 0];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int j = j0 + 32 * u;
+            if (iok && j < n) {
+                const double rv = (i == j ? 1.0 : 0.0) - xij[u];
+                rsum = fma(rv, rv, rsum);
+                if (i != j) {
+                    off = fma(sij[u], sij[u], off);
+                    const double lj = sh_lam[j];
+                    const double av = fabs(0.5 * (sij[u] + sji[u]) + 0.5 * (li + lj) * rv), g = fabs(lj - li);
+                    if (av > tiny) {
+                        if (av > QC_REF_TAU * fmax(g, gfloor)) { ++cnt; who = j; }
+                        else if (g <= gfloor) cmax = fmax(cmax, av);
+                        else { big |= !(av <= 0.1 * g) ? 1 : 0; notlast |= !(av <= 1e-7 * g) ? 1 : 0; }
+                    }
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int o = 16; o > 0; o >>= 1) { cnt += __shfl_xor(cnt, o, 32); who = max(who, __shfl_xor(who, o, 32)); }
+    if (l == 0 && iok) {
+        partner[i] = cnt == 0 ? -1 : (cnt == 1 ? who : -2);
+        if (cnt > 1) sh_multi = 1;
+        if (cnt == 1) atomicAdd(&sh_nstrong, 1);
+    }
+    for (int o = 32; o > 0; o >>= 1) { off += __shfl_down(off, o, 64); rsum += __shfl_down(rsum, o, 64); cmax = fmax(cmax, __shfl_down(cmax, o, 64)); }
+    if ((tid & 63) == 0) { red[0][tid >> 6] = off; red[1][tid >> 6] = rsum; red[2][tid >> 6] = cmax; }
+    if (big) sh_big = 1;
+    if (notlast) sh_notlast = 1;
+    __syncthreads();
+    if (tid == 0) {
+        double *p = part + 8 * blockIdx.x;
+        p[0] = (red[0][0] + red[0][1]) + (red[0][2] + red[0][3]);
+        p[1] = (red[1][0] + red[1][1]) + (red[1][2] + red[1][3]);
+        p[2] = fmax(fmax(red[2][0], red[2][1]), fmax(red[2][2], red[2][3]));
+        p[3] = sh_nstrong; p[4] = sh_multi; p[5] = sh_big; p[6] = sh_notlast; p[7] = scale;
+    }
+}
+__global__ __launch_bounds__(256) void qc_refine_statsB_kernel(int n, const double *__restrict__ S, const double *__restrict__ XtX,
+                                                                const double *__restrict__ lam, double *__restrict__ stats,
+                                                                const int *__restrict__ partner, const double *__restrict__ part, int nwg,
+                                                                int *__restrict__ ctl, double *__restrict__ M) {
+    if (ctl[0] != 0) return;
+    extern __shared__ double shb[];                          // lam[n], then partner[n] as ints
+    double *sh_lam = shb;
+    int *sh_partner = reinterpret_cast<int *>(shb + n);
+    __shared__ int sh_go, sh_multi;
+    __shared__ double sh_scale;
+    const int tid = threadIdx.x, r = tid >> 5, l = tid & 31;
+    for (int t = tid; t < n; t += 256) { sh_lam[t] = lam[t]; sh_partner[t] = partner[t]; }
+    if (tid == 0) sh_multi = 0;
+    __syncthreads();
+    for (int t = tid; t < n; t += 256) { const int pj = sh_partner[t]; if (pj >= 0 && sh_partner[pj] != t) sh_multi = 1; }    // a strong pair must be mutual
+    __syncthreads();
+    if (tid == 0) {
+        double off = 0.0, rs = 0.0, cm = 0.0, nstrong = 0.0;
+        int multi = sh_multi, big = 0, notlast = 0;
+        for (int w = 0; w < nwg; ++w) {
+            const double *p = part + 8 * w;
+            off += p[0]; rs += p[1]; cm = fmax(cm, p[2]); nstrong += p[3];
+            multi |= p[4] != 0.0; big |= p[5] != 0.0; notlast |= p[6] != 0.0;
+        }
+        const double scale = part[7], orth = sqrt(rs), scl = fmax(scale, 1e-300);
+        sh_scale = scale;
+        int c0 = 0, c1 = 0, c2 = 0;
+        if (big || !(orth <= 1e-3) || multi) c0 = 2;                          // not perturbative: rotations needed
+        else {
+            c1 = (!notlast && orth <= 1e-7 && nstrong == 0.0) ? 1 : 0;        // one more update finishes
+            c2 = (cm <= 1e-12 * scl) ? 1 : 0;                                 // no coupling left inside degenerate pairs
+        }
+        sh_go = c0 == 0;
+        if (blockIdx.x == 0) {
+            stats[0] = sqrt(off); stats[1] = orth; stats[2] = scale; stats[3] = 0.5 * nstrong; stats[4] = cm;
+            stats[5] = big ? 1.0 : (notlast ? 1e-6 : 0.0); stats[6] = multi;
+            if (c0) ctl[0] = c0; else { ctl[1] = c1; ctl[2] = c2; }
+        }
+    }
+    __syncthreads();
+    if (!sh_go) return;
+    const double scale = sh_scale, tiny = QC_REF_TINY * scale, gfloor = QC_REF_GFLOOR * scale;
+    const int i = blockIdx.x * QC_STATS_ROWS + r;
+    if (i >= n) return;
+    const double li = sh_lam[i];
+    const int pi_ = sh_partner[i];
+    for (int j0 = l; j0 < n; j0 += 128) {
+        double sij[4], sji[4], xij[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int j = j0 + 32 * u;
+            const bool ok = j < n;
+            sij[u] = S[ok ? (size_t)i * n + j : 0]; sji[u] = S[ok ? (size_t)j * n + i : 0]; xij[u] = XtX[ok ? (size_t)i * n + j : 0];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int j = j0 + 32 * u;
+            if (j < n) {
+                const double lj = sh_lam[j];
+                const double rv = (i == j ? 1.0 : 0.0) - xij[u];
+                const double sy = 0.5 * (sij[u] + sji[u]);
+                const double av = sy + 0.5 * (li + lj) * rv, g = lj - li;
+                double mm;
+                if (i == j) {
+                    mm = 1.0 + 0.5 * rv;
+                    if (pi_ >= 0) {
+                        const double avp = 0.5 * (S[(size_t)i * n + pi_] + S[(size_t)pi_ * n + i]) - 0.5 * (li + sh_lam[pi_]) * XtX[(size_t)i * n + pi_];
+                        const double theta = (sh_lam[pi_] - li) / (2.0 * avp);
+                        const double t = (theta >= 0.0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(fma(theta, theta, 1.0)));
+                        mm = 1.0 / sqrt(fma(t, t, 1.0)) + 0.5 * rv;
+                    }
+                } else if (pi_ == j) {
+                    const double theta = g / (2.0 * av);
+                    const double t = (theta >= 0.0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(fma(theta, theta, 1.0)));
+                    mm = t / sqrt(fma(t, t, 1.0));
+                } else if (fabs(av) <= tiny || fabs(g) <= gfloor) mm = 0.5 * rv;
+                else mm = (sy + lj * rv) / g;
+                M[(size_t)i * n + j] = mm;
+            }
+        }
+    }
+}
+// doubles of the scratch behind lam / stats / partner that the two kernels need
+size_t qc_refine_part_doubles(int n) { return 8 * (size_t)((n + QC_STATS_ROWS - 1) / QC_STATS_ROWS); }
+
 // element x of M = I + E, with exact rotations on the strong pairs
 __device__ __forceinline__ double qc_refine_m(int n, int x, const double *__restrict__ S, const double *__restrict__ XtX,
                                               const double *__restrict__ lam, double tiny, double gfloor, const int *__restrict__ partner) {
@@ -691,26 +860,37 @@ __global__ __launch_bounds__(1024) void qc_refine_finish_kernel(int n, const dou
     __syncthreads();
     if (tid == 0) ctl[3] += 1;                              // passes used (the host sizes the next step's pipeline with it)
     if (last && clean) {                                    // Xn holds the final vectors: ascending eigenvalues, columns alongside
+        double *lam_s = reinterpret_cast<double *>(rank_s + ((n + 1) & ~1));      // (the n quotients once, not n times per thread, from L2)
+        for (int i = tid; i < n; i += 1024) lam_s[i] = lam[i];
+        __syncthreads();
         for (int i = tid; i < n; i += 1024) {
-            const double wi = lam[i];
+            const double wi = lam_s[i];
             int r = 0;
-            for (int j = 0; j < n; ++j) r += (lam[j] < wi || (lam[j] == wi && j < i)) ? 1 : 0;
+            for (int j = 0; j < n; ++j) r += (lam_s[j] < wi || (lam_s[j] == wi && j < i)) ? 1 : 0;
             rank_s[i] = r;
             w[r] = wi;
         }
         __syncthreads();
-        for (int x = tid; x < n * n; x += 1024) {
-            const int i = x / n, j = x - i * n;
-            Xs[(size_t)i * n + rank_s[j]] = Xn[x];
+        // thread (row group, column): eight elements requested at a time, no index division
+        const int c = tid & 127, rg = tid >> 7;
+        for (int c0 = 0; c0 < n; c0 += 128) {
+            const int j = c0 + c;
+            const int rj = j < n ? rank_s[j] : 0;
+            for (int i0 = rg; i0 < n; i0 += 64) {
+                double v[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) { const int i = i0 + 8 * u; v[u] = Xn[(j < n && i < n) ? (size_t)i * n + j : 0]; }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) { const int i = i0 + 8 * u; if (j < n && i < n) Xs[(size_t)i * n + rj] = v[u]; }
+            }
         }
         __syncthreads();
         if (tid == 0) ctl[0] = 1;
     } else if (last || final_pass) {
         __syncthreads();
         if (tid == 0) ctl[0] = 2;                           // coupling inside a degenerate cluster, or passes exhausted
-    } else {
-        for (int x = tid; x < n * n; x += 1024) X[x] = Xn[x];
     }
+    // (otherwise the next pass reads Xn in place: the passes alternate between two buffers, no copy)
 }
 
 int qc_eig_refine_async(hipStream_t st, int n, double *dA, const double *dV0, double *dV, double *dw, double *d_work, double *t1, double *t2,
@@ -718,14 +898,25 @@ int qc_eig_refine_async(hipStream_t st, int n, double *dA, const double *dV0, do
     double *lam = small, *stats = small + n;
     int *partner = reinterpret_cast<int *>(small + n + 8);
     // ctl[0..3] must be zero on entry (the SCF step clears all control words with one memset)
-    const double *X = dV0;                                    // pass 0 reads the start vectors in place, later passes t4
+    const double *X = dV0;                                    // pass 0 reads the start vectors in place
     for (int pass = 0; pass < npass; ++pass) {
         qc_gemm_pair(st, n, dA, false, X, t1, X, true, X, t3, ctl);                     // A X  and  X^T X in one launch
         qc_gemm(st, n, n, n, 1.0, X, n, true, t1, n, false, 0.0, t2, n, ctl);           // S = X^T A X
-        hipLaunchKernelGGL(qc_refine_stats_kernel, dim3(1), dim3(1024), 0, st, n, t2, t3, lam, stats, partner, ctl, t1);   // + M = I + E -> t1
-        qc_gemm(st, n, n, n, 1.0, X, n, false, t1, n, false, 0.0, d_work, n, ctl);      // X (I + E)
-        hipLaunchKernelGGL(qc_refine_finish_kernel, dim3(1), dim3(1024), n * sizeof(int), st, n, lam, d_work, t4, dw, dV, ctl, pass == npass - 1 ? 1 : 0);
-        X = t4;
+        {   // statistics, decisions, M = I + E -> t1
+            static const bool one_wg = getenv("QC_STATS_ONE_WG") != nullptr;      // (A/B switch: the single-workgroup kernel)
+            if (one_wg) hipLaunchKernelGGL(qc_refine_stats_kernel, dim3(1), dim3(1024), 0, st, n, t2, t3, lam, stats, partner, ctl, t1);
+            else {
+                const int nwg = (n + QC_STATS_ROWS - 1) / QC_STATS_ROWS;
+                double *part = small + 2 * n + 16;            // (behind lam[n], stats[8], partner[n]: callers allocate qc_eig_small_doubles(n))
+                hipLaunchKernelGGL(qc_refine_statsA_kernel, dim3(nwg), dim3(256), n * sizeof(double), st, n, t2, t3, lam, partner, part, ctl);
+                hipLaunchKernelGGL(qc_refine_statsB_kernel, dim3(nwg), dim3(256), n * sizeof(double) + n * sizeof(int) + 8, st, n, t2, t3, lam, stats, partner,
+                                   part, nwg, ctl, t1);
+            }
+        }
+        double *Xn = (pass & 1) ? t4 : d_work;                // (passes alternate between d_work and t4; pass 0 reads the start vectors in place)
+        qc_gemm(st, n, n, n, 1.0, X, n, false, t1, n, false, 0.0, Xn, n, ctl);          // X (I + E)
+        hipLaunchKernelGGL(qc_refine_finish_kernel, dim3(1), dim3(1024), ((n + 1) & ~1) * sizeof(int) + n * sizeof(double), st, n, lam, Xn, (double *)nullptr, dw, dV, ctl, pass == npass - 1 ? 1 : 0);
+        X = Xn;
     }
     return hipGetLastError() == hipSuccess ? QC_OK : QC_ERR_HIP;
 }
@@ -877,28 +1068,34 @@ __global__ void qc_symmetrize_add_kernel(int n, const double *Gt, size_t lo_off,
 __global__ __launch_bounds__(64) void qc_fold_symmetrize_kernel(int n, int nrep, size_t rep_stride, long long *__restrict__ Gh, size_t lo_off,
                                                                 double *__restrict__ G, const double *__restrict__ H, double *__restrict__ F,
                                                                 const double *__restrict__ fxs) {
-    const int x = blockIdx.x * 64 + threadIdx.x;
-    if (x >= n * n) return;
-    const int i = x / n, j = x - i * n;
-    if (i > j) return;
-    const int xt = j * n + i;
+    // lane = (element of this workgroup's 16, quarter of the replicas): one batch of loads per lane, the quarters meet by shuffles
+    const int e = threadIdx.x >> 2, part = threadIdx.x & 3;
+    const int x = blockIdx.x * 16 + e;
+    const bool in = x < n * n;
+    const int i = in ? x / n : 0, j = in ? x - i * n : 0;
+    const bool act = in && i <= j;
+    const int xx = act ? x : 0, xt = act ? j * n + i : 0;
     long long *__restrict__ Gl = Gh + lo_off;
+    const int per = (nrep + 3) / 4, r0 = part * per, r1 = min(nrep, r0 + per);
     long long h = 0, l = 0;
-    for (int r0 = 0; r0 < nrep; r0 += 8) {
+    for (int rb = r0; rb < r1; rb += 8) {
         long long a[8], b[8], c[8], d[8];
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
-            const size_t o = (size_t)min(r0 + u, nrep - 1) * rep_stride;
-            a[u] = Gh[o + x]; b[u] = Gh[o + xt]; c[u] = Gl[o + x]; d[u] = Gl[o + xt];
+            const size_t o = (size_t)min(rb + u, nrep - 1) * rep_stride;
+            a[u] = Gh[o + xx]; b[u] = Gh[o + xt]; c[u] = Gl[o + xx]; d[u] = Gl[o + xt];
         }
 #pragma unroll
         for (int u = 0; u < 8; ++u)
-            if (r0 + u < nrep) {
+            if (act && rb + u < r1) {
                 h += a[u] + (i == j ? 0 : b[u]); l += c[u] + (i == j ? 0 : d[u]);
-                const size_t o = (size_t)(r0 + u) * rep_stride;
-                Gh[o + x] = 0; Gh[o + xt] = 0; Gl[o + x] = 0; Gl[o + xt] = 0;
+                const size_t o = (size_t)(rb + u) * rep_stride;
+                Gh[o + xx] = 0; Gh[o + xt] = 0; Gl[o + xx] = 0; Gl[o + xt] = 0;
             }
     }
+    h += __shfl_xor(h, 1, 4); l += __shfl_xor(l, 1, 4);
+    h += __shfl_xor(h, 2, 4); l += __shfl_xor(l, 2, 4);
+    if (!act || part != 0) return;
     if (i == j) { h *= 2; l *= 2; }                       // (diagonal: Gt_ii + Gt_ii)
     const double u1 = fxs[1], u2 = u1 * 0x1p-32;
     const double g = fma((double)l, u2, (double)h * u1);
@@ -907,7 +1104,7 @@ __global__ __launch_bounds__(64) void qc_fold_symmetrize_kernel(int n, int nrep,
 }
 void qc_fold_symmetrize(hipStream_t st, int n, int nrep, size_t rep_stride, double *Gt, size_t lo_off, double *G, const double *H, double *F,
                         const double *fxs) {
-    hipLaunchKernelGGL(qc_fold_symmetrize_kernel, dim3((n * n + 63) / 64), dim3(64), 0, st, n, nrep, rep_stride,
+    hipLaunchKernelGGL(qc_fold_symmetrize_kernel, dim3((n * n + 15) / 16), dim3(64), 0, st, n, nrep, rep_stride,
                        reinterpret_cast<long long *>(Gt), lo_off, G, H, F, fxs);
 }
 void qc_symmetrize_add(hipStream_t st, int n, const double *Gt, size_t lo_off, double *G, const double *H, double *F, const double *fxs) {
@@ -986,14 +1183,6 @@ void qc_reduce_replicas(hipStream_t st, size_t count, int nrep, size_t stride, c
     else hipLaunchKernelGGL(qc_reduce_replicas_kernel<double>, dim3(grid), dim3(64), 0, st, count, nrep, stride, nplanes, plane_stride, Gt, out);
 }
 
-__device__ __forceinline__ double block_sum_256(double v, double *sh) {
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
-    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
-    __syncthreads();
-    double r = sh[0] + sh[1] + sh[2] + sh[3];
-    __syncthreads();
-    return r;
-}
 
 // ---------------------------------------------------------------------------------------------------------------
 // Stored-tensor ("conventional") Fock build: the reference's own algorithm with the n^4 tensor resident in HBM
@@ -1093,18 +1282,30 @@ void qc_tensor_gemv(hipStream_t st, int n, const double *T1, const double *D1, c
 
 // out[j] = <x, ys[j]>, one workgroup per j (diis.rs:43-45)
 struct QcPtrList { const double *p[16]; };
-__global__ __launch_bounds__(256) void qc_dots_kernel(int nn, const double *x, QcPtrList ys, double *out) {
-    __shared__ double sh[4];
+__global__ __launch_bounds__(1024) void qc_dots_kernel(int nn, const double *x, QcPtrList ys, double *out) {
+    __shared__ double sh[16];
     const double *y = ys.p[blockIdx.x];
     double s = 0.0;
-    for (int i = threadIdx.x; i < nn; i += 256) s = fma(x[i], y[i], s);
-    s = block_sum_256(s, sh);
-    if (threadIdx.x == 0) out[blockIdx.x] = s;
+    for (int i0 = threadIdx.x; i0 < nn; i0 += 4 * 1024) {       // (four elements of each array requested before the first is used: 16 -> 6 us at n = 114)
+        double a[4], b[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { const int i = min(i0 + u * 1024, nn - 1); a[u] = x[i]; b[u] = y[i]; }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) if (i0 + u * 1024 < nn) s = fma(a[u], b[u], s);
+    }
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o, 64);
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double t = 0.0;
+        for (int k = 0; k < 16; ++k) t += sh[k];
+        out[blockIdx.x] = t;
+    }
 }
 void qc_dots(hipStream_t st, int n, const double *x, const double *const *ys, int ny, double *out) {
     QcPtrList l;
     for (int j = 0; j < ny; ++j) l.p[j] = ys[j];
-    hipLaunchKernelGGL(qc_dots_kernel, dim3(ny), dim3(256), 0, st, n * n, x, l, out);
+    hipLaunchKernelGGL(qc_dots_kernel, dim3(ny), dim3(1024), 0, st, n * n, x, l, out);
 }
 
 // out2[0] = 0.5 tr(Dnew (2H + G)),  out2[1] = sum_i (Dnew - Dold)_ii^2      (rhf.rs:84-88)
@@ -1115,9 +1316,16 @@ __global__ __launch_bounds__(1024) void qc_energy_rms_kernel(int n, const double
                                                              double *out2, int *ctl, int *ctl_out) {
     __shared__ double sh[2][16];
     double e = 0.0, r = 0.0;
-    for (int x = threadIdx.x; x < n * n; x += 1024) {
-        const int i = x / n, j = x - i * n;
-        e = fma(Dn[x], 2.0 * H[j * n + i] + G[j * n + i], e);
+    // tr(Dn (2H + G)) = sum_x Dn[x] (2H + G)[x^T]; H and G are symmetric bit for bit (qc_one_electron.hip, qc_symmetrize_add_kernel), so the
+    // transposed elements are the elements themselves and every read is coalesced; eight elements per thread are requested at a time
+    // (as a chain of thirteen strided trips to L2 this kernel took 25 us at n = 114, now 11)
+    const int nn = n * n;
+    for (int x0 = threadIdx.x; x0 < nn; x0 += 8 * 1024) {
+        double d[8], h[8], g[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { const int x = min(x0 + u * 1024, nn - 1); d[u] = Dn[x]; h[u] = H[x]; g[u] = G[x]; }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) if (x0 + u * 1024 < nn) e = fma(d[u], 2.0 * h[u] + g[u], e);
     }
     for (int i = threadIdx.x; i < n; i += 1024) { const double d = Dn[(size_t)i * n + i] - Do[(size_t)i * n + i]; r = fma(d, d, r); }
     for (int o = 32; o > 0; o >>= 1) { e += __shfl_down(e, o, 64); r += __shfl_down(r, o, 64); }

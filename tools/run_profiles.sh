@@ -1,7 +1,10 @@
-# Round profile set (run on the GPU box through gpurun): bash tools/run_profiles.sh <round tag, e.g. r02>
+# Round profile set (run on the GPU box through gpurun): bash tools/run_profiles.sh <round tag, e.g. r03>
 # Per workload: (1) the bench line itself, (2) rocprofv3 --kernel-trace --stats of the same command, (3) PMC passes in their own
 # runs (separate --pmc passes, nothing but --kernel-trace beside them).  Under rocprofv3 the program goes directly after `--`.
-TAG=${1:-r02}
+# Then, in the SAME invocation: the summaries (tools/make_profile_summary.py -> profiles/<tag>_*) and the default `python bench.py` line,
+# which quotes its HBM traffic from the PMC summary just written - so the two cannot disagree.  Everything lands under
+# gpurun_out/prof_<tag>/ (profiles/ of the box copy is mirrored into gpurun_out/prof_<tag>/profiles/ for the way back).
+TAG=${1:-r03}
 R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/prof_$TAG
 mkdir -p $O
@@ -16,3 +19,10 @@ for W in h2o_ccpvtz c6h6_ccpvdz; do
   rocprofv3 --kernel-trace --pmc WRITE_SIZE TCC_EA0_ATOMIC_sum --output-format csv -d $O/${W}_write -- python $ARGS > /dev/null 2> $O/${W}_write.err || exit 1
   echo "$W done"
 done
+cd $R
+python tools/make_profile_summary.py $TAG $O > $O/summary.txt 2>&1 || { cat $O/summary.txt; exit 1; }
+cat $O/summary.txt
+python bench.py > $O/bench_default.json 2> $O/bench_default.err || exit 1
+cp bench_detail.json $O/bench_default_detail.json
+mkdir -p $O/profiles && cp profiles/${TAG}_* $O/profiles/
+wc -c $O/bench_default.json
