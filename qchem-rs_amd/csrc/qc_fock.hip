@@ -68,6 +68,7 @@ int qc_device_reshard(qc_system *S) {
     S->prepared = false; S->gt_clean = false;                    // a build prepared for the old work lists must not skip the fork of the next one
     S->unit_ms.clear(); S->unit_stream.clear();
     S->cand_stream.clear(); S->cand_weight.clear(); S->cand_ms.clear(); S->cand_n.clear(); S->cand_frozen = false; S->cand_skip = false; S->cand_cur = 0;
+    S->second_stage = 0; S->tune_count = 0; S->inpass_sum = 0.0; S->inpass_n = 0; S->builds_seen = 0;
     qc_build_shards(S);
     if (!S->device_ready) return QC_OK;
     return upload_slots(S);
@@ -485,7 +486,7 @@ int qc_launch_fock_classes(qc_system *S, const QcFockArgs &fa, float *class_ms, 
             for (size_t u = 0; u < units.size(); ++u) if (!units[u].empty()) act.push_back((int)u);
             float tcur = 0.f;
             if ((rc = measure(cur, tcur)) != QC_OK) return rc;
-            unsigned rng = 2463534242u;
+            unsigned rng = 2463534242u + 40503u * (unsigned)S->tune_count;      // (a second tuner run takes another path)
             auto next = [&]() { rng ^= rng << 13; rng ^= rng >> 17; rng ^= rng << 5; return rng >> 4; };
             float spent = 0.f;
             for (int step = 0; step < QC_TUNE_LOCAL && act.size() > 1 && (step < 8 || spent < 100.f); ++step) {
@@ -541,6 +542,7 @@ int qc_launch_fock_classes(qc_system *S, const QcFockArgs &fa, float *class_ms, 
             if (fin_c[r] == best) S->cand_cur = (int)S->cand_stream.size() - 1;
         }
         S->unit_stream = cand[best]; S->unit_weight = weight[best];
+        S->tuned_best_ms = best_t; S->tune_count += 1; S->inpass_sum = 0.0; S->inpass_n = 0;
         S->cand_skip = true;                             // (the time of THIS build contains the tuning)
         if (fa.G0) QC_HIP_CHECK(hipMemsetAsync(fa.G0, 0, gbytes, S->stream));
         nofork = false;                                  // the side streams must see that memset (and the tuner's builds) finished
@@ -554,9 +556,36 @@ int qc_launch_fock_classes(qc_system *S, const QcFockArgs &fa, float *class_ms, 
 // QC_ONLINE_SAMPLES of them in turn (the first after a switch is not counted), then the best mean stays.  Stream assignment does not
 // change results (integer accumulation), only time.
 constexpr int QC_ONLINE_SAMPLES = 3;
+constexpr int QC_INPASS_SAMPLES = 4;
 void qc_fock_feedback(qc_system *S, float build_ms) {
-    const int nc = (int)S->cand_stream.size();
-    if (nc < 2 || S->cand_frozen || S->unit_stream.empty()) return;
+    int nc = (int)S->cand_stream.size();
+    if (S->unit_stream.empty()) return;
+    S->builds_seen += 1;
+    // (the second tuner run keeps its own best: no sampling of finalists, the whole procedure ends within a dozen builds)
+    if (S->second_stage == 1 && nc >= 2 && !S->cand_frozen) { S->cand_frozen = true; nc = 0; }
+    static const bool no_second = getenv("QC_TUNE_ONCE") != nullptr;           // (A/B switch)
+    if ((nc < 2 || S->cand_frozen) && S->second_stage < 2 && !no_second) {
+        // second opinion: in-pass mean of the current assignment against the tuner's figure
+        if (S->cand_skip) { S->cand_skip = false; return; }
+        S->inpass_sum += build_ms; S->inpass_n += 1;
+        if (S->inpass_n < QC_INPASS_SAMPLES) return;
+        const double mean = S->inpass_sum / S->inpass_n;
+        static const bool dbg = getenv("QC_TUNE_DEBUG") != nullptr;
+        if (S->second_stage == 0) {
+            if (mean <= 1.10 * S->tuned_best_ms || S->builds_seen > 8) { S->second_stage = 2; return; }       // (good enough, or too late in the run)
+            if (dbg) fprintf(stderr, "[tune] in-pass builds %.3f ms vs %.3f ms tuned: one more tuner run\n", mean, S->tuned_best_ms);
+            S->first_mean = mean; S->first_stream = S->unit_stream; S->first_weight = S->unit_weight;
+            S->second_stage = 1;
+            S->unit_ms.clear();                            // the next build tunes again (its time is not counted: cand_skip)
+            S->cand_stream.clear(); S->cand_weight.clear(); S->cand_ms.clear(); S->cand_n.clear(); S->cand_frozen = false; S->cand_cur = 0;
+        } else {
+            if (dbg) fprintf(stderr, "[tune] in-pass builds: first choice %.3f ms, second %.3f ms\n", S->first_mean, mean);
+            if (S->first_mean < mean) { S->unit_stream = S->first_stream; S->unit_weight = S->first_weight; S->cand_stream.clear(); S->cand_frozen = true; }
+            S->second_stage = 2;
+        }
+        return;
+    }
+    if (nc < 2 || S->cand_frozen) return;
     const int c = S->cand_cur;
     if (S->cand_skip) S->cand_skip = false;            // first build after a switch: not counted
     else { S->cand_ms[c] += build_ms; S->cand_n[c] += 1; }

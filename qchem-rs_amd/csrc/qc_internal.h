@@ -160,6 +160,15 @@ struct qc_system {
     std::vector<int> cand_n;
     int cand_cur = 0;
     bool cand_frozen = false, cand_skip = false;
+    // second opinion (qc_fock_feedback): the tuner measures builds back to back; inside SCF passes the same assignment is 7-22 % slower,
+    // and by how much differs from one tuner run to the next.  When the passes' builds are > 10 % slower than the tuner's figure, the
+    // tuner runs ONCE more and the assignment with the better in-pass mean stays.
+    float tuned_best_ms = 0.f;               // the tuner's own figure for its choice
+    int tune_count = 0;                      // tuner runs on this shard layout
+    int second_stage = 0;                    // 0 sampling the first choice, 1 sampling the second, 2 decided
+    double inpass_sum = 0.0; int inpass_n = 0, builds_seen = 0;
+    double first_mean = 0.0;
+    std::vector<int> first_stream; std::vector<float> first_weight;
     // accumulators zeroed, fixed-point scale (and the UHF density sum) already enqueued for a build from exactly these densities, and the host
     // has waited for the handle's stream since (qc_fock_prepare_device): the build then starts its side streams without a fork
     bool prepared = false;

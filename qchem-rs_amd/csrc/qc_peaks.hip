@@ -1,5 +1,8 @@
 // qc_peaks.hip - the two measured ceilings the roofline is quoted against next to the datasheet ones: what a
 // register-resident v_fma_f64 loop and a 16-byte streaming copy reach on THIS device, measured by the harness outside its timed region.
+#include <cstdio>
+#include <cstdlib>
+
 #include "qc_internal.h"
 
 namespace {
@@ -22,13 +25,20 @@ __global__ __launch_bounds__(256) void qc_peak_fma_kernel(int iters, double seed
     if (s == 12345.678) out[0] = s;              // keeps the chains alive, never true
 }
 
-// STREAM copy: 16-byte loads and stores, four in flight per lane, grid-stride
+// STREAM copy: 16-byte loads and stores, eight in flight per lane, grid-stride; NT = nontemporal stores (write-once data)
+template <bool NT>
 __global__ __launch_bounds__(256) void qc_peak_copy_kernel(size_t n4, const double2 *__restrict__ src, double2 *__restrict__ dst) {
     const size_t stride = (size_t)gridDim.x * blockDim.x;
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    for (; i + 3 * stride < n4; i += 4 * stride) {
-        const double2 v0 = src[i], v1 = src[i + stride], v2 = src[i + 2 * stride], v3 = src[i + 3 * stride];
-        dst[i] = v0; dst[i + stride] = v1; dst[i + 2 * stride] = v2; dst[i + 3 * stride] = v3;
+    for (; i + 7 * stride < n4; i += 8 * stride) {
+        double2 v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = src[i + u * stride];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            if (NT) { __builtin_nontemporal_store(v[u].x, &dst[i + u * stride].x); __builtin_nontemporal_store(v[u].y, &dst[i + u * stride].y); }
+            else dst[i + u * stride] = v[u];
+        }
     }
     for (; i < n4; i += stride) dst[i] = src[i];
 }
@@ -57,13 +67,20 @@ extern "C" int qc_measure_peaks(double *fp64_tflops, double *hbm_copy_gbs) {
             if (hipEventSynchronize(e1) != hipSuccess) { rc = QC_ERR_HIP; break; }
             float ms = 0.f; (void)hipEventElapsedTime(&ms, e0, e1);
             if (rep > 0 && ms < best_f) best_f = ms;
-            (void)hipEventRecord(e0, st);
-            hipLaunchKernelGGL(qc_peak_copy_kernel, dim3(256 * 16), dim3(256), 0, st, bytes / 16, reinterpret_cast<const double2 *>(buf),
-                               reinterpret_cast<double2 *>(buf + bytes / 8));
-            (void)hipEventRecord(e1, st);
-            if (hipEventSynchronize(e1) != hipSuccess) { rc = QC_ERR_HIP; break; }
-            (void)hipEventElapsedTime(&ms, e0, e1);
-            if (rep > 0 && ms < best_c) best_c = ms;
+            for (int variant = 0; variant < 4; ++variant) {       // grid 8 / 16 workgroups per CU x plain / nontemporal stores: the best counts
+                const int g = 256 * (variant & 1 ? 16 : 8);
+                (void)hipEventRecord(e0, st);
+                if (variant & 2) hipLaunchKernelGGL(qc_peak_copy_kernel<true>, dim3(g), dim3(256), 0, st, bytes / 16, reinterpret_cast<const double2 *>(buf),
+                                                    reinterpret_cast<double2 *>(buf + bytes / 8));
+                else hipLaunchKernelGGL(qc_peak_copy_kernel<false>, dim3(g), dim3(256), 0, st, bytes / 16, reinterpret_cast<const double2 *>(buf),
+                                        reinterpret_cast<double2 *>(buf + bytes / 8));
+                (void)hipEventRecord(e1, st);
+                if (hipEventSynchronize(e1) != hipSuccess) { rc = QC_ERR_HIP; break; }
+                (void)hipEventElapsedTime(&ms, e0, e1);
+                if (rep > 0 && ms < best_c) best_c = ms;
+                if (getenv("QC_PEAKS_DEBUG")) fprintf(stderr, "[peaks] copy variant %d: %.3f ms = %.0f GB/s\n", variant, ms, 2.0 * (double)bytes / (ms * 1e-3) / 1e9);
+            }
+            if (rc != QC_OK) break;
         }
         if (rc != QC_OK) break;
         *fp64_tflops = 2.0 * 64.0 * iters * (double)grid * 256.0 / (best_f * 1e-3) / 1e12;
