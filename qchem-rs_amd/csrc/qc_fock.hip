@@ -290,6 +290,10 @@ static int launch_segments(qc_system *S, int unit, const std::vector<Seg> &segs,
         ++k;
     }
     t.nseg = k;
+    {   // (experiment switch: extra dynamic LDS per workgroup - does the build respond to the LDS the column kernels hold?)
+        static const int pad_kb = getenv("QC_LDS_PAD_KB") ? atoi(getenv("QC_LDS_PAD_KB")) : 0;
+        if (pad_kb > 0 && lds + pad_kb * 1024 <= QC_LDS_MAX) lds += pad_kb * 1024;
+    }
     // a wide-ket launch made of d.d / f.p-ket buckets only (no basis function above d): the kernel variant without the f-ket bodies
     int tier = unit % 2;
     if (tier == 1) {

@@ -32,7 +32,10 @@ constexpr double QC_SCHWARZ_TAU = 1e-12; // quartets with sqrt((ab|ab) (cd|cd)) 
 constexpr int QC_LDS_MAX = 160 * 1024;  // LDS of a gfx950 CU, the cap the kernels with dynamic LDS are allowed
 constexpr int QC_TUNE_ROUNDS = 6;        // concurrent builds measured before the stream assignment is frozen
 constexpr int QC_TUNE_LOCAL = 128;        // local-search steps (move / swap of launches between streams) around the best of them
-constexpr int QC_NSTREAMS = 7;          // class kernels of one build run concurrently on this many streams
+#ifndef QC_NSTREAMS_N
+#define QC_NSTREAMS_N 7
+#endif
+constexpr int QC_NSTREAMS = QC_NSTREAMS_N;  // class kernels of one build run concurrently on this many streams (compile-time: A/B builds)
 constexpr int QC_NUNITS = 2 * (QC_LPAIR + 1) + 4;   // launch units of one build: (LAB, tier) of the column kernels + 4 bra-major launches
 
 __host__ __device__ constexpr int qc_nherm(int L) { return (L + 1) * (L + 2) * (L + 3) / 6; }
