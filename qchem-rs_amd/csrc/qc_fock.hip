@@ -264,6 +264,8 @@ static int launch_segments(qc_system *S, int unit, const std::vector<Seg> &segs,
         }
         t.nseg = k;
         const int lds = QC_BM_LDS_TABLE + nw * wbytes;
+        static const bool lds_dbg = getenv("QC_LDS_DEBUG") != nullptr;
+        if (lds_dbg) fprintf(stderr, "[lds] bm<%d,%d>: %d workgroups x %d waves, %d bytes of LDS per workgroup (table %d, per wave %d)\n", v / 2, v % 2, grid, nw, lds, QC_BM_LDS_TABLE, wbytes);
         return qc_launch_bm(v / 2, v % 2, grid, nw, (size_t)lds, st, t);
     }
     QcTierArgs t{};
@@ -300,6 +302,12 @@ static int launch_segments(qc_system *S, int unit, const std::vector<Seg> &segs,
         bool only4 = true;
         for (const Seg &sg : segs) only4 = only4 && sg.c->LCD == 4;
         if (only4) tier = 2;
+    }
+    static const bool lds_dbg = getenv("QC_LDS_DEBUG") != nullptr;
+    if (lds_dbg) {
+        fprintf(stderr, "[lds] tier<%d,%d>: %d workgroups (1 wave), %d bytes of LDS per workgroup; segments:", unit / 2, tier, grid, lds);
+        for (const Seg &sg : segs) fprintf(stderr, " <%d,%d,%d> %d slots %d B", sg.c->LAB, sg.c->LCD, sg.c->LGC, sg.nslots, sg.c->lds_bytes);
+        fprintf(stderr, "\n");
     }
     return launch_tier(unit / 2, tier, grid, (size_t)lds, st, t);
 }
