@@ -193,10 +193,13 @@ __device__ __forceinline__ void qc_bm_body(const QcKernelArgs &a, const double *
     const int strideB = qc_pair_stride(LAB, nab);
 
     const bool active = lane < nket;
-    const int ket = ketlist[first + (active ? lane : 0)];
+    // entry: ket pair | first primitive << 18 | primitives << 25 (0: the whole pair) - qc_make_bundles
+    const unsigned kent = (unsigned)ketlist[first + (active ? lane : 0)];
+    const int ket = (int)(kent & 0x3ffffu), kl0 = (int)((kent >> 18) & 0x7fu), klen = (int)(kent >> 25);
     const QcPairDesc pk = a.pairs[ket];
-    const int K_cd = active ? pk.K : 0, Kc1 = max(K_cd - 1, 0);
-    const double *__restrict__ ketBase = (LCD == 0) ? pd + pk.doff : pspack + pk.psoff;
+    const int K_cd = active ? (klen ? klen : pk.K) : 0, Kc1 = max(K_cd - 1, 0);
+    constexpr int strideK0 = (LCD == 0) ? qc_pair_stride(0, 1) : 8;
+    const double *__restrict__ ketBase = ((LCD == 0) ? pd + pk.doff : pspack + pk.psoff) + (size_t)kl0 * strideK0;
     double *const I = Iw + lane;                              // I[x * LS], x = ab * NC + col
 
     for (int x = 0; x < nab * NC; ++x) I[x * LS] = 0.0;

@@ -281,7 +281,8 @@ inline int qc_shard_owner(size_t i, int nranks, size_t ci) {
 }
 void qc_make_slots(const qc_system *S, const std::vector<QcTask> &tasks, int itmax, bool split_cols, std::vector<QcSlot> &out);
 // group tasks by bra into bundles of <= 64 kets (sorted by primitive count); itmax > 0 also cuts the bra primitive range
-void qc_make_bundles(const qc_system *S, const std::vector<QcTask> &tasks, int itmax, std::vector<QcBundle> &bundles, std::vector<int> &ketlist);
+// (unit > 0: lanes take chunks of at most `unit` primitives of a ket pair, packed into the ketlist entry; 0: whole pairs)
+void qc_make_bundles(const qc_system *S, const std::vector<QcTask> &tasks, int itmax, std::vector<QcBundle> &bundles, std::vector<int> &ketlist, int unit = 0);
 inline int qc_unit_of(int LAB, int LCD, bool bm) { return bm ? 2 * (QC_LPAIR + 1) + 2 * LCD + (LAB >= 3 ? 1 : 0) : 2 * LAB + (LCD >= 4 ? 1 : 0); }
 void qc_dots(hipStream_t st, int n, const double *x, const double *const *ys, int ny, double *out);  // device ptr list
 void qc_lincomb(hipStream_t st, int n, const double *const *Fs, const double *c, int m, double *out);   // out = sum c_i Fs_i

@@ -322,8 +322,49 @@ void qc_make_slots(const qc_system *S, const std::vector<QcTask> &tasks, int itm
 // Bra-major work units: the tasks of one bra pair, kets sorted by primitive count (so the lanes of a wave run nearly
 // equal trip counts), cut into bundles of at most 64 kets; with itmax > 0 a bundle is further cut along the bra primitive
 // pairs so that a lane evaluates about itmax primitive quartets.
-void qc_make_bundles(const qc_system *S, const std::vector<QcTask> &tasks, int itmax, std::vector<QcBundle> &bundles, std::vector<int> &ketlist) {
+// `unit` > 0 (round 3): a lane's work unit is a CHUNK of at most `unit` primitives of a ket pair instead of the whole pair - the entry of
+// `ketlist` then carries the chunk (ket | first primitive << 18 | length << 25, seven bits each; length 0 = the whole pair, as the set-up
+// passes use it).  Integrals are linear in the ket primitives and the digestion is linear in the integrals, so every chunk is digested on its own.
+// With whole pairs a wave runs as long as its most contracted ket (64 primitive pairs for a pair of contracted s shells) while the
+// lanes of single-primitive kets idle, and a molecule with few shell pairs cannot fill 64 lanes per bra at all (H2O/cc-pVTZ: 55 ss
+// pairs); chunks of equal length fill the lanes and bound the trip count.
+void qc_make_bundles(const qc_system *S, const std::vector<QcTask> &tasks, int itmax, std::vector<QcBundle> &bundles, std::vector<int> &ketlist, int unit) {
     bundles.clear(); ketlist.clear();
+    if (unit > 0 && S->pairs.size() < (1u << 18)) {
+        struct U { int bra, ket, kl0, len; };
+        std::vector<U> us;
+        for (const auto &t : tasks) {
+            const int K = S->pairs[t.ket].K;
+            if (K > 127) { us.clear(); break; }                  // (does not fit the packed entry: whole pairs below)
+            const int nch = (K + unit - 1) / unit;
+            for (int c = 0; c < nch; ++c) {
+                const int lo = (int)((int64_t)K * c / nch), hi = (int)((int64_t)K * (c + 1) / nch);
+                us.push_back(U{t.bra, t.ket, lo, hi - lo});
+            }
+        }
+        if (!us.empty()) {
+            std::stable_sort(us.begin(), us.end(), [](const U &x, const U &y) { return x.bra != y.bra ? x.bra < y.bra : x.len > y.len; });
+            for (size_t i = 0; i < us.size();) {
+                size_t j = i;
+                while (j < us.size() && us[j].bra == us[i].bra && j - i < 64) ++j;
+                const int Kab = S->pairs[us[i].bra].K, maxK = us[i].len;
+                const int first = (int)ketlist.size();
+                for (size_t k = i; k < j; ++k) ketlist.push_back((int)((unsigned)us[k].ket | ((unsigned)us[k].kl0 << 18) | ((unsigned)us[k].len << 25)));
+                // bra primitive pairs per bundle: about max(itmax, 32) primitive quartets per lane, so that the digestion of a partial block
+                // (two to three primitive quartets' worth of instructions) stays a small share
+                static const int pq_env = getenv("QC_BM_PQ") ? atoi(getenv("QC_BM_PQ")) : 32;           // (A/B switch)
+                const int rows = std::max(1, std::min(Kab, std::max(itmax, pq_env) / std::max(maxK, 1)));
+                const int nparts = (Kab + rows - 1) / rows;
+                for (int sp = 0; sp < nparts; ++sp)
+                    bundles.push_back(QcBundle{us[i].bra, (int)((int64_t)Kab * sp / nparts), (int)((int64_t)Kab * (sp + 1) / nparts), first, (int)(j - i), maxK, 0, 0});
+                i = j;
+            }
+            std::stable_sort(bundles.begin(), bundles.end(), [](const QcBundle &x, const QcBundle &y) {
+                return (int64_t)(x.ij_hi - x.ij_lo) * x.maxK > (int64_t)(y.ij_hi - y.ij_lo) * y.maxK;
+            });
+            return;
+        }
+    }
     std::vector<QcTask> t(tasks);
     std::stable_sort(t.begin(), t.end(), [&](const QcTask &x, const QcTask &y) {
         if (x.bra != y.bra) return x.bra < y.bra;
@@ -391,6 +432,20 @@ void qc_build_shards(qc_system *S) {
             c.bm_rows = 0;
             for (const auto &t : c.shard) c.bm_rows = std::max(c.bm_rows, S->pairs[t.bra].na + S->pairs[t.bra].nb);
             qc_make_bundles(S, c.shard, itmax, c.bundles, c.ketlist);
+            // ket-primitive chunks instead of whole ket pairs where they save lane-iterations: cost of a list = sum over its bundles of
+            // (bra primitive pairs x longest chunk) + the digestion of the lanes' partial blocks (~6 primitive quartets' worth per bundle)
+            static const int unit_env = getenv("QC_BM_UNIT") ? atoi(getenv("QC_BM_UNIT")) : 8;       // (A/B switch: 0 = whole ket pairs)
+            if (unit_env > 0) {
+                auto cost = [](const std::vector<QcBundle> &bs) { int64_t t = 0; for (const auto &b : bs) t += (int64_t)(b.ij_hi - b.ij_lo) * b.maxK + 6; return t; };
+                std::vector<QcBundle> ub; std::vector<int> uk;
+                qc_make_bundles(S, c.shard, itmax, ub, uk, unit_env);
+                // (measured, three alternating runs each: a list that fills the chip - benzene - gains only where the model promises > 20 %
+                // (build 1.66 -> 1.58 ms; 1.67-1.71 when every class with any modelled gain switches); a list that cannot - H2O, where a
+                // launch is as long as its longest wave - gains from balance even at a modelled loss (build 0.271 -> 0.233 ms))
+                static const int gain_env = getenv("QC_BM_GAIN") ? atoi(getenv("QC_BM_GAIN")) : 0;       // (A/B switch: percent of the old cost)
+                const int gain = gain_env > 0 ? gain_env : (c.bundles.size() < 4096 ? 120 : 80);
+                if (!ub.empty() && cost(ub) * 100 < cost(c.bundles) * gain) { c.bundles.swap(ub); c.ketlist.swap(uk); }
+            }
         }
         else {
             qc_make_slots(S, c.shard, itmax, false, c.slots);
