@@ -150,9 +150,15 @@ __device__ __forceinline__ void qc_dot4_bc(double (&acc)[4], const double (&Er)[
     ((qc_fmac_bc<(H & 15)>(acc[0], Er[0][H >> 4], W[H]), qc_fmac_bc<(H & 15)>(acc[1], Er[1][H >> 4], W[H]),
       qc_fmac_bc<(H & 15)>(acc[2], Er[2][H >> 4], W[H]), qc_fmac_bc<(H & 15)>(acc[3], Er[3][H >> 4], W[H])), ...);
 }
-constexpr int QC_DPP_BATCH = 8;
-template <int LAB, int NR, int H0, int... J>
-__device__ __forceinline__ void qc_step2_dpp_batch(double (&W)[qc_nherm(LAB)], const double (&Rd)[NR], const double (&e)[QC_DPP_BATCH],
+// ket coefficients of step 2 arrive in batches of 8, one batch ahead of the FMAs that use them.  (16 per batch for the d.d ... f.f kets -
+// 35 / 56 / 84 coefficients per column, where a batch's FMAs are shorter than the next batch's trip to L2 - was measured in round 3,
+// -DQC_DPPB_HI=16: H2O build 0.233 -> 0.252 ms, benzene 1.635 -> 1.652: the registers cost more than the latency gives.)
+#ifndef QC_DPPB_HI
+#define QC_DPPB_HI 8
+#endif
+__host__ __device__ constexpr int qc_dpp_batch(int LCD) { return LCD >= 4 ? QC_DPPB_HI : 8; }
+template <int LAB, int NR, int H0, int NBT, int... J>
+__device__ __forceinline__ void qc_step2_dpp_batch(double (&W)[qc_nherm(LAB)], const double (&Rd)[NR], const double (&e)[NBT],
                                                    double sc, std::integer_sequence<int, J...>) {
     (qc_step2_dpp_row<LAB, NR, H0 + J>(W, Rd, e[J] * ((qc_order_of<H0 + J>() & 1) ? -sc : sc),
                                        std::make_integer_sequence<int, qc_nherm(LAB)>{}), ...);
@@ -160,44 +166,44 @@ __device__ __forceinline__ void qc_step2_dpp_batch(double (&W)[qc_nherm(LAB)], c
 // Batches H0.. of one primitive quartet.  Before the FMAs of the last batch the first coefficients (eN) and the R
 // registers (RdN) of the *next* primitive quartet are requested, so a step never starts by waiting for its operands.
 template <int LAB, int LCD, int NR, int H0>
-__device__ __forceinline__ void qc_step2_dpp_from(double (&W)[qc_nherm(LAB)], const double (&Rd)[NR], const double (&e)[QC_DPP_BATCH],
+__device__ __forceinline__ void qc_step2_dpp_from(double (&W)[qc_nherm(LAB)], const double (&Rd)[NR], const double (&e)[qc_dpp_batch(LCD)],
                                                   const double *__restrict__ Ecd, int ncd, double sc,
                                                   const double *__restrict__ EcdN, const double *__restrict__ RwN, int l16,
-                                                  double (&eN)[QC_DPP_BATCH], double (&RdN)[NR]) {
-    constexpr int HCD = qc_nherm(LCD), HR = qc_nherm(LAB + LCD), NB = (HCD - H0 < QC_DPP_BATCH) ? HCD - H0 : QC_DPP_BATCH;
+                                                  double (&eN)[qc_dpp_batch(LCD)], double (&RdN)[NR]) {
+    constexpr int HCD = qc_nherm(LCD), HR = qc_nherm(LAB + LCD), NB = (HCD - H0 < qc_dpp_batch(LCD)) ? HCD - H0 : qc_dpp_batch(LCD);
     if constexpr (H0 + NB < HCD) {
-        double en[QC_DPP_BATCH];
+        double en[qc_dpp_batch(LCD)];
 #pragma unroll
-        for (int j = 0; j < QC_DPP_BATCH; ++j) en[j] = (H0 + NB + j < HCD) ? Ecd[(size_t)(H0 + NB + j) * ncd] : 0.0;
+        for (int j = 0; j < qc_dpp_batch(LCD); ++j) en[j] = (H0 + NB + j < HCD) ? Ecd[(size_t)(H0 + NB + j) * ncd] : 0.0;
         __builtin_amdgcn_sched_barrier(0);          // the next batch is requested before this one's FMAs
-        qc_step2_dpp_batch<LAB, NR, H0>(W, Rd, e, sc, std::make_integer_sequence<int, NB>{});
+        qc_step2_dpp_batch<LAB, NR, H0, qc_dpp_batch(LCD)>(W, Rd, e, sc, std::make_integer_sequence<int, NB>{});
         qc_step2_dpp_from<LAB, LCD, NR, H0 + NB>(W, Rd, en, Ecd, ncd, sc, EcdN, RwN, l16, eN, RdN);
     } else {
 #pragma unroll
-        for (int j = 0; j < QC_DPP_BATCH; ++j) eN[j] = (j < HCD) ? EcdN[(size_t)j * ncd] : 0.0;
+        for (int j = 0; j < qc_dpp_batch(LCD); ++j) eN[j] = (j < HCD) ? EcdN[(size_t)j * ncd] : 0.0;
 #pragma unroll
         for (int k = 0; k < NR; ++k) RdN[k] = RwN[min(16 * k + l16, HR - 1)];
         __builtin_amdgcn_sched_barrier(0);
-        qc_step2_dpp_batch<LAB, NR, H0>(W, Rd, e, sc, std::make_integer_sequence<int, NB>{});
+        qc_step2_dpp_batch<LAB, NR, H0, qc_dpp_batch(LCD)>(W, Rd, e, sc, std::make_integer_sequence<int, NB>{});
     }
 }
 // operands of the first primitive quartet of a run
 template <int LAB, int LCD, int NR>
 __device__ __forceinline__ void qc_step2_dpp_first(const double *__restrict__ Ecd, int ncd, const double *__restrict__ Rw, int l16,
-                                                   double (&e)[QC_DPP_BATCH], double (&Rd)[NR]) {
+                                                   double (&e)[qc_dpp_batch(LCD)], double (&Rd)[NR]) {
     constexpr int HCD = qc_nherm(LCD), HR = qc_nherm(LAB + LCD);
 #pragma unroll
-    for (int j = 0; j < QC_DPP_BATCH; ++j) e[j] = (j < HCD) ? Ecd[(size_t)j * ncd] : 0.0;
+    for (int j = 0; j < qc_dpp_batch(LCD); ++j) e[j] = (j < HCD) ? Ecd[(size_t)j * ncd] : 0.0;
 #pragma unroll
     for (int k = 0; k < NR; ++k) Rd[k] = Rw[min(16 * k + l16, HR - 1)];
 }
 // one primitive quartet on its own (cooperative-table classes: the table of the next one does not exist yet)
 // (`e` = the first batch of ket coefficients, requested by the caller before it built the table)
 template <int LAB, int LCD>
-__device__ __forceinline__ void qc_step2_dpp(double (&W)[qc_nherm(LAB)], const double (&e)[QC_DPP_BATCH], const double *__restrict__ Ecd, int ncd, double sc,
+__device__ __forceinline__ void qc_step2_dpp(double (&W)[qc_nherm(LAB)], const double (&e)[qc_dpp_batch(LCD)], const double *__restrict__ Ecd, int ncd, double sc,
                                              const double *__restrict__ Rw, int lane) {
     constexpr int NR = (qc_nherm(LAB + LCD) + 15) / 16, HR = qc_nherm(LAB + LCD);
-    double Rd[NR], eN[QC_DPP_BATCH], RdN[NR];
+    double Rd[NR], eN[qc_dpp_batch(LCD)], RdN[NR];
 #pragma unroll
     for (int k = 0; k < NR; ++k) Rd[k] = Rw[min(16 * k + (lane & 15), HR - 1)];
     qc_step2_dpp_from<LAB, LCD, NR, 0>(W, Rd, e, Ecd, ncd, sc, Ecd, Rw, lane & 15, eN, RdN);
@@ -683,7 +689,7 @@ __device__ __forceinline__ void qc_fock_body(const QcKernelArgs &a, const QcSlot
                         const int l16 = lane & 15, colo = colok ? col : 0;
                         double prefN = meta[0];
                         int2 ikN = reinterpret_cast<const int2 *>(meta)[1];
-                        double eA[QC_DPP_BATCH], RdA[NR];
+                        double eA[qc_dpp_batch(LCD)], RdA[NR];
                         qc_step2_dpp_first<LAB, LCD, NR>(ketBase + ikN.y + colo, ncd, Rw, l16, eA, RdA);
                         for (int s = 0; s < nB; ++s) {
                             const bool valid = it0 + s < len;
@@ -699,9 +705,9 @@ __device__ __forceinline__ void qc_fock_body(const QcKernelArgs &a, const QcSlot
                                 cur_ij = ik.x;
                             }
                             const double sc = (valid && colok) ? pref : 0.0;
-                            double ec[QC_DPP_BATCH], Rdc[NR];
+                            double ec[qc_dpp_batch(LCD)], Rdc[NR];
 #pragma unroll
-                            for (int j = 0; j < QC_DPP_BATCH; ++j) ec[j] = eA[j];
+                            for (int j = 0; j < qc_dpp_batch(LCD); ++j) ec[j] = eA[j];
 #pragma unroll
                             for (int k = 0; k < NR; ++k) Rdc[k] = RdA[k];
                             qc_step2_dpp_from<LAB, LCD, NR, 0>(W, Rdc, ec, ketBase + ik.y + colo, ncd, sc, ketBase + ikN.y + colo,
@@ -734,11 +740,11 @@ __device__ __forceinline__ void qc_fock_body(const QcKernelArgs &a, const QcSlot
                     hb = *reinterpret_cast<const double4 *>(braBase + (size_t)ij * strideB);
                     hk = *reinterpret_cast<const double4 *>(ketBase + (size_t)kl * strideK);
                 }
-                double e0[QC_DPP_BATCH];               // first ket coefficients: on their way while the table is built
+                double e0[qc_dpp_batch(LCD)];               // first ket coefficients: on their way while the table is built
                 {
                     const double *E0 = ket + 4 + (colok ? col : 0);
 #pragma unroll
-                    for (int j = 0; j < QC_DPP_BATCH; ++j) e0[j] = (j < HCD) ? E0[(size_t)j * ncd] : 0.0;
+                    for (int j = 0; j < qc_dpp_batch(LCD); ++j) e0[j] = (j < HCD) ? E0[(size_t)j * ncd] : 0.0;
                 }
                 const double p = cb.x, q = ck.x;
                 const double X = cb.y - ck.y, Y = cb.z - ck.z, Z = cb.w - ck.w;
