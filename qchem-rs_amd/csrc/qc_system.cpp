@@ -432,19 +432,24 @@ void qc_build_shards(qc_system *S) {
             c.bm_rows = 0;
             for (const auto &t : c.shard) c.bm_rows = std::max(c.bm_rows, S->pairs[t.bra].na + S->pairs[t.bra].nb);
             qc_make_bundles(S, c.shard, itmax, c.bundles, c.ketlist);
-            // ket-primitive chunks instead of whole ket pairs where they save lane-iterations: cost of a list = sum over its bundles of
-            // (bra primitive pairs x longest chunk) + the digestion of the lanes' partial blocks (~6 primitive quartets' worth per bundle)
+            // ket-primitive chunks instead of whole ket pairs where they save instructions of the slowest lanes (model below)
             static const int unit_env = getenv("QC_BM_UNIT") ? atoi(getenv("QC_BM_UNIT")) : 8;       // (A/B switch: 0 = whole ket pairs)
             if (unit_env > 0) {
+                // Model of a list: sum over its bundles of (bra primitive pairs x longest chunk) + 6 for the digestion of the lanes' partial
+                // blocks.  Measured (four alternating runs each, H2O / benzene build in ms; whole pairs 0.269 / 1.642): chunks wherever this
+                // model gains 0.229 / 1.640; only in the launches of the low bras (LAB <= 2) 0.240 / 1.601; with a model that also prices
+                // step 3 - paid per bra primitive pair and LANE, 4116 FMAs for an (ff| bra, whatever the chunk length - 0.233 / 1.635.  So:
+                // the low-bra launches switch where the model gains (>= 20 % for lists that fill the chip, any modelled gain and up to a
+                // 20 % modelled loss for lists that cannot - there a launch is as long as its longest wave); the high-bra launches only when
+                // the list is tiny (H2O's 192 bundles).
                 auto cost = [](const std::vector<QcBundle> &bs) { int64_t t = 0; for (const auto &b : bs) t += (int64_t)(b.ij_hi - b.ij_lo) * b.maxK + 6; return t; };
                 std::vector<QcBundle> ub; std::vector<int> uk;
                 qc_make_bundles(S, c.shard, itmax, ub, uk, unit_env);
-                // (measured, three alternating runs each: a list that fills the chip - benzene - gains only where the model promises > 20 %
-                // (build 1.66 -> 1.58 ms; 1.67-1.71 when every class with any modelled gain switches); a list that cannot - H2O, where a
-                // launch is as long as its longest wave - gains from balance even at a modelled loss (build 0.271 -> 0.233 ms))
                 static const int gain_env = getenv("QC_BM_GAIN") ? atoi(getenv("QC_BM_GAIN")) : 0;       // (A/B switch: percent of the old cost)
+                const bool high_bra = c.LAB >= 3;
                 const int gain = gain_env > 0 ? gain_env : (c.bundles.size() < 4096 ? 120 : 80);
-                if (!ub.empty() && cost(ub) * 100 < cost(c.bundles) * gain) { c.bundles.swap(ub); c.ketlist.swap(uk); }
+                const bool allowed = !high_bra || c.bundles.size() < 512;
+                if (!ub.empty() && allowed && cost(ub) * 100 < cost(c.bundles) * gain) { c.bundles.swap(ub); c.ketlist.swap(uk); }
             }
         }
         else {
