@@ -27,6 +27,11 @@ typedef __attribute__((address_space(3))) double qc_lds_double;
 // (the row buffer belongs to one wave and every add to it is an instruction of that wave: the DS unit serves the lanes of an
 // instruction in a fixed order, so these sums do not depend on timing - f64 is fine here in the fixed-point mode too)
 __device__ __forceinline__ void qc_lds_add(double *p, double v) { (void)__builtin_amdgcn_ds_atomic_fadd_f64((qc_lds_double *)p, v); }
+// Wave-uniform reads of the bra's pair data go through the scalar unit: a pointer taken from the kernel's argument struct carries no
+// no-alias information, so the compiler reads `pd[uniform]` with a 64-lane vector load per two values (10 loads and a full memory
+// latency per row of step 3); the same address in the constant address space is an s_load.  (The pair data are written by the host
+// before any launch.)
+typedef const __attribute__((address_space(4))) double qc_cdouble;
 
 constexpr int QC_BM_TROW = 9;
 constexpr int QC_BM_TWORDS = QC_BOYS_NGRID * QC_BM_TROW;
@@ -90,18 +95,28 @@ __device__ __forceinline__ void qc_step2_ps(double (&W)[3][qc_nherm(LAB)], const
 
 // One pass over the ket primitives for NIJ consecutive bra primitive pairs (NIJ = 2 shares every ket load between two
 // primitive quartets), followed by step 3 with the wave-uniform bra blocks.
+// Latencies a pass used to expose, and what hides them now (round 3; with ket chunks of <= 8 primitives a pass is only ~16 primitive
+// quartets long, so they were a third to a half of a wave's life): the bra headers of the NEXT pass are requested before the
+// primitive loop (`hd` carries them from pass to pass); the first ket record is loaded once per bundle (`hk0`, `ek0`); the rows of
+// step 3 come in pieces of QC_BM_PIECE scalars, each requested while the previous one is being used.
+constexpr int QC_BM_PIECE = 10;
 template <int LAB, int LCD, int NIJ>
 __device__ __forceinline__ void qc_bm_pass(const double *__restrict__ pd, const double *__restrict__ pdT, const double *__restrict__ Tb,
-                                           const int bdoff, const int strideB, const int ij, const int nab, const double *__restrict__ ketBase,
-                                           const int K_cd, const int Kc1, const int maxK, double *const I) {
+                                           const int bdoff, const int strideB, const int ij, const int ij_last, const int nab,
+                                           const double *__restrict__ ketBase, const double4 hk0, const double4 ek0,
+                                           const int K_cd, const int Kc1, const int maxK, double *const I, double (&hd)[2][4]) {
     constexpr int L = LAB + LCD, HAB = qc_nherm(LAB), NC = (LCD == 0) ? 1 : 3;
     constexpr int strideK = (LCD == 0) ? qc_pair_stride(0, 1) : 8;
     constexpr int LS = 65;
     double p[NIJ], Px[NIJ], Py[NIJ], Pz[NIJ];
 #pragma unroll
-    for (int u = 0; u < NIJ; ++u) {
-        const double *__restrict__ bh = pd + bdoff + (size_t)(ij + u) * strideB;
-        p[u] = bh[0]; Px[u] = bh[1]; Py[u] = bh[2]; Pz[u] = bh[3];
+    for (int u = 0; u < NIJ; ++u) { p[u] = hd[u][0]; Px[u] = hd[u][1]; Py[u] = hd[u][2]; Pz[u] = hd[u][3]; }
+    // headers of the bra primitive pairs after this pass (clamped: the last pass re-reads its own)
+    double hn[2][4];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        qc_cdouble *bh = (qc_cdouble *)(pd + bdoff + (size_t)min(ij + NIJ + u, ij_last) * strideB);
+        hn[u][0] = bh[0]; hn[u][1] = bh[1]; hn[u][2] = bh[2]; hn[u][3] = bh[3];
     }
     double W[NIJ][NC][HAB];
 #pragma unroll
@@ -112,9 +127,9 @@ __device__ __forceinline__ void qc_bm_pass(const double *__restrict__ pd, const 
             for (int h = 0; h < HAB; ++h) W[u][c][h] = 0.0;
     // the next ket primitive's record is requested one iteration ahead.  ss kets: pair-data block [q, Q | E]; ps kets:
     // packed record [q, Q | e0x, e0y, e0z, e1] (ketBase points into pspack, stride 8)
-    double4 hk = *reinterpret_cast<const double4 *>(ketBase);
-    double4 ekn4 = (LCD == 1) ? *reinterpret_cast<const double4 *>(ketBase + 4) : double4{0.0, 0.0, 0.0, 0.0};
-    double ekn = (LCD == 0) ? ketBase[4] : 0.0;
+    double4 hk = hk0;
+    double4 ekn4 = ek0;
+    double ekn = ek0.x;
     for (int kl = 0; kl < maxK; ++kl) {
         const bool valid = kl < K_cd;
         const double4 ck = hk;
@@ -147,24 +162,44 @@ __device__ __forceinline__ void qc_bm_pass(const double *__restrict__ pd, const 
         }
     }
     // step 3 with the wave-uniform bra blocks: I[ab][c] += sum_u sum_h E_ab,ij+u[ab][h] W[u][c][h]
-    const double *__restrict__ ET = pdT + bdoff + (size_t)ij * strideB + 4;
+    constexpr int PL = QC_BM_PIECE, NPC = (HAB + PL - 1) / PL, NP = NIJ * NPC;
+    qc_cdouble *ET = (qc_cdouble *)(pdT + bdoff + (size_t)ij * strideB + 4);
+    auto load_piece = [&](double (&e)[PL], const int ab, const int u, const int pc) {
+        qc_cdouble *row = ET + (size_t)u * strideB + ab * HAB + pc * PL;
+#pragma unroll
+        for (int k = 0; k < PL; ++k)
+            if (pc * PL + k < HAB) e[k] = row[k];
+    };
+    double cur[PL], nxt[PL];
+#pragma unroll
+    for (int k = 0; k < PL; ++k) cur[k] = nxt[k] = 0.0;
+    load_piece(cur, 0, 0, 0);
     for (int ab = 0; ab < nab; ++ab) {
         double acc[NC];
 #pragma unroll
         for (int c = 0; c < NC; ++c) acc[c] = 0.0;
+        const int abn = min(ab + 1, nab - 1);
 #pragma unroll
-        for (int u = 0; u < NIJ; ++u) {
-            const double *__restrict__ row = ET + (size_t)u * strideB + ab * HAB;
+        for (int j = 0; j < NP; ++j) {
+            const int u = j / NPC, pc = j % NPC;
+            if (j + 1 < NP) load_piece(nxt, ab, (j + 1) / NPC, (j + 1) % NPC);
+            else load_piece(nxt, abn, 0, 0);
 #pragma unroll
-            for (int h = 0; h < HAB; ++h) {
-                const double e = row[h];
+            for (int k = 0; k < PL; ++k)
+                if (pc * PL + k < HAB) {
 #pragma unroll
-                for (int c = 0; c < NC; ++c) acc[c] = fma(e, W[u][c][h], acc[c]);
-            }
+                    for (int c = 0; c < NC; ++c) acc[c] = fma(cur[k], W[u][c][pc * PL + k], acc[c]);
+                }
+#pragma unroll
+            for (int k = 0; k < PL; ++k) cur[k] = nxt[k];
         }
 #pragma unroll
-        for (int c = 0; c < NC; ++c) I[(ab * NC + c) * LS] += acc[c];
+        for (int c = 0; c < NC; ++c) qc_lds_add(&I[(ab * NC + c) * LS], acc[c]);
     }
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) hd[u][k] = hn[u][k];
 }
 
 template <int LAB, int LCD>
@@ -204,10 +239,19 @@ __device__ __forceinline__ void qc_bm_body(const QcKernelArgs &a, const double *
 
     for (int x = 0; x < nab * NC; ++x) I[x * LS] = 0.0;
 
+    // first ket record of the lane's chunk (the same for every pass) and the headers of the first two bra primitive pairs
+    const double4 hk0 = *reinterpret_cast<const double4 *>(ketBase);
+    const double4 ek0 = (LCD == 1) ? *reinterpret_cast<const double4 *>(ketBase + 4) : double4{ketBase[4], 0.0, 0.0, 0.0};
+    double hd[2][4];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        qc_cdouble *bh = (qc_cdouble *)(pd + bdoff + (size_t)min(ij_lo + u, ij_hi - 1) * strideB);
+        hd[u][0] = bh[0]; hd[u][1] = bh[1]; hd[u][2] = bh[2]; hd[u][3] = bh[3];
+    }
     int ij = ij_lo;
     if constexpr (PAIRED)
-        for (; ij + 1 < ij_hi; ij += 2) qc_bm_pass<LAB, LCD, 2>(pd, pdT, Tb, bdoff, strideB, ij, nab, ketBase, K_cd, Kc1, maxK, I);
-    for (; ij < ij_hi; ++ij) qc_bm_pass<LAB, LCD, 1>(pd, pdT, Tb, bdoff, strideB, ij, nab, ketBase, K_cd, Kc1, maxK, I);
+        for (; ij + 1 < ij_hi; ij += 2) qc_bm_pass<LAB, LCD, 2>(pd, pdT, Tb, bdoff, strideB, ij, ij_hi - 1, nab, ketBase, hk0, ek0, K_cd, Kc1, maxK, I, hd);
+    for (; ij < ij_hi; ++ij) qc_bm_pass<LAB, LCD, 1>(pd, pdT, Tb, bdoff, strideB, ij, ij_hi - 1, nab, ketBase, hk0, ek0, K_cd, Kc1, maxK, I, hd);
 
     const int nd = pk.nb;                                     // (nc, nd) = (1,1), (3,1) or (1,3)
     const int c0 = pk.offa, d0 = pk.offb;
