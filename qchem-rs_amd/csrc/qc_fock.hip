@@ -45,6 +45,26 @@ int qc_device_ready(void) {
     return QC_OK;
 }
 
+// Device records of a bra-major work list (QcBundleDev / QcKetUnit, qc_internal.h) from the host lists of qc_make_bundles
+static void qc_bm_device_lists(const qc_system *S, int lcd, const std::vector<QcBundle> &bundles, const std::vector<int> &ketlist,
+                               std::vector<QcBundleDev> &db, std::vector<QcKetUnit> &du) {
+    db.resize(bundles.size()); du.resize(ketlist.size());
+    for (size_t i = 0; i < bundles.size(); ++i) {
+        const QcBundle &b = bundles[i];
+        const QcPairDesc &p = S->pairs[b.bra];
+        db[i] = QcBundleDev{b.bra, b.ij_lo, b.ij_hi, b.first, b.nket, b.maxK, p.doff, p.offa, p.offb, p.na | (p.nb << 8) | ((p.shA_eq_shB ? 1 : 0) << 16), 0, 0};
+    }
+    for (size_t i = 0; i < ketlist.size(); ++i) {
+        const unsigned e = (unsigned)ketlist[i];
+        const int ket = (int)(e & 0x3ffffu), kl0 = (int)((e >> 18) & 0x7fu), klen = (int)(e >> 25);
+        const QcPairDesc &p = S->pairs[ket];
+        const int stride = lcd == 0 ? qc_pair_stride(0, 1) : 8;
+        const int K = klen ? klen : p.K;
+        du[i] = QcKetUnit{ket, (lcd == 0 ? p.doff : p.psoff) + kl0 * stride, p.offa | (p.offb << 16),
+                          (K & 0xffff) | ((p.nb == 1 ? 1 : 0) << 16) | ((p.shA_eq_shB ? 1 : 0) << 17) | ((p.psperm & 63) << 18)};
+    }
+}
+
 static int upload_slots(qc_system *S) {
     for (auto &c : S->classes) {
         if (c.d_slots) { (void)hipFree(c.d_slots); c.d_slots = nullptr; }
@@ -55,10 +75,12 @@ static int upload_slots(qc_system *S) {
             QC_HIP_CHECK(hipMemcpy(c.d_slots, c.slots.data(), c.slots.size() * sizeof(QcSlot), hipMemcpyHostToDevice));
         }
         if (!c.bundles.empty()) {
-            QC_HIP_CHECK(hipMalloc(&c.d_bundles, c.bundles.size() * sizeof(QcBundle)));
-            QC_HIP_CHECK(hipMemcpy(c.d_bundles, c.bundles.data(), c.bundles.size() * sizeof(QcBundle), hipMemcpyHostToDevice));
-            QC_HIP_CHECK(hipMalloc(&c.d_ketlist, c.ketlist.size() * sizeof(int)));
-            QC_HIP_CHECK(hipMemcpy(c.d_ketlist, c.ketlist.data(), c.ketlist.size() * sizeof(int), hipMemcpyHostToDevice));
+            std::vector<QcBundleDev> db; std::vector<QcKetUnit> du;
+            qc_bm_device_lists(S, c.LCD, c.bundles, c.ketlist, db, du);
+            QC_HIP_CHECK(hipMalloc(&c.d_bundles, db.size() * sizeof(QcBundleDev)));
+            QC_HIP_CHECK(hipMemcpy(c.d_bundles, db.data(), db.size() * sizeof(QcBundleDev), hipMemcpyHostToDevice));
+            QC_HIP_CHECK(hipMalloc(&c.d_ketlist, du.size() * sizeof(QcKetUnit)));
+            QC_HIP_CHECK(hipMemcpy(c.d_ketlist, du.data(), du.size() * sizeof(QcKetUnit), hipMemcpyHostToDevice));
         }
     }
     return QC_OK;
@@ -228,7 +250,7 @@ static QcKernelArgs base_args(qc_system *S, const QcFockArgs &fa) {
 }
 
 // segment of one launch: a class bucket with its slots (column kernels) or bundles (bra-major kernels)
-struct Seg { const QcClass *c; const QcSlot *d_slots; int nslots; const QcBundle *d_bundles = nullptr; const int *d_ketlist = nullptr; int lds = 0;
+struct Seg { const QcClass *c; const QcSlot *d_slots; int nslots; const QcBundleDev *d_bundles = nullptr; const QcKetUnit *d_ketlist = nullptr; int lds = 0;
              int run = 0, rb_rows = 0; };     // (bra-run mode of the class's own slot list; the set-up passes bring independent slots)
 
 static Seg seg_of(const QcClass &c) {
@@ -641,11 +663,13 @@ int qc_schwarz_device(qc_system *S) {
         if (diag.empty()) continue;
         if (c.bm) {
             qc_make_bundles(S, diag, 0, bundles, ketlist);
-            QcTmpDev<QcBundle> db; QcTmpDev<int> dk;
-            QC_HIP_CHECK(db.alloc(bundles.size()));
-            QC_HIP_CHECK(dk.alloc(ketlist.size()));
-            QC_HIP_CHECK(hipMemcpyAsync(db.p, bundles.data(), bundles.size() * sizeof(QcBundle), hipMemcpyHostToDevice, S->stream));
-            QC_HIP_CHECK(hipMemcpyAsync(dk.p, ketlist.data(), ketlist.size() * sizeof(int), hipMemcpyHostToDevice, S->stream));
+            QcTmpDev<QcBundleDev> db; QcTmpDev<QcKetUnit> dk;
+            std::vector<QcBundleDev> hb; std::vector<QcKetUnit> hu;
+            qc_bm_device_lists(S, c.LCD, bundles, ketlist, hb, hu);
+            QC_HIP_CHECK(db.alloc(hb.size()));
+            QC_HIP_CHECK(dk.alloc(hu.size()));
+            QC_HIP_CHECK(hipMemcpyAsync(db.p, hb.data(), hb.size() * sizeof(QcBundleDev), hipMemcpyHostToDevice, S->stream));
+            QC_HIP_CHECK(hipMemcpyAsync(dk.p, hu.data(), hu.size() * sizeof(QcKetUnit), hipMemcpyHostToDevice, S->stream));
             int mx = 0;
             for (const auto &t : diag) mx = std::max(mx, S->pairs[t.bra].na * S->pairs[t.bra].nb * S->pairs[t.ket].na * S->pairs[t.ket].nb);
             int rc = launch_segments(S, qc_unit_of(c.LAB, c.LCD, true), {Seg{&c, nullptr, (int)bundles.size(), db.p, dk.p, mx * 65 * 8}}, S->stream, a);
@@ -679,11 +703,13 @@ int qc_launch_eri_full(qc_system *S, double *d_out) {
         if (c.bm) {
             qc_make_bundles(S, c.tasks, 0, bundles, ketlist);
             if (bundles.empty()) continue;
-            QcTmpDev<QcBundle> db; QcTmpDev<int> dk;
-            QC_HIP_CHECK(db.alloc(bundles.size()));
-            QC_HIP_CHECK(dk.alloc(ketlist.size()));
-            QC_HIP_CHECK(hipMemcpyAsync(db.p, bundles.data(), bundles.size() * sizeof(QcBundle), hipMemcpyHostToDevice, S->stream));
-            QC_HIP_CHECK(hipMemcpyAsync(dk.p, ketlist.data(), ketlist.size() * sizeof(int), hipMemcpyHostToDevice, S->stream));
+            QcTmpDev<QcBundleDev> db; QcTmpDev<QcKetUnit> dk;
+            std::vector<QcBundleDev> hb; std::vector<QcKetUnit> hu;
+            qc_bm_device_lists(S, c.LCD, bundles, ketlist, hb, hu);
+            QC_HIP_CHECK(db.alloc(hb.size()));
+            QC_HIP_CHECK(dk.alloc(hu.size()));
+            QC_HIP_CHECK(hipMemcpyAsync(db.p, hb.data(), hb.size() * sizeof(QcBundleDev), hipMemcpyHostToDevice, S->stream));
+            QC_HIP_CHECK(hipMemcpyAsync(dk.p, hu.data(), hu.size() * sizeof(QcKetUnit), hipMemcpyHostToDevice, S->stream));
             int mx = 0;
             for (const auto &t : c.tasks) mx = std::max(mx, S->pairs[t.bra].na * S->pairs[t.bra].nb * S->pairs[t.ket].na * S->pairs[t.ket].nb);
             int rc = launch_segments(S, qc_unit_of(c.LAB, c.LCD, true), {Seg{&c, nullptr, (int)bundles.size(), db.p, dk.p, mx * 65 * 8}}, S->stream, a);

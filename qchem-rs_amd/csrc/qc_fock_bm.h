@@ -19,8 +19,8 @@ struct QcBmArgs {
     int seg_iwords[QC_MAXSEG];         // doubles of one wave's I block (nab * ncd * 65)
     int seg_rows[QC_MAXSEG];           // most bra functions (na + nb) of the segment's bundles: rows of a wave's exchange buffer (0: none)
     int use_rowbuf;                    // exchange rows accumulate in LDS (n small enough), else global atomics per bundle
-    const QcBundle *seg_bundles[QC_MAXSEG];
-    const int *seg_ketlist[QC_MAXSEG];
+    const QcBundleDev *seg_bundles[QC_MAXSEG];
+    const QcKetUnit *seg_ketlist[QC_MAXSEG];
 };
 
 int qc_launch_bm(int lcd, int hi, int grid, int nwaves /* <= qc_bm_waves(lcd, hi) */, size_t lds, hipStream_t st, const QcBmArgs &a);

@@ -33,6 +33,16 @@ __device__ __forceinline__ void qc_lds_add(double *p, double v) { (void)__builti
 // before any launch.)
 typedef const __attribute__((address_space(4))) double qc_cdouble;
 
+// -DQC_BM_TIMING (tools/build_phase_lib.sh): wave 0 of the first workgroups of a segment prints where its time went (10 ns units)
+#ifdef QC_BM_TIMING
+#define QC_BT(i) do { const long long t_ = wall_clock64(); tph[i] += t_ - tlast; tlast = t_; } while (0)
+#define QC_BT_ARGS , long long *tph, long long &tlast
+#define QC_BT_PASS , tph, tlast
+#else
+#define QC_BT(i) do {} while (0)
+#define QC_BT_ARGS
+#define QC_BT_PASS
+#endif
 constexpr int QC_BM_TROW = 9;
 constexpr int QC_BM_TWORDS = QC_BOYS_NGRID * QC_BM_TROW;
 
@@ -104,7 +114,7 @@ template <int LAB, int LCD, int NIJ>
 __device__ __forceinline__ void qc_bm_pass(const double *__restrict__ pd, const double *__restrict__ pdT, const double *__restrict__ Tb,
                                            const int bdoff, const int strideB, const int ij, const int ij_last, const int nab,
                                            const double *__restrict__ ketBase, const double4 hk0, const double4 ek0,
-                                           const int K_cd, const int Kc1, const int maxK, double *const I, double (&hd)[2][4]) {
+                                           const int K_cd, const int Kc1, const int maxK, double *const I, double (&hd)[2][4] QC_BT_ARGS) {
     constexpr int L = LAB + LCD, HAB = qc_nherm(LAB), NC = (LCD == 0) ? 1 : 3;
     constexpr int strideK = (LCD == 0) ? qc_pair_stride(0, 1) : 8;
     constexpr int LS = 65;
@@ -161,6 +171,7 @@ __device__ __forceinline__ void qc_bm_pass(const double *__restrict__ pd, const 
             }
         }
     }
+    QC_BT(1);
     // step 3 with the wave-uniform bra blocks: I[ab][c] += sum_u sum_h E_ab,ij+u[ab][h] W[u][c][h]
     constexpr int PL = QC_BM_PIECE, NPC = (HAB + PL - 1) / PL, NP = NIJ * NPC;
     qc_cdouble *ET = (qc_cdouble *)(pdT + bdoff + (size_t)ij * strideB + 4);
@@ -200,12 +211,26 @@ __device__ __forceinline__ void qc_bm_pass(const double *__restrict__ pd, const 
     for (int u = 0; u < 2; ++u)
 #pragma unroll
         for (int k = 0; k < 4; ++k) hd[u][k] = hn[u][k];
+    QC_BT(2);
+}
+
+// Device records of the work lists (built by qc_bm_device_lists, qc_fock.hip): the bundle carries what the kernel needs of its bra pair,
+// the unit what it needs of the lane's ket pair - a wave used to start with three dependent trips to memory (bundle -> pair descriptors
+// -> first ket record); now the bundle comes through the scalar unit and both records of the NEXT bundle are requested while the current
+// one is being digested (qc_bm_segment).
+typedef int qc_v4i __attribute__((ext_vector_type(4)));
+typedef const __attribute__((address_space(4))) qc_v4i qc_cv4i;
+struct QcBmBundleRegs { int bra, ij_lo, ij_hi, first, nket, maxK, bdoff, offa, offb, na, nb, eq; };   // wave-uniform
+__device__ __forceinline__ QcBmBundleRegs qc_bm_load_bundle(const QcBundleDev *bundles, const int b) {
+    const qc_cv4i *bp = (const qc_cv4i *)(bundles + b);
+    const qc_v4i x = bp[0], y = bp[1], z = bp[2];
+    return QcBmBundleRegs{x.x, x.y, x.z, x.w, y.x, y.y, y.z, y.w, z.x, z.y & 0xff, (z.y >> 8) & 0xff, (z.y >> 16) & 1};
 }
 
 template <int LAB, int LCD>
-__device__ __forceinline__ void qc_bm_body(const QcKernelArgs &a, const double *__restrict__ pdT, const QcBundle *__restrict__ bundles,
-                                           const int *__restrict__ ketlist, const int blk, const double *__restrict__ Tb, double *const Iw,
-                                           const double *__restrict__ pspack, double *const rowbuf, const int rowcap) {
+__device__ __forceinline__ void qc_bm_body(const QcKernelArgs &a, const double *__restrict__ pdT, const QcBmBundleRegs &bd, const QcKetUnit ue,
+                                           const int blk, const double *__restrict__ Tb, double *const Iw,
+                                           const double *__restrict__ pspack, double *const rowbuf, const int rowcap QC_BT_ARGS) {
     constexpr int HAB = qc_nherm(LAB), NC = (LCD == 0) ? 1 : 3;
     constexpr int LS = 65;                                    // LDS row stride (doubles)
     constexpr bool PAIRED = 2 * NC * HAB <= 24;               // two bra primitive pairs per pass when W[2][NC][HAB] fits
@@ -215,26 +240,20 @@ __device__ __forceinline__ void qc_bm_body(const QcKernelArgs &a, const double *
     const bool uhf = a.Dk1 != nullptr;
     const double fxscale = a.fxs ? a.fxs[0] : 0.0;           // 0: f64 atomics
 
-    const QcBundle bd = bundles[blk];
-    const int bra = __builtin_amdgcn_readfirstlane(bd.bra);
-    const int ij_lo = __builtin_amdgcn_readfirstlane(bd.ij_lo), ij_hi = __builtin_amdgcn_readfirstlane(bd.ij_hi);
-    const int first = __builtin_amdgcn_readfirstlane(bd.first), nket = __builtin_amdgcn_readfirstlane(bd.nket);
-    const int maxK = __builtin_amdgcn_readfirstlane(bd.maxK);
-    const QcPairDesc pb = a.pairs[bra];
-    const int na = __builtin_amdgcn_readfirstlane(pb.na), nb = __builtin_amdgcn_readfirstlane(pb.nb);
-    const int offa = __builtin_amdgcn_readfirstlane(pb.offa), offb = __builtin_amdgcn_readfirstlane(pb.offb);
-    const int bdoff = __builtin_amdgcn_readfirstlane(pb.doff);
+    const int bra = bd.bra, ij_lo = bd.ij_lo, ij_hi = bd.ij_hi, nket = bd.nket, maxK = bd.maxK;
+    const int na = bd.na, nb = bd.nb, offa = bd.offa, offb = bd.offb, bdoff = bd.bdoff;
     const int nab = na * nb;
     const int strideB = qc_pair_stride(LAB, nab);
 
     const bool active = lane < nket;
-    // entry: ket pair | first primitive << 18 | primitives << 25 (0: the whole pair) - qc_make_bundles
-    const unsigned kent = (unsigned)ketlist[first + (active ? lane : 0)];
-    const int ket = (int)(kent & 0x3ffffu), kl0 = (int)((kent >> 18) & 0x7fu), klen = (int)(kent >> 25);
-    const QcPairDesc pk = a.pairs[ket];
-    const int K_cd = active ? (klen ? klen : pk.K) : 0, Kc1 = max(K_cd - 1, 0);
-    constexpr int strideK0 = (LCD == 0) ? qc_pair_stride(0, 1) : 8;
-    const double *__restrict__ ketBase = ((LCD == 0) ? pd + pk.doff : pspack + pk.psoff) + (size_t)kl0 * strideK0;
+    // unit: ket pair | offset of its (chunk of) primitive records | c0, d0 | primitives, shape - QcKetUnit
+    const int ket = ue.ket;
+    const int K_cd = active ? (ue.info & 0xffff) : 0, Kc1 = max(K_cd - 1, 0);
+    const bool nd1 = (ue.info >> 16) & 1;                      // (nc, nd) = (1,1), (3,1) [nd1] or (1,3)
+    const bool keq = (ue.info >> 17) & 1;
+    const int psperm = (ue.info >> 18) & 63;
+    const int c0 = ue.cd & 0xffff, d0 = (int)((unsigned)ue.cd >> 16);
+    const double *__restrict__ ketBase = ((LCD == 0) ? pd : pspack) + ue.koff;
     double *const I = Iw + lane;                              // I[x * LS], x = ab * NC + col
 
     for (int x = 0; x < nab * NC; ++x) I[x * LS] = 0.0;
@@ -248,13 +267,12 @@ __device__ __forceinline__ void qc_bm_body(const QcKernelArgs &a, const double *
         qc_cdouble *bh = (qc_cdouble *)(pd + bdoff + (size_t)min(ij_lo + u, ij_hi - 1) * strideB);
         hd[u][0] = bh[0]; hd[u][1] = bh[1]; hd[u][2] = bh[2]; hd[u][3] = bh[3];
     }
+    QC_BT(0);
     int ij = ij_lo;
     if constexpr (PAIRED)
-        for (; ij + 1 < ij_hi; ij += 2) qc_bm_pass<LAB, LCD, 2>(pd, pdT, Tb, bdoff, strideB, ij, ij_hi - 1, nab, ketBase, hk0, ek0, K_cd, Kc1, maxK, I, hd);
-    for (; ij < ij_hi; ++ij) qc_bm_pass<LAB, LCD, 1>(pd, pdT, Tb, bdoff, strideB, ij, ij_hi - 1, nab, ketBase, hk0, ek0, K_cd, Kc1, maxK, I, hd);
+        for (; ij + 1 < ij_hi; ij += 2) qc_bm_pass<LAB, LCD, 2>(pd, pdT, Tb, bdoff, strideB, ij, ij_hi - 1, nab, ketBase, hk0, ek0, K_cd, Kc1, maxK, I, hd QC_BT_PASS);
+    for (; ij < ij_hi; ++ij) qc_bm_pass<LAB, LCD, 1>(pd, pdT, Tb, bdoff, strideB, ij, ij_hi - 1, nab, ketBase, hk0, ek0, K_cd, Kc1, maxK, I, hd QC_BT_PASS);
 
-    const int nd = pk.nb;                                     // (nc, nd) = (1,1), (3,1) or (1,3)
-    const int c0 = pk.offa, d0 = pk.offb;
     if (a.schwarz_out != nullptr) {
         // Schwarz factors: the bundles are (P|P) quartets, one ket per bundle; the largest element of the block is on its diagonal
         if (active) {
@@ -272,8 +290,8 @@ __device__ __forceinline__ void qc_bm_body(const QcKernelArgs &a, const double *
             for (int ab = 0; ab < nab; ++ab) {
                 const size_t i = offa + ab / nb, j = offb + ab % nb;
                 for (int c = 0; c < NC; ++c) {
-                    const int fc = (LCD == 0) ? 0 : (pk.psperm >> (2 * c)) & 3;    // ps kets: column c = axis c = p function fc
-                    const size_t k = c0 + (nd == 1 ? fc : 0), l = d0 + (nd == 1 ? 0 : fc);
+                    const int fc = (LCD == 0) ? 0 : (psperm >> (2 * c)) & 3;    // ps kets: column c = axis c = p function fc
+                    const size_t k = c0 + (nd1 ? fc : 0), l = d0 + (nd1 ? 0 : fc);
                     const double v = I[(ab * NC + c) * LS];
                     o[i * n3 + j * n2 + k * n1 + l] = v; o[j * n3 + i * n2 + k * n1 + l] = v;
                     o[i * n3 + j * n2 + l * n1 + k] = v; o[j * n3 + i * n2 + l * n1 + k] = v;
@@ -287,14 +305,18 @@ __device__ __forceinline__ void qc_bm_body(const QcKernelArgs &a, const double *
 
     const size_t rep = (size_t)(blk % a.nrep) * a.rep_stride;
     double *G0 = a.G0 + rep, *G1 = a.G1 + rep;
-    const double f = active ? (pb.shA_eq_shB ? 0.5 : 1.0) * (pk.shA_eq_shB ? 0.5 : 1.0) * (bra == ket ? 0.5 : 1.0) : 0.0;
+    const double f = active ? (bd.eq ? 0.5 : 1.0) * (keq ? 0.5 : 1.0) * (bra == ket ? 0.5 : 1.0) : 0.0;
     // column c of this lane's ket is the function pair (c0 + kc[c], d0 + lc[c])
     int kc[NC], lc[NC];
 #pragma unroll
     for (int c = 0; c < NC; ++c) {
-        const int fc = (LCD == 0) ? 0 : (pk.psperm >> (2 * c)) & 3;     // ps kets: column c = axis c = p function fc
-        kc[c] = (nd == 1) ? fc : 0; lc[c] = (nd == 1) ? 0 : fc;
+        const int fc = (LCD == 0) ? 0 : (psperm >> (2 * c)) & 3;     // ps kets: column c = axis c = p function fc
+        kc[c] = nd1 ? fc : 0; lc[c] = nd1 ? 0 : fc;
     }
+    // this lane's ket-side density elements (Coulomb part below): requested here, used after the exchange blocks
+    double dcd[NC];
+#pragma unroll
+    for (int c = 0; c < NC; ++c) dcd[c] = active ? a.Dj[(size_t)(c0 + kc[c]) * n + d0 + lc[c]] : 0.0;
 
     const double fk = -a.cK * f;
     // Exchange contributions land in the rows of the bra's functions (r = i, or na + j) at the columns of this lane's ket
@@ -308,7 +330,7 @@ __device__ __forceinline__ void qc_bm_body(const QcKernelArgs &a, const double *
         if constexpr (NC == 1) {
             kadd(sp, r, grow, c0, fk * accK[0]);
             kadd(sp, r, grow, d0, fk * accL[0]);
-        } else if (nd == 1) {                                 // columns differ in k, share l
+        } else if (nd1) {                                     // columns differ in k, share l
             kadd(sp, r, grow, c0 + kc[0], fk * accK[0]); kadd(sp, r, grow, c0 + kc[1], fk * accK[1]); kadd(sp, r, grow, c0 + kc[2], fk * accK[2]);
             kadd(sp, r, grow, d0, fk * (accL[0] + accL[1] + accL[2]));
         } else {                                              // columns differ in l, share k
@@ -316,62 +338,82 @@ __device__ __forceinline__ void qc_bm_body(const QcKernelArgs &a, const double *
             kadd(sp, r, grow, d0 + lc[0], fk * accL[0]); kadd(sp, r, grow, d0 + lc[1], fk * accL[1]); kadd(sp, r, grow, d0 + lc[2], fk * accL[2]);
         }
     };
-    // ---- exchange blocks first (they read I), per spin: Gt_ik -= cK f sum_jl I D_jl and the il / jk / jl images
+    // ---- exchange blocks first (they read I), per spin: Gt_ik -= cK f sum_jl I D_jl and the il / jk / jl images.
+    // The density rows of the functions of the OTHER bra shell are gathered first (one memory latency per half instead of one per
+    // target row: the elements do not depend on the target), then every target row is a loop over LDS reads.  RB covers a whole
+    // shell, so a target element is ONE sum over the other shell's functions in ascending order, as before (the O2 triplet run of
+    // the tests sits on a saddle and follows these roundings).
+    constexpr int RB = (LAB <= 2) ? 6 : 10;
+    auto exchange_half = [&](const double *__restrict__ Dk, const int s, const bool on_a) {
+        const int nt = on_a ? na : nb, no = on_a ? nb : na;              // target shell / other shell (wave-uniform)
+        const int offo = on_a ? offb : offa;
+        for (int o0 = 0; o0 < no; o0 += RB) {
+            double dK[RB][NC], dL[RB][NC];
+#pragma unroll
+            for (int r = 0; r < RB; ++r) {
+#pragma unroll
+                for (int c = 0; c < NC; ++c) dK[r][c] = dL[r][c] = 0.0;
+                if (o0 + r < no) {
+                    const double *__restrict__ Drow = Dk + (size_t)(offo + o0 + r) * n;
+#pragma unroll
+                    for (int c = 0; c < NC; ++c) { dK[r][c] = Drow[d0 + lc[c]]; dL[r][c] = Drow[c0 + kc[c]]; }
+                }
+            }
+            for (int t = 0; t < nt; ++t) {
+                double accK[NC], accL[NC];                   // G[target, c_k] and G[target, d_l] partial sums
+#pragma unroll
+                for (int c = 0; c < NC; ++c) accK[c] = accL[c] = 0.0;
+#pragma unroll
+                for (int r = 0; r < RB; ++r) {
+                    if (o0 + r < no) {
+                        const int o = o0 + r;
+                        const int ab = on_a ? t * nb + o : o * nb + t;
+#pragma unroll
+                        for (int c = 0; c < NC; ++c) {
+                            const double v = I[(ab * NC + c) * LS];
+                            accK[c] = fma(v, dK[r][c], accK[c]);
+                            accL[c] = fma(v, dL[r][c], accL[c]);
+                        }
+                    }
+                }
+                kadd3(s, on_a ? t : na + t, (on_a ? offa : offb) + t, accK, accL);
+            }
+        }
+    };
     if (active) {
         for (int s = 0; s < (uhf ? 2 : 1); ++s) {
             const double *__restrict__ Dk = s ? a.Dk1 : a.Dk0;
-            // targets on the bra function a_i: needs D[b_j, d_l] and D[b_j, c_k]
-            for (int i = 0; i < na; ++i) {
-                double accK[NC], accL[NC];                   // G[a_i, c_k] and G[a_i, d_l] partial sums
-#pragma unroll
-                for (int c = 0; c < NC; ++c) accK[c] = accL[c] = 0.0;
-#pragma unroll 3
-                for (int j = 0; j < nb; ++j) {
-                    const double *__restrict__ Drow = Dk + (size_t)(offb + j) * n;
-#pragma unroll
-                    for (int c = 0; c < NC; ++c) {
-                        const double v = I[((i * nb + j) * NC + c) * LS];
-                        accK[c] = fma(v, Drow[d0 + lc[c]], accK[c]);
-                        accL[c] = fma(v, Drow[c0 + kc[c]], accL[c]);
-                    }
-                }
-                kadd3(s, i, offa + i, accK, accL);
-            }
-            // targets on the bra function b_j: needs D[a_i, d_l] and D[a_i, c_k]
-            for (int j = 0; j < nb; ++j) {
-                double accK[NC], accL[NC];
-#pragma unroll
-                for (int c = 0; c < NC; ++c) accK[c] = accL[c] = 0.0;
-#pragma unroll 3
-                for (int i = 0; i < na; ++i) {
-                    const double *__restrict__ Drow = Dk + (size_t)(offa + i) * n;
-#pragma unroll
-                    for (int c = 0; c < NC; ++c) {
-                        const double v = I[((i * nb + j) * NC + c) * LS];
-                        accK[c] = fma(v, Drow[d0 + lc[c]], accK[c]);
-                        accL[c] = fma(v, Drow[c0 + kc[c]], accL[c]);
-                    }
-                }
-                kadd3(s, na + j, offb + j, accK, accL);
-            }
+            exchange_half(Dk, s, true);                       // targets on the bra functions a_i: D[b_j, d_l] and D[b_j, c_k]
+            exchange_half(Dk, s, false);                      // targets on the bra functions b_j: D[a_i, d_l] and D[a_i, c_k]
         }
     }
 
+    QC_BT(3);
     // ---- Coulomb blocks: Gt_cd += 2f sum_ab I D_ab (per lane);  Gt_ab += 2f sum_cd I D_cd (reduced over the wave)
     const double fj = 2.0 * f;
-    double dcd[NC], jcd[NC];
+    double jcd[NC];
 #pragma unroll
-    for (int c = 0; c < NC; ++c) { dcd[c] = active ? a.Dj[(size_t)(c0 + kc[c]) * n + d0 + lc[c]] : 0.0; jcd[c] = 0.0; }
-    for (int ab = 0; ab < nab; ++ab) {
-        const double dab = a.Dj[(size_t)(offa + ab / nb) * n + offb + ab % nb];      // wave-uniform
-        double t = 0.0;
+    for (int c = 0; c < NC; ++c) jcd[c] = 0.0;
+    {
+        // D_ab is wave-uniform: scalar loads, one element ahead (the density is written by earlier launches only)
+        qc_cdouble *Dj = (qc_cdouble *)a.Dj;
+        int bi = 0, bj = 0;
+        double dab = Dj[(size_t)offa * n + offb];
+        for (int ab = 0; ab < nab; ++ab) {
+            int bjn = bj + 1, bin = bi;
+            if (bjn == nb) { bjn = 0; ++bin; }
+            if (bin == na) { bin = na - 1; bjn = nb - 1; }
+            const double dnx = Dj[(size_t)(offa + bin) * n + offb + bjn];
+            double t = 0.0;
 #pragma unroll
-        for (int c = 0; c < NC; ++c) {
-            const double v = I[(ab * NC + c) * LS];
-            jcd[c] = fma(v, dab, jcd[c]);
-            t = fma(v, dcd[c], t);
+            for (int c = 0; c < NC; ++c) {
+                const double v = I[(ab * NC + c) * LS];
+                jcd[c] = fma(v, dab, jcd[c]);
+                t = fma(v, dcd[c], t);
+            }
+            I[(ab * NC) * LS] = fj * t;                       // own column: this lane's share of Gt_ab
+            dab = dnx; bi = bin; bj = bjn;
         }
-        I[(ab * NC) * LS] = fj * t;                           // own column: this lane's share of Gt_ab
     }
     if (active) {
 #pragma unroll
@@ -392,6 +434,7 @@ __device__ __forceinline__ void qc_bm_body(const QcKernelArgs &a, const double *
         const size_t o = (size_t)(offa + ab / nb) * n + offb + ab % nb;
         qc_gadd2(&G0[o], &G1[o], uhf, s0 + s1, fxscale, a.fx_lo);
     }
+    QC_BT(4);
 }
 
 // Workgroup = qc_bm_waves(LCD, HI) independent waves sharing the LDS Boys table of their segment's Hermite order; every wave
@@ -428,12 +471,12 @@ __device__ __forceinline__ void qc_bm_segment(const QcBmArgs &a, const int s, co
     double *const Iw = wbase;
     double *const rowbuf = rowwords ? wbase + a.seg_iwords[s] : nullptr;
     for (int x = lane; x < rowwords; x += 64) rowbuf[x] = 0.0;
-    const QcBundle *__restrict__ bundles = a.seg_bundles[s];
+    const QcBundleDev *__restrict__ bundles = a.seg_bundles[s];
+    const QcKetUnit *__restrict__ units = a.seg_ketlist[s];
     // the rows a wave has accumulated for the bundle of bra pair `bra` leave as one global atomic per touched element:
     // the 64 kets of a bundle share most of their functions, so the lanes' contributions combine 2-5x in LDS first
     const double fxscale = a.base.fxs ? a.base.fxs[0] : 0.0;
-    auto flush_rows = [&](int bra) {
-        const QcPairDesc pb = a.base.pairs[bra];
+    auto flush_rows = [&](const QcBmBundleRegs &pb) {
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
         for (int sp = 0; sp < nsp; ++sp) {
@@ -451,10 +494,31 @@ __device__ __forceinline__ void qc_bm_segment(const QcBmArgs &a, const int s, co
         __builtin_amdgcn_wave_barrier();
     };
     const int nb = a.seg_nbundles[s];
-    for (int b = wg * nw + wave; b < nb; b += nwg * nw) {
-        qc_bm_body<LAB, LCD>(a.base, a.pairdataT, bundles, a.seg_ketlist[s], b, lds, Iw, a.pspack, rowbuf, rowcap);
-        if (rowbuf) flush_rows(__builtin_amdgcn_readfirstlane(bundles[b].bra));
+#ifdef QC_BM_TIMING
+    long long tph[8] = {}, tlast = wall_clock64();
+    int nbun = 0;
+#endif
+    const int b0 = __builtin_amdgcn_readfirstlane(wg * nw + wave), bstep = nwg * nw;
+    if (b0 >= nb) return;
+    QcBmBundleRegs bd = qc_bm_load_bundle(bundles, b0);
+    QcKetUnit ue = units[bd.first + min(lane, bd.nket - 1)];
+    for (int b = b0; b < nb; b += bstep) {
+        // records of the wave's next bundle: the bundle now (scalar), its unit while the rows of this one are flushed
+        const QcBmBundleRegs bdn = qc_bm_load_bundle(bundles, min(b + bstep, nb - 1));
+        qc_bm_body<LAB, LCD>(a.base, a.pairdataT, bd, ue, b, lds, Iw, a.pspack, rowbuf, rowcap QC_BT_PASS);
+        const QcKetUnit uen = units[bdn.first + min(lane, bdn.nket - 1)];
+        if (rowbuf) flush_rows(bd);
+        bd = bdn; ue = uen;
+        QC_BT(5);
+#ifdef QC_BM_TIMING
+        ++nbun;
+#endif
     }
+#ifdef QC_BM_TIMING
+    if (lane == 0 && wave == 0 && wg < 2 && a.base.eri_out == nullptr && a.base.schwarz_out == nullptr)
+        printf("bm<%d,%d> seg wg %d: %d bundles (of %d)  setup %lld  k-loop %lld  step3 %lld  digestK %lld  digestJ %lld  flush %lld  [10 ns]\n", LAB, LCD, wg, nbun, nb,
+               tph[0], tph[1], tph[2], tph[3], tph[4], tph[5]);
+#endif
 }
 
 template <int LCD, int HI>

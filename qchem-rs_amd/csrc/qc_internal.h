@@ -90,6 +90,13 @@ struct QcSlot { int bra, ket, lo, hi, c0, c1; };  // a quartet restricted to pri
 // Work unit of the bra-major kernels (narrow kets, qc_fock_bm.hip): one wave = one bra pair restricted to the bra
 // primitive pairs [ij_lo, ij_hi), against up to 64 ket pairs (one per lane) ketlist[first .. first + nket).
 struct QcBundle { int bra, ij_lo, ij_hi, first, nket, maxK, pad0, pad1; };
+// Device forms of the bra-major work lists (qc_bm_device_lists): the bundle with what the kernel needs of its bra pair (so that it is
+// one scalar load), the lane's unit with what it needs of the ket pair (no look-up in the pair table between the list and the
+// primitive records).  nanb = na | nb << 8 | shA_eq_shB << 16;  cd = offa | offb << 16 of the ket pair;
+// info = primitives of the unit | (nb == 1) << 16 | shA_eq_shB << 17 | psperm << 18;  koff = offset (doubles) of the unit's first
+// primitive record in the pair data (ss kets) or in pspack (ps kets).
+struct alignas(16) QcBundleDev { int bra, ij_lo, ij_hi, first, nket, maxK, bdoff, offa, offb, nanb, pad0, pad1; };
+struct alignas(16) QcKetUnit { int ket, koff, cd, info; };
 
 struct QcClass {
     int LAB, LCD, LGC;            // Hermite orders of bra / ket pairs; log2 of the lane-group width C
@@ -107,8 +114,8 @@ struct QcClass {
     int bm_rows = 0;              // most bra functions (na + nb) of a bundle: rows of the kernels' exchange buffer
     std::vector<QcBundle> bundles;
     std::vector<int> ketlist;
-    QcBundle *d_bundles = nullptr;
-    int *d_ketlist = nullptr;
+    QcBundleDev *d_bundles = nullptr;
+    QcKetUnit *d_ketlist = nullptr;
     // work model of `shard`
     int64_t prim_quartets = 0;
     double bytes_alg = 0, flops_alg = 0;
