@@ -671,8 +671,8 @@ int qc_schwarz_device(qc_system *S) {
             QC_HIP_CHECK(hipMemcpyAsync(db.p, hb.data(), hb.size() * sizeof(QcBundleDev), hipMemcpyHostToDevice, S->stream));
             QC_HIP_CHECK(hipMemcpyAsync(dk.p, hu.data(), hu.size() * sizeof(QcKetUnit), hipMemcpyHostToDevice, S->stream));
             int mx = 0;
-            for (const auto &t : diag) mx = std::max(mx, S->pairs[t.bra].na * S->pairs[t.bra].nb * S->pairs[t.ket].na * S->pairs[t.ket].nb);
-            int rc = launch_segments(S, qc_unit_of(c.LAB, c.LCD, true), {Seg{&c, nullptr, (int)bundles.size(), db.p, dk.p, mx * 65 * 8}}, S->stream, a);
+            for (const auto &t : diag) mx = std::max(mx, qc_bm_wave_words(c.LAB, S->pairs[t.bra].na * S->pairs[t.bra].nb, S->pairs[t.ket].na * S->pairs[t.ket].nb));
+            int rc = launch_segments(S, qc_unit_of(c.LAB, c.LCD, true), {Seg{&c, nullptr, (int)bundles.size(), db.p, dk.p, mx * 8}}, S->stream, a);
             QC_HIP_CHECK(hipStreamSynchronize(S->stream));
             if (rc != QC_OK) return rc;
             continue;
@@ -711,8 +711,8 @@ int qc_launch_eri_full(qc_system *S, double *d_out) {
             QC_HIP_CHECK(hipMemcpyAsync(db.p, hb.data(), hb.size() * sizeof(QcBundleDev), hipMemcpyHostToDevice, S->stream));
             QC_HIP_CHECK(hipMemcpyAsync(dk.p, hu.data(), hu.size() * sizeof(QcKetUnit), hipMemcpyHostToDevice, S->stream));
             int mx = 0;
-            for (const auto &t : c.tasks) mx = std::max(mx, S->pairs[t.bra].na * S->pairs[t.bra].nb * S->pairs[t.ket].na * S->pairs[t.ket].nb);
-            int rc = launch_segments(S, qc_unit_of(c.LAB, c.LCD, true), {Seg{&c, nullptr, (int)bundles.size(), db.p, dk.p, mx * 65 * 8}}, S->stream, a);
+            for (const auto &t : c.tasks) mx = std::max(mx, qc_bm_wave_words(c.LAB, S->pairs[t.bra].na * S->pairs[t.bra].nb, S->pairs[t.ket].na * S->pairs[t.ket].nb));
+            int rc = launch_segments(S, qc_unit_of(c.LAB, c.LCD, true), {Seg{&c, nullptr, (int)bundles.size(), db.p, dk.p, mx * 8}}, S->stream, a);
             QC_HIP_CHECK(hipStreamSynchronize(S->stream));
             if (rc != QC_OK) return rc;
             continue;

@@ -173,6 +173,42 @@ __device__ __forceinline__ void qc_bm_pass(const double *__restrict__ pd, const 
     }
     QC_BT(1);
     // step 3 with the wave-uniform bra blocks: I[ab][c] += sum_u sum_h E_ab,ij+u[ab][h] W[u][c][h]
+    if constexpr (LAB >= 3) {
+        // High bras (HAB = 20 / 35, up to 36 function pairs): a row is 2-4 scalar pieces, and one piece ahead leaves the step bound by the
+        // scalar-load latency (17 us of a 36 us bundle for the (dd|ss) class).  The block is staged in the wave's LDS - coalesced
+        // loads, one latency - and read back as wave-uniform (broadcast) DS reads.
+        static_assert(NIJ == 1, "high bras run one bra primitive pair per pass");
+        const int lane = threadIdx.x & 63;
+        double *const Es = I - lane + nab * NC * LS;            // behind the wave's I block (qc_bm_wave_words)
+        const double *__restrict__ Eg = pdT + bdoff + (size_t)ij * strideB + 4;
+        const int ne = nab * HAB;
+        for (int x0 = lane; x0 < ne; x0 += 4 * 64) {
+            double v[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) v[k] = Eg[min(x0 + k * 64, ne - 1)];
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                if (x0 + k * 64 < ne) Es[x0 + k * 64] = v[k];
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        for (int ab = 0; ab < nab; ++ab) {
+            const double *row = Es + ab * HAB;
+            double acc[NC];
+#pragma unroll
+            for (int c = 0; c < NC; ++c) acc[c] = 0.0;
+#pragma unroll
+            for (int h = 0; h < HAB; ++h) {            // (one chain in ascending h, as in the scalar form: same roundings)
+                const double e = row[h];
+#pragma unroll
+                for (int c = 0; c < NC; ++c) acc[c] = fma(e, W[0][c][h], acc[c]);
+            }
+#pragma unroll
+            for (int c = 0; c < NC; ++c) qc_lds_add(&I[(ab * NC + c) * LS], acc[c]);
+        }
+        // (the next pass overwrites Es only after these reads: DS operations of a wave execute in order)
+    } else {
     constexpr int PL = QC_BM_PIECE, NPC = (HAB + PL - 1) / PL, NP = NIJ * NPC;
     qc_cdouble *ET = (qc_cdouble *)(pdT + bdoff + (size_t)ij * strideB + 4);
     auto load_piece = [&](double (&e)[PL], const int ab, const int u, const int pc) {
@@ -206,6 +242,7 @@ __device__ __forceinline__ void qc_bm_pass(const double *__restrict__ pd, const 
         }
 #pragma unroll
         for (int c = 0; c < NC; ++c) qc_lds_add(&I[(ab * NC + c) * LS], acc[c]);
+    }
     }
 #pragma unroll
     for (int u = 0; u < 2; ++u)

@@ -518,11 +518,11 @@ void qc_build_shards(qc_system *S) {
             int mx = 0;
             c.bm_rows = 0;
             for (const auto &t : c.shard) {
-                mx = std::max(mx, S->pairs[t.bra].na * S->pairs[t.bra].nb * S->pairs[t.ket].na * S->pairs[t.ket].nb);
+                mx = std::max(mx, qc_bm_wave_words(c.LAB, S->pairs[t.bra].na * S->pairs[t.bra].nb, S->pairs[t.ket].na * S->pairs[t.ket].nb));
                 c.bm_rows = std::max(c.bm_rows, S->pairs[t.bra].na + S->pairs[t.bra].nb);
             }
             c.slot_words = mx;
-            c.lds_bytes = mx * 65 * 8;
+            c.lds_bytes = mx * 8;
         }
     }
 }
