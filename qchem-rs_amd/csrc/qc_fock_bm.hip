@@ -135,6 +135,21 @@ __device__ __forceinline__ void qc_bm_pass(const double *__restrict__ pd, const 
         for (int c = 0; c < NC; ++c)
 #pragma unroll
             for (int h = 0; h < HAB; ++h) W[u][c][h] = 0.0;
+    // high bras: the expansion block of this bra primitive pair (step 3 below) is requested now - coalesced, NV values per lane held in
+    // registers through the primitive loop - and staged in the wave's LDS afterwards
+    // (LAB = 3: at most 18 function pairs x 20 = 6 values per lane; LAB = 4 would need 20 - that costs the ss-ket launch its second wave
+    // per SIMD - and its bras are mostly single primitive pairs, one pass per bundle: staged after the loop, one exposed latency)
+    constexpr bool STAGE = LAB >= 3 && LCD == 0;     // (ps kets, three columns per lane: measured slower staged - 17 vs 10 us per bundle on H2O/cc-pVTZ)
+    constexpr int NV = (LAB == 3) ? (18 * 20 + 63) / 64 : 1;
+    constexpr bool PRE = STAGE && LAB == 3;
+    const int lane = threadIdx.x & 63;
+    const double *__restrict__ Eg = pdT + bdoff + (size_t)ij * strideB + 4;
+    const int ne = nab * HAB;
+    double est[NV];
+    if constexpr (PRE) {
+#pragma unroll
+        for (int k = 0; k < NV; ++k) est[k] = (k * 64 < ne) ? Eg[min(lane + k * 64, ne - 1)] : 0.0;
+    }
     // the next ket primitive's record is requested one iteration ahead.  ss kets: pair-data block [q, Q | E]; ps kets:
     // packed record [q, Q | e0x, e0y, e0z, e1] (ketBase points into pspack, stride 8)
     double4 hk = hk0;
@@ -173,16 +188,18 @@ __device__ __forceinline__ void qc_bm_pass(const double *__restrict__ pd, const 
     }
     QC_BT(1);
     // step 3 with the wave-uniform bra blocks: I[ab][c] += sum_u sum_h E_ab,ij+u[ab][h] W[u][c][h]
-    if constexpr (LAB >= 3) {
+    if constexpr (STAGE) {
         // High bras (HAB = 20 / 35, up to 36 function pairs): a row is 2-4 scalar pieces, and one piece ahead leaves the step bound by the
         // scalar-load latency (17 us of a 36 us bundle for the (dd|ss) class).  The block is staged in the wave's LDS - coalesced
         // loads, one latency - and read back as wave-uniform (broadcast) DS reads.
         static_assert(NIJ == 1, "high bras run one bra primitive pair per pass");
-        const int lane = threadIdx.x & 63;
         double *const Es = I - lane + nab * NC * LS;            // behind the wave's I block (qc_bm_wave_words)
-        const double *__restrict__ Eg = pdT + bdoff + (size_t)ij * strideB + 4;
-        const int ne = nab * HAB;
-        for (int x0 = lane; x0 < ne; x0 += 4 * 64) {
+        if constexpr (PRE) {
+#pragma unroll
+            for (int k = 0; k < NV; ++k)
+                if (k * 64 < ne) Es[min(lane + k * 64, ne - 1)] = est[k];   // (lanes past the end rewrite the last element with its own value)
+        }
+        for (int x0 = lane + (PRE ? NV * 64 : 0); x0 < ne; x0 += 4 * 64) {  // what the register stage does not hold
             double v[4];
 #pragma unroll
             for (int k = 0; k < 4; ++k) v[k] = Eg[min(x0 + k * 64, ne - 1)];

@@ -95,9 +95,9 @@ struct QcBundle { int bra, ij_lo, ij_hi, first, nket, maxK, pad0, pad1; };
 // primitive records).  nanb = na | nb << 8 | shA_eq_shB << 16;  cd = offa | offb << 16 of the ket pair;
 // info = primitives of the unit | (nb == 1) << 16 | shA_eq_shB << 17 | psperm << 18;  koff = offset (doubles) of the unit's first
 // primitive record in the pair data (ss kets) or in pspack (ps kets).
-// LDS doubles of one wave of a bra-major launch: its block I[nab * ncd][65] and, for the high bras (LAB >= 3), the staged expansion
-// block E[nab][HAB] of the current bra primitive pair (step 3 of qc_bm_pass)
-inline int qc_bm_wave_words(int LAB, int nab, int ncd) { return nab * ncd * 65 + (LAB >= 3 ? ((nab * qc_nherm(LAB) + 1) & ~1) : 0); }
+// LDS doubles of one wave of a bra-major launch: its block I[nab * ncd][65] and, for the high bras (LAB >= 3) against ss kets, the
+// staged expansion block E[nab][HAB] of the current bra primitive pair (step 3 of qc_bm_pass)
+inline int qc_bm_wave_words(int LAB, int nab, int ncd) { return nab * ncd * 65 + (LAB >= 3 && ncd == 1 ? ((nab * qc_nherm(LAB) + 1) & ~1) : 0); }
 struct alignas(16) QcBundleDev { int bra, ij_lo, ij_hi, first, nket, maxK, bdoff, offa, offb, nanb, pad0, pad1; };
 struct alignas(16) QcKetUnit { int ket, koff, cd, info; };
 

@@ -1,0 +1,10 @@
+# A/B of one environment setting on ONE box, H2O/cc-pVTZ: bash tools/ab_env.sh "VAR=value" [rounds]
+E=$1; R=${2:-6}
+for r in $(seq 1 $R); do
+  for X in "QC_AB_DUMMY=1" "$E"; do
+      env $X timeout -k 10 300 python bench.py --workload h2o_ccpvtz --no-extras --no-cpu-baseline --steps 30 2>/dev/null | python -c "
+import json,sys
+d=json.loads(sys.stdin.readline()); b=d['iter_breakdown_ms']
+print('%-28s iter %.4f  build %.4f  linalg %.4f' % ('$X', d['ms_per_step'], b['fock_build'], b['diis_eig_density']))"
+  done
+done
