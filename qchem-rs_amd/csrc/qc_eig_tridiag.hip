@@ -529,7 +529,8 @@ int qc_eig_tridiag_start(hipStream_t st, int n, const double *dA, double *dX0, d
         if (hipFuncSetAttribute(reinterpret_cast<const void *>(qc_tridiag_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, QC_LDS_MAX) != hipSuccess) return QC_ERR_HIP;
         raised.store(true, std::memory_order_release);
     }
-    const double rel_pert = 1e-9;
+    static const double pert_env = getenv("QC_TRI_PERT") ? atof(getenv("QC_TRI_PERT")) : 0.0;      // A/B switch
+    const double rel_pert = pert_env > 0.0 ? pert_env : 1e-11;
     const size_t small = ((size_t)n + 32) * sizeof(double);
     // row stride: 8 mod 32 doubles, so that the eight rows a wave reads at a time fall into disjoint LDS banks (when that still fits)
     int ld = n + ((8 - n % 32) + 32) % 32;

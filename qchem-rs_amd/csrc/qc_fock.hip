@@ -209,6 +209,10 @@ int qc_device_init(qc_system *S) {
     QC_HIP_CHECK(hipMalloc(&S->d_Gred, (size_t)2 * 2 * nn * sizeof(double)));
     QC_HIP_CHECK(hipMalloc(&S->d_Dj, nn * sizeof(double)));
     QC_HIP_CHECK(hipMalloc(&S->d_flag, 4 * sizeof(int)));
+    QC_HIP_CHECK(hipMalloc(&S->d_join, 4 * sizeof(unsigned)));
+    QC_HIP_CHECK(hipMemset(S->d_join, 0, 4 * sizeof(unsigned)));
+    QC_HIP_CHECK(hipHostMalloc(&S->h_join_timeout, sizeof(int), hipHostMallocDefault));
+    *S->h_join_timeout = 0; S->join_target = 0;
     QC_HIP_CHECK(hipMalloc(&S->d_fxs, 2 * sizeof(double)));
     // Schwarz factors of the pairs (once per geometry), then the screened work lists
     int rc = qc_schwarz_device(S);
@@ -227,6 +231,8 @@ void qc_device_free(qc_system *S) {
     }
     void *ptrs[] = {S->d_rplan, S->d_gidx, S->d_shells, S->d_pairdata, S->d_pairdataT, S->d_pspack, S->d_pairs, S->d_boys, S->d_D, S->d_G, S->d_Gtmp, S->d_Gred, S->d_Dj, S->d_flag, S->d_fxs};
     S->d_flag = nullptr; S->d_fxs = nullptr;
+    if (S->d_join) { (void)hipFree(S->d_join); S->d_join = nullptr; }
+    if (S->h_join_timeout) { (void)hipHostFree(S->h_join_timeout); S->h_join_timeout = nullptr; }
     for (void *p : ptrs) if (p) (void)hipFree(p);
     S->d_shells = nullptr; S->d_pairdata = S->d_pairdataT = S->d_pspack = nullptr; S->d_pairs = nullptr; S->d_rplan = nullptr; S->d_gidx = nullptr; S->d_boys = S->d_D = S->d_G = S->d_Gtmp = S->d_Gred = S->d_Dj = nullptr;
     for (int i = 0; i < QC_NSTREAMS; ++i) {
@@ -239,6 +245,23 @@ void qc_device_free(qc_system *S) {
 
     if (S->own_stream && S->stream) (void)hipStreamDestroy(S->stream);
     S->stream = nullptr; S->own_stream = false; S->device_ready = false;
+}
+
+// Device-side join of a build's side streams.  Joining through events costs the cross-queue signal path - event packet on the side
+// queue, barrier packet on the handle's queue, ~20 us between the last class kernel and the fold on the H2O/cc-pVTZ trace.  Instead every
+// side stream ends with a one-lane marker kernel that counts itself (in-queue dependency: a few us), and the handle's stream runs a
+// one-lane kernel that waits for the count of this build (monotonic counter, signed comparison) before the fold.  The wait gives up after
+// two seconds of the constant 100 MHz clock - only possible when a side stream's launches never complete - and says so in pinned memory.
+__global__ void qc_join_mark_kernel(unsigned *cnt) {
+    if (threadIdx.x == 0) (void)__hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+}
+__global__ void qc_join_wait_kernel(unsigned *cnt, unsigned target, int *timeout_flag) {
+    if (threadIdx.x != 0) return;
+    const long long t0 = wall_clock64();
+    while ((int)(__hip_atomic_load(cnt, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) - target) < 0) {
+        __builtin_amdgcn_s_sleep(4);
+        if (wall_clock64() - t0 > 200000000LL) { *timeout_flag = 1; __threadfence_system(); break; }
+    }
 }
 
 static QcKernelArgs base_args(qc_system *S, const QcFockArgs &fa) {
@@ -394,11 +417,15 @@ int qc_launch_fock_classes(qc_system *S, const QcFockArgs &fa, float *class_ms, 
     // stream's, GPU_MAX_HW_QUEUES=8).  Kernels on one stream run in order, so the assignment matters: the first build
     // of a handle times every unit alone (density-independent), then units are placed longest-first on the least
     // loaded stream.
-    auto lpt = [&](const std::vector<float> &w, int nstreams) {
+    // (`head_start`, ms: stream 0 is given that much more work than the others.  The most loaded stream becomes the handle's own stream,
+    // and a build that ends on the handle's stream goes straight on to the fold, while one that ends on a side stream first pays the
+    // cross-queue signal - event packet, barrier packets, ~20 us on the H2O/cc-pVTZ trace.)
+    auto lpt = [&](const std::vector<float> &w, int nstreams, float head_start = 0.f) {
         std::vector<int> ord;
         for (size_t u = 0; u < units.size(); ++u) if (!units[u].empty()) ord.push_back((int)u);
         std::stable_sort(ord.begin(), ord.end(), [&](int x, int y) { return w[x] > w[y]; });
         std::vector<float> load(nstreams, 0.f);
+        load[0] = -head_start;
         S->unit_stream.assign(units.size(), 0);
         for (int u : ord) {
             const int k = (int)(std::min_element(load.begin(), load.end()) - load.begin());
@@ -445,10 +472,26 @@ int qc_launch_fock_classes(qc_system *S, const QcFockArgs &fa, float *class_ms, 
             if (rc != QC_OK) return rc;
             if (ev && per_unit) QC_HIP_CHECK(hipEventRecord(ev[3 + 2 * u], st));
         }
-        for (int k = 0; k < QC_NSTREAMS; ++k) {
-            if (!used[k] || k == kmain) continue;
-            QC_HIP_CHECK(hipEventRecord(S->ev_join[k], S->side[k]));
-            QC_HIP_CHECK(hipStreamWaitEvent(S->stream, S->ev_join[k], 0));
+        static const bool event_join = getenv("QC_EVENT_JOIN") != nullptr;           // (A/B switch: the event join of rounds 1-2)
+        if (event_join) {
+            for (int k = 0; k < QC_NSTREAMS; ++k) {
+                if (!used[k] || k == kmain) continue;
+                QC_HIP_CHECK(hipEventRecord(S->ev_join[k], S->side[k]));
+                QC_HIP_CHECK(hipStreamWaitEvent(S->stream, S->ev_join[k], 0));
+            }
+        } else {
+            if (*S->h_join_timeout) return QC_ERR_HIP;              // an earlier build's join gave up: its result was not complete
+            unsigned nside = 0;
+            for (int k = 0; k < QC_NSTREAMS; ++k) {
+                if (!used[k] || k == kmain) continue;
+                hipLaunchKernelGGL(qc_join_mark_kernel, dim3(1), dim3(64), 0, S->side[k], S->d_join);
+                ++nside;
+            }
+            if (nside) {
+                S->join_target += nside;
+                hipLaunchKernelGGL(qc_join_wait_kernel, dim3(1), dim3(64), 0, S->stream, S->d_join, S->join_target, S->h_join_timeout);
+            }
+            if (hipGetLastError() != hipSuccess) return QC_ERR_HIP;
         }
         if (ev) QC_HIP_CHECK(hipEventRecord(ev[1], S->stream));
         return QC_OK;
@@ -481,8 +524,10 @@ int qc_launch_fock_classes(qc_system *S, const QcFockArgs &fa, float *class_ms, 
             float tot = 0.f;
             QC_HIP_CHECK(hipEventElapsedTime(&tot, ev[0], ev[1]));
             std::vector<float> dur(units.size(), 0.f);
+            // (the device-side join tells the handle's stream, not the runtime, that the side streams are through: their events are
+            // waited for by name before they are read)
             for (size_t u = 0; u < units.size(); ++u)
-                if (!units[u].empty()) QC_HIP_CHECK(hipEventElapsedTime(&dur[u], ev[2 + 2 * u], ev[3 + 2 * u]));
+                if (!units[u].empty()) { QC_HIP_CHECK(hipEventSynchronize(ev[3 + 2 * u])); QC_HIP_CHECK(hipEventElapsedTime(&dur[u], ev[2 + 2 * u], ev[3 + 2 * u])); }
             // (a candidate keeps the durations measured in ITS build: they order the launches - longest chain first - when it is replayed)
             cand.push_back(S->unit_stream); weight.push_back(dur); total.push_back(tot);
             if (dbg) {
@@ -492,6 +537,36 @@ int qc_launch_fock_classes(qc_system *S, const QcFockArgs &fa, float *class_ms, 
             }
             static const int widths[QC_TUNE_ROUNDS] = {QC_NSTREAMS, QC_NSTREAMS, 5, 4, 6, QC_NSTREAMS};   // of the *next* candidate
             lpt(dur, widths[round]);
+        }
+        // (round 3) The totals above were measured with two events around every launch, and those change the picture (a build of 13 launches
+        // gains 26 event packets): the ranking that the local search and the finals start from is taken again from builds as the steady state
+        // runs them - together with three more candidates, longest-first on the durations ALONE over 4, 5 and 6 streams: a kernel trace of
+        // H2O/cc-pVTZ passes showed in-build durations equal to the durations alone at five concurrent launches (the chip's wave slots
+        // are full at that point; a sixth or seventh launch only stretches the others), and the chosen assignment ending 187 us after its
+        // start on a four-launch chain where longest-first over five streams packs the same durations into 156.
+        static const bool tune_v1 = getenv("QC_TUNE_V1") != nullptr;            // (A/B switch: the ranking of round 2)
+        if (!tune_v1) {
+            for (int wdt : {4, 5, 6}) {
+                if (wdt > QC_NSTREAMS) continue;
+                for (float hs : {0.f, 0.015f}) {
+                    lpt(S->unit_ms, wdt, hs);
+                    cand.push_back(S->unit_stream); weight.push_back(S->unit_ms); total.push_back(0.f);
+                }
+            }
+            for (size_t i = 0; i < cand.size(); ++i) {
+                S->unit_stream = cand[i]; S->unit_weight = weight[i];
+                float tmin = 1e30f;
+                for (int rep = 0; rep < 3; ++rep) {
+                    if (fa.G0) QC_HIP_CHECK(hipMemsetAsync(fa.G0, 0, gbytes, S->stream));
+                    if ((rc = launch_concurrent(ev.data(), false)) != QC_OK) return rc;
+                    QC_HIP_CHECK(hipEventSynchronize(ev[1]));
+                    float t = 0.f;
+                    QC_HIP_CHECK(hipEventElapsedTime(&t, ev[0], ev[1]));
+                    if (rep > 0) tmin = std::min(tmin, t);
+                }
+                total[i] = tmin;
+                if (dbg) fprintf(stderr, "[tune] cand %zu as the steady state runs it: %.3f ms\n", i, tmin);
+            }
         }
         // local search around the fastest candidate: move one launch to another stream or swap two launches, keep what makes the build
         // faster (steady-state form of the build, best of two; which kernels disturb each other is not something the longest-first rule

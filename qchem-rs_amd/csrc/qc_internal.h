@@ -162,6 +162,9 @@ struct qc_system {
     double *d_Dj = nullptr;
     double *d_fxs = nullptr;                 // [2^S, 2^-S]: fixed-point scale of the current build
     int *d_flag = nullptr;
+    unsigned *d_join = nullptr;              // counter of the device-side join of a build's side streams (qc_join_mark / qc_join_wait)
+    int *h_join_timeout = nullptr;           // pinned: set by a join that gave up (a side stream's launches never finished)
+    unsigned join_target = 0;
     void *comm = nullptr;                    // ncclComm_t
     std::vector<float> unit_ms;              // measured serial time of each launch unit (autotuned once per shard)
     std::vector<int> unit_stream;            // side stream of each launch unit (longest-processing-time assignment)
