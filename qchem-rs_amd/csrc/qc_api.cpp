@@ -155,7 +155,8 @@ struct ScfWork {
         if (tri.alloc(qc_eig_tridiag_work_doubles(n)) != QC_OK) return QC_ERR_HIP;
         if (w.alloc(n) != QC_OK || scal.alloc(16) != QC_OK || small.alloc(qc_eig_small_doubles(n)) != QC_OK) return QC_ERR_HIP;
         if (hipMalloc(&ctl, 16 * sizeof(int)) != hipSuccess || hipMemset(ctl, 0, 16 * sizeof(int)) != hipSuccess) return QC_ERR_HIP;
-        if (hipHostMalloc(&h_scal, 2 * QC_SYNC_WORDS * sizeof(double)) != hipSuccess) return QC_ERR_HIP;
+        if (hipHostMalloc(&h_scal, (2 * QC_SYNC_WORDS + 1) * sizeof(double)) != hipSuccess) return QC_ERR_HIP;
+        std::memset(h_scal, 0, (2 * QC_SYNC_WORDS + 1) * sizeof(double));     // (the last word: sequence number of the pass, see scf_iterate)
         if (hipMalloc(&d_sync, 2 * QC_SYNC_WORDS * sizeof(unsigned long long)) != hipSuccess) return QC_ERR_HIP;
         return QC_OK;
     }
@@ -251,7 +252,7 @@ int roothaan_enqueue(qc_system *S, ScfWork &W, DeviceDiis &diis, const double *d
 
 // The same step for n <= QC_SMALL_MAXN, density / energy / rms of rhf.rs:78-88 included: one launch when the eigensolve is a refinement from
 // the previous vectors, pre | tridiagonal start | refine + post when it starts cold, pre | Jacobi kernel | post for the rotation-only runs.
-struct SmallTail { int nocc; double dfac; double *Dn; const double *Dold; double *scal_out; int *ctl_all, *ctl_out; double *fxs_out; };
+struct SmallTail { int nocc; double dfac; double *Dn; const double *Dold; double *scal_out; int *ctl_all, *ctl_out; double *fxs_out; unsigned *seq_out = nullptr; unsigned seq = 0; };
 int roothaan_small(qc_system *S, ScfWork &W, DeviceDiis &diis, const double *dG, const double *dD, double *dw_out, double *dC, int spin,
                    double *dE, double *dF, bool have_F, const SmallTail &tl) {
     const int n = S->nbasis;
@@ -268,6 +269,7 @@ int roothaan_small(qc_system *S, ScfWork &W, DeviceDiis &diis, const double *dG,
     a.ctl = W.ctl + 4 * spin;
     a.Cp_out = W.CpNew[spin].p; a.w_out = dw_out; a.C_out = dC; a.Dn = tl.Dn; a.Dold = tl.Dold; a.nocc = tl.nocc; a.dfac = tl.dfac;
     a.scal_out = tl.scal_out; a.ctl_all = tl.ctl_all; a.ctl_out = tl.ctl_out; a.fxs_out = tl.fxs_out; a.imax = S->imax;
+    a.seq_out = tl.seq_out; a.seq = tl.seq;
     W.cold[spin] = false;
     static const bool force_jacobi = getenv("QC_EIG_JACOBI") != nullptr;
     int rc;
@@ -276,7 +278,7 @@ int roothaan_small(qc_system *S, ScfWork &W, DeviceDiis &diis, const double *dG,
         return qc_scf_small_launch(st, a);
     }
     QcSmallArgs pre = a;
-    pre.phases = 1; pre.ctl_all = nullptr;
+    pre.phases = 1; pre.ctl_all = nullptr; pre.seq_out = nullptr;
     if ((rc = qc_scf_small_launch(st, pre)) != QC_OK) return rc;
     if (qc_tri_ok(n) && !force_jacobi && !W.rotations_only) {
         W.cold[spin] = true;
@@ -585,6 +587,8 @@ struct qc_scf_state {
     DeviceDiis *diis[2] = {nullptr, nullptr};
     hipEvent_t ev0 = nullptr, ev1 = nullptr, ev2 = nullptr;
     double ms_fock = 0, ms_linalg = 0, ms_setup = 0;
+    unsigned pass_seq = 0;                     // sequence number of the last pass whose end the host saw through the pinned word
+    bool linalg_pending = false;               // ... and whose linear-algebra time (ev1 -> ev2) has not been read yet
     ~qc_scf_state() {
         if (S && S->prep_owner == this) { S->prepared = false; S->prep_owner = nullptr; }
         delete diis[0]; delete diis[1];
@@ -668,6 +672,14 @@ static int scf_begin(qc_system *S, bool uhf, int n_alpha, int n_beta, qc_scf_sta
     return QC_OK;
 }
 
+// (a pass whose end the host saw through the pinned sequence word has not read its ev1 -> ev2 time yet: ev2 may still have been in flight)
+static void scf_flush_timing(qc_scf_state *st) {
+    if (!st->linalg_pending) return;
+    st->linalg_pending = false;
+    float ms_l = 0;
+    if (hipEventSynchronize(st->ev2) == hipSuccess && hipEventElapsedTime(&ms_l, st->ev1, st->ev2) == hipSuccess) st->ms_linalg += ms_l;
+}
+
 // Wait for an event by polling (what hipStreamSynchronize does too): a parked thread's wake-up latency is longer
 // than a whole SCF pass of a small molecule.
 static hipError_t wait_event(hipEvent_t ev) {
@@ -690,6 +702,7 @@ static int scf_iterate(qc_scf_state *st, double *energy, double *rms_out) {
     const int nspin = st->uhf ? 2 : 1;
     int rc;
     const double th0 = now_ms();
+    scf_flush_timing(st);
     QC_HIP_CHECK(hipEventRecord(st->ev0, sm));
     double *dE[2] = {nullptr, nullptr}, *dF[2] = {nullptr, nullptr};       // this pass's DIIS sample buffers (error, Fock matrix) per spin
     for (int s = 0; s < nspin; ++s) st->diis[s]->next_sample(&dE[s], &dF[s]);
@@ -745,13 +758,19 @@ static int scf_iterate(qc_scf_state *st, double *energy, double *rms_out) {
     };
     if (multi && nspin == 1) QC_HIP_CHECK(hipMemsetAsync(W.d_sync + 2, 0, 2 * sizeof(double), sm));       // unused spin slot
     bool scale_in_kernel = false;
+    // Single-rank runs on the one-workgroup path: the kernel that ends the pass stores the pass's sequence number into pinned memory
+    // after the scalars and control words, and the host polls THAT instead of the event behind it (a few microseconds earlier per pass).
+    static const bool no_seq = getenv("QC_EVENT_WAIT") != nullptr;              // (A/B switch)
+    const bool seq_wait = W.small_fused && !multi && !no_seq;
+    unsigned *h_seq = reinterpret_cast<unsigned *>(W.h_scal + 2 * QC_SYNC_WORDS);
     if (W.small_fused) {
         for (int s = 0; s < nspin; ++s) {
             // (RHF, direct fixed-point builds: the kernel that forms the new density also leaves the next build's fixed-point unit)
             const bool scale_here = !st->uhf && !st->stored && S->accum_fx;
             scale_in_kernel = scale_here;
-            const SmallTail tl{st->nocc[s], st->uhf ? 1.0 : 2.0, st->Dn[s].p, st->D[s].p, scal_out + 2 * s, s == nspin - 1 ? W.ctl : nullptr, ctl_out,
-                               scale_here ? S->d_fxs : nullptr};
+            SmallTail tl{st->nocc[s], st->uhf ? 1.0 : 2.0, st->Dn[s].p, st->D[s].p, scal_out + 2 * s, s == nspin - 1 ? W.ctl : nullptr, ctl_out,
+                         scale_here ? S->d_fxs : nullptr};
+            if (seq_wait && s == nspin - 1) { tl.seq_out = h_seq; tl.seq = st->pass_seq + 1; }
             if ((rc = roothaan_small(S, W, *st->diis[s], st->G.p + s * nn, st->D[s].p, st->ws.p + s * n, st->Cs.p + s * nn, s, dE[s], dF[s], have_F, tl)) != QC_OK) return rc;
         }
     } else
@@ -762,7 +781,18 @@ static int scf_iterate(qc_scf_state *st, double *energy, double *rms_out) {
     if ((rc = prepare_next()) != QC_OK) return rc;
     QC_HIP_CHECK(hipEventRecord(st->ev2, sm));
     const double th1 = now_ms();
-    QC_HIP_CHECK(wait_event(st->ev2));
+    if (seq_wait) {
+        const unsigned want = st->pass_seq + 1;
+        unsigned spins = 0;
+        while (__atomic_load_n(h_seq, __ATOMIC_ACQUIRE) != want) {
+            if ((++spins & 0xfff) == 0) {                   // (a failed launch or a fault never stores the word: the event knows)
+                const hipError_t e = hipEventQuery(st->ev2);
+                if (e == hipErrorNotReady) continue;
+                if (e != hipSuccess || __atomic_load_n(h_seq, __ATOMIC_ACQUIRE) != want) { fprintf(stderr, "qchem_hip: the pass ended without its sequence word (%s)\n", hipGetErrorString(e)); return QC_ERR_HIP; }
+            }
+        }
+        st->pass_seq = want;
+    } else QC_HIP_CHECK(wait_event(st->ev2));
     const double th2 = now_ms();
     if (!ranks_agree()) { fprintf(stderr, "qchem_hip: rank %d: the ranks' SCF scalars differ - replicated state diverged\n", S->rank); return QC_ERR_RCCL; }
     if (h_ctl[8] != 0) return QC_DIIS_SINGULAR;                          // "DIIS failed", rhf.rs:73
@@ -778,8 +808,15 @@ static int scf_iterate(qc_scf_state *st, double *energy, double *rms_out) {
         fprintf(stderr, "\n");
     }
     float ms_f = 0, ms_l = 0;
-    (void)hipEventElapsedTime(&ms_f, st->ev0, st->ev1);
-    (void)hipEventElapsedTime(&ms_l, st->ev1, st->ev2);
+    if (seq_wait) {
+        // ev1 lies before the kernel whose word has just arrived; ev2 behind it - its time is read when the next pass begins
+        (void)hipEventSynchronize(st->ev1);
+        (void)hipEventElapsedTime(&ms_f, st->ev0, st->ev1);
+        st->linalg_pending = true;
+    } else {
+        (void)hipEventElapsedTime(&ms_f, st->ev0, st->ev1);
+        (void)hipEventElapsedTime(&ms_l, st->ev1, st->ev2);
+    }
     if (!st->stored && !S->comm) qc_fock_feedback(S, ms_f);              // (multi-rank: every rank keeps its tuner's choice)
     bool redo = false;
     for (int s = 0; s < nspin; ++s) {
@@ -788,7 +825,7 @@ static int scf_iterate(qc_scf_state *st, double *energy, double *rms_out) {
         if (h_ctl[4 * s] == 1) { W.npass[s] = W.cold[s] ? 3 : std::max(1, std::min(3, h_ctl[4 * s + 3])); continue; }
         W.npass[s] = 3;
         // the refinement wanted rotations (large step, or a degenerate cluster): repeat this spin's eigensolve the careful way
-        if (!redo) QC_HIP_CHECK(hipEventRecord(st->ev1, sm));
+        if (!redo) { scf_flush_timing(st); QC_HIP_CHECK(hipEventRecord(st->ev1, sm)); }
         if ((rc = roothaan_redo_eig(S, W, st->ws.p + s * n, st->Cs.p + s * nn, s)) != QC_OK) return rc;
         if ((rc = density_and_scalars(s, false)) != QC_OK) return rc;
         redo = true;
@@ -860,6 +897,7 @@ static int scf_run(qc_system *S, const qc_hf_config *cfg, qc_hf_output *out, boo
             break;
         }
     }
+    scf_flush_timing(st);
     out->ms_setup = st->ms_setup; out->ms_fock_total = st->ms_fock; out->ms_linalg_total = st->ms_linalg;
     out->ms_total = now_ms() - t_begin;
     return status;
@@ -935,6 +973,7 @@ int qc_set_fock_mode(qc_system *S, int mode) {
 double qc_scf_tensor_ms(qc_scf_state *st) { return st ? st->ms_tensor : 0.0; }
 int qc_scf_timings(qc_scf_state *st, double *ms_setup, double *ms_fock, double *ms_linalg) {
     if (!st) return QC_ERR_INVALID;
+    scf_flush_timing(st);
     if (ms_setup) *ms_setup = st->ms_setup;
     if (ms_fock) *ms_fock = st->ms_fock;
     if (ms_linalg) *ms_linalg = st->ms_linalg;

@@ -5,6 +5,13 @@
 #include <vector>
 
 #include "qc_fock_kernel.h"
+#include <atomic>
+#include <chrono>
+#include <condition_variable>
+#include <functional>
+#include <memory>
+#include <mutex>
+#include <thread>
 #include "qc_fock_bm.h"
 
 int qc_launch_tier_lab0(int, int, size_t, hipStream_t, const QcTierArgs &);
@@ -231,6 +238,7 @@ void qc_device_free(qc_system *S) {
     }
     void *ptrs[] = {S->d_rplan, S->d_gidx, S->d_shells, S->d_pairdata, S->d_pairdataT, S->d_pspack, S->d_pairs, S->d_boys, S->d_D, S->d_G, S->d_Gtmp, S->d_Gred, S->d_Dj, S->d_flag, S->d_fxs};
     S->d_flag = nullptr; S->d_fxs = nullptr;
+    delete S->issue_pool; S->issue_pool = nullptr;
     if (S->d_join) { (void)hipFree(S->d_join); S->d_join = nullptr; }
     if (S->h_join_timeout) { (void)hipHostFree(S->h_join_timeout); S->h_join_timeout = nullptr; }
     for (void *p : ptrs) if (p) (void)hipFree(p);
@@ -246,6 +254,75 @@ void qc_device_free(qc_system *S) {
     if (S->own_stream && S->stream) (void)hipStreamDestroy(S->stream);
     S->stream = nullptr; S->own_stream = false; S->device_ready = false;
 }
+
+// ---- Issuing a build from several host threads.  The runtime needs 5-8 us of host time per launch; a build of H2O/cc-pVTZ is 13 launches
+// and 5 markers, so the last one left the caller ~100 us after the first - half the length of the build itself, and every stream's first
+// kernel started 6-7 us after the previous stream's.  Launches into DIFFERENT streams are independent in the runtime (one lock per
+// stream), so the side streams are shared out between a few helper threads that issue them while the caller issues the handle's own
+// chain.  A helper spins for its next job for a few milliseconds after the last one (a pass of a small molecule is 0.35 ms: a parked
+// thread's wake-up would cost more than it saves) and sleeps on a condition variable after that.
+struct QcIssuePool {
+    struct Worker {
+        std::thread th;
+        std::mutex m;
+        std::condition_variable cv;
+        bool sleeping = false;
+        std::atomic<int> go{0}, done{0};
+        std::atomic<bool> quit{false};
+        std::function<int()> job;
+        int rc = QC_OK;
+    };
+    std::vector<std::unique_ptr<Worker>> w;
+    int gen = 0;
+    static void relax() { __builtin_ia32_pause(); }
+    static void run(Worker *W, int device) {
+        (void)hipSetDevice(device);
+        int seen = 0;
+        for (;;) {
+            int spins = 0;
+            while (W->go.load(std::memory_order_acquire) == seen && !W->quit.load(std::memory_order_acquire)) {
+                if (++spins < 400000) relax();
+                else {
+                    std::unique_lock<std::mutex> lk(W->m);
+                    W->sleeping = true;
+                    W->cv.wait_for(lk, std::chrono::milliseconds(100), [&] { return W->go.load(std::memory_order_acquire) != seen || W->quit.load(std::memory_order_acquire); });
+                    W->sleeping = false;
+                    spins = 0;
+                }
+            }
+            if (W->quit.load(std::memory_order_acquire)) return;
+            seen = W->go.load(std::memory_order_acquire);
+            W->rc = W->job();
+            W->done.store(seen, std::memory_order_release);
+        }
+    }
+    explicit QcIssuePool(int n, int device) {
+        for (int i = 0; i < n; ++i) {
+            w.emplace_back(new Worker());
+            Worker *W = w.back().get();
+            W->th = std::thread(run, W, device);
+        }
+    }
+    void start(int i, std::function<int()> job) {
+        Worker *W = w[i].get();
+        W->job = std::move(job);
+        W->go.store(gen, std::memory_order_release);
+        std::lock_guard<std::mutex> lk(W->m);
+        if (W->sleeping) W->cv.notify_one();
+    }
+    int wait(int i) {
+        Worker *W = w[i].get();
+        while (W->done.load(std::memory_order_acquire) != gen) relax();
+        return W->rc;
+    }
+    ~QcIssuePool() {
+        for (auto &W : w) {
+            W->quit.store(true, std::memory_order_release);
+            { std::lock_guard<std::mutex> lk(W->m); W->cv.notify_one(); }
+            if (W->th.joinable()) W->th.join();
+        }
+    }
+};
 
 // Device-side join of a build's side streams.  Joining through events costs the cross-queue signal path - event packet on the side
 // queue, barrier packet on the handle's queue, ~20 us between the last class kernel and the fold on the H2O/cc-pVTZ trace.  Instead every
@@ -445,52 +522,89 @@ int qc_launch_fock_classes(qc_system *S, const QcFockArgs &fa, float *class_ms, 
         // Issue order (the host needs ~8 us per launch, so it matters): inside a stream heaviest first; across streams the
         // first launch of every stream before any second one, streams in the order of their total load - the chain that
         // ends the build gets going first and no stream sits empty while another one's queue is being filled.
-        std::vector<int> order;
-        int kmain = 0;
+        std::vector<int> q[QC_NSTREAMS];
+        int ks[QC_NSTREAMS];
         {
             std::vector<int> byw;
             for (size_t u = 0; u < units.size(); ++u) if (!units[u].empty()) byw.push_back((int)u);
             std::stable_sort(byw.begin(), byw.end(), [&](int x, int y) { return S->unit_weight[x] > S->unit_weight[y]; });
-            std::vector<int> q[QC_NSTREAMS];
             float load[QC_NSTREAMS] = {};
             for (int u : byw) { q[S->unit_stream[u]].push_back(u); load[S->unit_stream[u]] += S->unit_weight[u]; }
-            int ks[QC_NSTREAMS];
             for (int k = 0; k < QC_NSTREAMS; ++k) ks[k] = k;
             std::stable_sort(ks, ks + QC_NSTREAMS, [&](int x, int y) { return load[x] > load[y]; });
-            for (size_t pos = 0; order.size() < byw.size(); ++pos)
-                for (int k : ks) if (pos < q[k].size()) order.push_back(q[k][pos]);
-            kmain = ks[0];
         }
         // the most loaded chain runs on the handle's own stream: no fork hop before it, no join after it
-        bool used[QC_NSTREAMS] = {};
-        for (int u : order) {
-            const int k = S->unit_stream[u];
-            hipStream_t st = k == kmain ? S->stream : S->side[k];
-            if (!used[k]) { if (k != kmain && fork) QC_HIP_CHECK(hipStreamWaitEvent(st, S->ev_fork, 0)); used[k] = true; }
-            if (ev && per_unit) QC_HIP_CHECK(hipEventRecord(ev[2 + 2 * u], st));
-            int rc = launch_segments(S, u, segs_of(units[u]), st, a);
-            if (rc != QC_OK) return rc;
-            if (ev && per_unit) QC_HIP_CHECK(hipEventRecord(ev[3 + 2 * u], st));
-        }
+        const int kmain = ks[0];
         static const bool event_join = getenv("QC_EVENT_JOIN") != nullptr;           // (A/B switch: the event join of rounds 1-2)
+        if (!event_join && *S->h_join_timeout) return QC_ERR_HIP;    // an earlier build's join gave up: its result was not complete
+        // launches of a set of streams, interleaved (first launch of every stream of the set before any second one), then the
+        // streams' markers of the device-side join
+        auto issue = [&](const int *set, int nset) -> int {
+            size_t longest = 0;
+            for (int i = 0; i < nset; ++i) longest = std::max(longest, q[set[i]].size());
+            for (size_t pos = 0; pos < longest; ++pos)
+                for (int i = 0; i < nset; ++i) {
+                    const int k = set[i];
+                    if (pos >= q[k].size()) continue;
+                    const int u = q[k][pos];
+                    hipStream_t st = k == kmain ? S->stream : S->side[k];
+                    if (pos == 0 && k != kmain && fork) QC_HIP_CHECK(hipStreamWaitEvent(st, S->ev_fork, 0));
+                    if (ev && per_unit) QC_HIP_CHECK(hipEventRecord(ev[2 + 2 * u], st));
+                    int rc = launch_segments(S, u, segs_of(units[u]), st, a);
+                    if (rc != QC_OK) return rc;
+                    if (ev && per_unit) QC_HIP_CHECK(hipEventRecord(ev[3 + 2 * u], st));
+                }
+            if (!event_join) {
+                for (int i = 0; i < nset; ++i)
+                    if (set[i] != kmain && !q[set[i]].empty()) hipLaunchKernelGGL(qc_join_mark_kernel, dim3(1), dim3(64), 0, S->side[set[i]], S->d_join);
+                if (hipGetLastError() != hipSuccess) return QC_ERR_HIP;
+            }
+            return QC_OK;
+        };
+        int nused = 0;
+        unsigned nside = 0;
+        for (int k = 0; k < QC_NSTREAMS; ++k) if (!q[k].empty()) { ++nused; if (k != kmain) ++nside; }
+        // Measured (alternating runs on one box, means of six / two): H2O/cc-pVTZ builds 0.227 ms with three helpers against 0.204 ms
+        // issued by the caller alone - its 13 launches of 30-70 us each do better when they start 6-7 us apart than all at once -
+        // benzene/cc-pVDZ 1.470 against 1.494 ms.  So the helpers are for builds whose launches are long against the issue time.
+        static const int nhelp_env = getenv("QC_ISSUE_THREADS") ? atoi(getenv("QC_ISSUE_THREADS")) : -1;    // (0: never; n: always n helpers)
+        float serial_ms = 0.f;
+        for (float x : S->unit_ms) serial_ms += x;
+        const int nhelp_want = nhelp_env >= 0 ? nhelp_env : (serial_ms > 1.0f ? 3 : 0);
+        const int nhelp = (event_join || (ev && per_unit) || nused < 3) ? 0 : std::min(nhelp_want, nused - 1);
+        if (nhelp <= 0) {
+            int used_set[QC_NSTREAMS], n = 0;
+            for (int k : ks) if (!q[k].empty()) used_set[n++] = k;
+            int rc = issue(used_set, n);
+            if (rc != QC_OK) return rc;
+        } else {
+            if (!S->issue_pool || (int)S->issue_pool->w.size() < nhelp) { delete S->issue_pool; S->issue_pool = new QcIssuePool(std::max(nhelp, nhelp_want), S->device); }
+            QcIssuePool &P = *S->issue_pool;
+            ++P.gen;
+            int sets[QC_NSTREAMS][QC_NSTREAMS], nset[QC_NSTREAMS] = {};
+            {   // side streams in the order of their load, dealt round the helpers
+                int h = 0;
+                for (int k : ks) if (k != kmain && !q[k].empty()) { sets[h][nset[h]++] = k; h = (h + 1) % nhelp; }
+            }
+            for (int h = 0; h < nhelp; ++h) P.start(h, [&, h]() -> int { return issue(sets[h], nset[h]); });
+            int rc = issue(&kmain, 1);
+            for (int h = 0; h < nhelp; ++h) { const int r = P.wait(h); if (rc == QC_OK) rc = r; }       // (every helper is waited for, whatever happened)
+            if (rc != QC_OK) {
+                // some markers of this build may be out, others not: the counter and the host's target meet again before anything else waits
+                unsigned c = 0;
+                if (hipDeviceSynchronize() == hipSuccess && hipMemcpy(&c, S->d_join, sizeof(c), hipMemcpyDeviceToHost) == hipSuccess) S->join_target = c;
+                return rc;
+            }
+        }
         if (event_join) {
             for (int k = 0; k < QC_NSTREAMS; ++k) {
-                if (!used[k] || k == kmain) continue;
+                if (q[k].empty() || k == kmain) continue;
                 QC_HIP_CHECK(hipEventRecord(S->ev_join[k], S->side[k]));
                 QC_HIP_CHECK(hipStreamWaitEvent(S->stream, S->ev_join[k], 0));
             }
-        } else {
-            if (*S->h_join_timeout) return QC_ERR_HIP;              // an earlier build's join gave up: its result was not complete
-            unsigned nside = 0;
-            for (int k = 0; k < QC_NSTREAMS; ++k) {
-                if (!used[k] || k == kmain) continue;
-                hipLaunchKernelGGL(qc_join_mark_kernel, dim3(1), dim3(64), 0, S->side[k], S->d_join);
-                ++nside;
-            }
-            if (nside) {
-                S->join_target += nside;
-                hipLaunchKernelGGL(qc_join_wait_kernel, dim3(1), dim3(64), 0, S->stream, S->d_join, S->join_target, S->h_join_timeout);
-            }
+        } else if (nside) {
+            S->join_target += nside;
+            hipLaunchKernelGGL(qc_join_wait_kernel, dim3(1), dim3(64), 0, S->stream, S->d_join, S->join_target, S->h_join_timeout);
             if (hipGetLastError() != hipSuccess) return QC_ERR_HIP;
         }
         if (ev) QC_HIP_CHECK(hipEventRecord(ev[1], S->stream));

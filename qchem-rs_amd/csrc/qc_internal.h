@@ -165,6 +165,7 @@ struct qc_system {
     unsigned *d_join = nullptr;              // counter of the device-side join of a build's side streams (qc_join_mark / qc_join_wait)
     int *h_join_timeout = nullptr;           // pinned: set by a join that gave up (a side stream's launches never finished)
     unsigned join_target = 0;
+    struct QcIssuePool *issue_pool = nullptr; // helper threads that issue a build's launches next to the caller (qc_fock.hip)
     void *comm = nullptr;                    // ncclComm_t
     std::vector<float> unit_ms;              // measured serial time of each launch unit (autotuned once per shard)
     std::vector<int> unit_stream;            // side stream of each launch unit (longest-processing-time assignment)
@@ -331,6 +332,7 @@ struct QcSmallArgs {
     double *scal_out;              // [0] 0.5 tr(Dn (2H + G)), [1] sum_i (Dn - Dold)_ii^2
     double *fxs_out; double imax;  // non-null (RHF): the fixed-point unit of the build that will digest Dn goes here (qc_fx_scale)
     int *ctl_all, *ctl_out;        // non-null: hand the 16 control words over to ctl_out and clear them
+    unsigned *seq_out; unsigned seq; // non-null (pinned host memory): the pass's sequence number, stored after everything else the host reads
 };
 int qc_scf_small_launch(hipStream_t st, const QcSmallArgs &a);
 size_t qc_scf_small_lds_bytes(int n);

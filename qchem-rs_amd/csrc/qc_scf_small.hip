@@ -574,6 +574,10 @@ __global__ __launch_bounds__(QCS_T) void qc_scf_small_kernel(const QcSmallArgs a
         }
     }
     __threadfence_system();
+    if (a.seq_out) {     // the host polls this word instead of the stream's event (which the packet processor signals some microseconds later)
+        __syncthreads();
+        if (tid == 0) __hip_atomic_store(a.seq_out, a.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
 #ifdef QC_SMALL_TIMING
     if (tid == 0) {
         printf("[small n=%d phases %d m %d] stamps (10 ns):", n, a.phases, a.m);
