@@ -204,9 +204,12 @@ int qc_fock_profile(qc_system *sys, const double *dD, double *dG, int reps, floa
 
 /* Same for the launch units of an un-instrumented build.  Units 0..13: kernel qc_fock_tier_kernel<LAB, TIER> gathers every
  * class bucket of bra class LAB with LCD <= 3 (TIER 0) or LCD >= 4 (TIER 1), unit = 2 * LAB + TIER.  Units 14..17: the
- * bra-major kernels qc_fock_bm_kernel<LCD, HI> (ket pair ss / ps, bra class LAB <= 2 / LAB >= 3), unit = 14 + 2 * LCD + HI.
+ * bra-major kernels qc_fock_bm_kernel<LCD, HI> (ket pair ss / ps, bra class LAB <= 2 / LAB >= 3), unit = 14 + 2 * LCD + HI; unit 18:
+ * qc_fock_bm_kernel<2, 0>, p.p kets against p.p / d.s bras.
  * All arrays: QC_PROFILE_UNITS entries. */
-#define QC_PROFILE_UNITS 18
+#define QC_PROFILE_UNITS 20
+/* Shell quartets of this rank's shard per launch unit (QC_PROFILE_UNITS entries; no device work). */
+int qc_unit_quartets(qc_system *sys, int64_t *unit_quartets);
 int qc_fock_profile_tiers(qc_system *sys, const double *dD, double *dG, int reps, float *unit_ms, int64_t *unit_quartets,
                           double *unit_bytes, double *unit_flops, float *total_ms);
 

@@ -1141,6 +1141,13 @@ int qc_fock_profile(qc_system *S, const double *dD, double *dG, int reps, float 
     return QC_OK;
 }
 
+int qc_unit_quartets(qc_system *S, int64_t *unit_quartets) {
+    if (!S || !unit_quartets) return QC_ERR_INVALID;
+    for (int u = 0; u < QC_NUNITS; ++u) unit_quartets[u] = 0;
+    for (const auto &c : S->classes) unit_quartets[qc_unit_of(c.LAB, c.LCD, c.bm)] += (int64_t)c.shard.size();
+    return QC_OK;
+}
+
 // Per launch unit ("tier" = (LAB, LCD <= 3 | LCD >= 4), the kernels an un-instrumented build really launches), timed
 // serially with hipEvents on the handle's stream.  Arrays have 14 entries, unit u = 2 * LAB + tier; empty units are 0.
 int qc_fock_profile_tiers(qc_system *S, const double *dD, double *dG, int reps, float *unit_ms, int64_t *unit_quartets,

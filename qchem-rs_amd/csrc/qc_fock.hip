@@ -59,16 +59,18 @@ static void qc_bm_device_lists(const qc_system *S, int lcd, const std::vector<Qc
     for (size_t i = 0; i < bundles.size(); ++i) {
         const QcBundle &b = bundles[i];
         const QcPairDesc &p = S->pairs[b.bra];
-        db[i] = QcBundleDev{b.bra, b.ij_lo, b.ij_hi, b.first, b.nket, b.maxK, p.doff, p.offa, p.offb, p.na | (p.nb << 8) | ((p.shA_eq_shB ? 1 : 0) << 16), 0, 0};
+        db[i] = QcBundleDev{b.bra, b.ij_lo, b.ij_hi, b.first, b.nket, b.maxK, p.doff, p.offa, p.offb, p.na | (p.nb << 8) | ((p.shA_eq_shB ? 1 : 0) << 16), b.pad0, 0};
     }
     for (size_t i = 0; i < ketlist.size(); ++i) {
         const unsigned e = (unsigned)ketlist[i];
         const int ket = (int)(e & 0x3ffffu), kl0 = (int)((e >> 18) & 0x7fu), klen = (int)(e >> 25);
         const QcPairDesc &p = S->pairs[ket];
-        const int stride = lcd == 0 ? qc_pair_stride(0, 1) : 8;
+        const int stride = lcd == 0 ? qc_pair_stride(0, 1) : (lcd == 1 ? 8 : 16);
         const int K = klen ? klen : p.K;
+        // (p.p kets: the columns of a lane are the functions of the SECOND shell - bits 18..23 carry its axis permutation, 24..29 the first shell's)
+        const int perm_bits = lcd == 2 ? ((((p.psperm >> 6) & 63) << 18) | ((p.psperm & 63) << 24)) : ((p.psperm & 63) << 18);
         du[i] = QcKetUnit{ket, (lcd == 0 ? p.doff : p.psoff) + kl0 * stride, p.offa | (p.offb << 16),
-                          (K & 0xffff) | ((p.nb == 1 ? 1 : 0) << 16) | ((p.shA_eq_shB ? 1 : 0) << 17) | ((p.psperm & 63) << 18)};
+                          (K & 0xffff) | ((lcd == 1 && p.nb == 1 ? 1 : 0) << 16) | ((p.shA_eq_shB ? 1 : 0) << 17) | perm_bits};
     }
 }
 
@@ -850,6 +852,18 @@ int qc_schwarz_device(qc_system *S) {
         diag.clear();
         for (const auto &t : c.tasks) if (t.bra == t.ket) diag.push_back(t);
         if (diag.empty()) continue;
+        if (c.bm && c.LCD == 2) {   // p.p-ket bra-major class: the column kernels have the Schwarz mode
+            QcClass cc;
+            cc.LAB = c.LAB; cc.LCD = c.LCD; cc.LGC = c.col_lgc; cc.slot_words = c.col_slot_words; cc.lds_bytes = c.col_lds_bytes;
+            qc_make_slots(S, diag, 0, false, slots);
+            QcTmpDev<QcSlot> d;
+            QC_HIP_CHECK(d.alloc(slots.size()));
+            QC_HIP_CHECK(hipMemcpyAsync(d.p, slots.data(), slots.size() * sizeof(QcSlot), hipMemcpyHostToDevice, S->stream));
+            int rc = launch_segments(S, qc_unit_of(cc.LAB, cc.LCD, false), {Seg{&cc, d.p, (int)slots.size()}}, S->stream, a);
+            QC_HIP_CHECK(hipStreamSynchronize(S->stream));
+            if (rc != QC_OK) return rc;
+            continue;
+        }
         if (c.bm) {
             qc_make_bundles(S, diag, 0, bundles, ketlist);
             QcTmpDev<QcBundleDev> db; QcTmpDev<QcKetUnit> dk;
@@ -889,6 +903,19 @@ int qc_launch_eri_full(qc_system *S, double *d_out) {
     std::vector<QcSlot> slots;
     std::vector<QcBundle> bundles; std::vector<int> ketlist;
     for (const auto &c : S->classes) {
+        if (c.bm && c.LCD == 2) {   // p.p-ket bra-major class: the column kernels have the tensor mode
+            QcClass cc;
+            cc.LAB = c.LAB; cc.LCD = c.LCD; cc.LGC = c.col_lgc; cc.slot_words = c.col_slot_words; cc.lds_bytes = c.col_lds_bytes;
+            qc_make_slots(S, c.tasks, 0, false, slots);
+            if (slots.empty()) continue;
+            QcTmpDev<QcSlot> d;
+            QC_HIP_CHECK(d.alloc(slots.size()));
+            QC_HIP_CHECK(hipMemcpyAsync(d.p, slots.data(), slots.size() * sizeof(QcSlot), hipMemcpyHostToDevice, S->stream));
+            int rc = launch_segments(S, qc_unit_of(cc.LAB, cc.LCD, false), {Seg{&cc, d.p, (int)slots.size()}}, S->stream, a);
+            QC_HIP_CHECK(hipStreamSynchronize(S->stream));
+            if (rc != QC_OK) return rc;
+            continue;
+        }
         if (c.bm) {
             qc_make_bundles(S, c.tasks, 0, bundles, ketlist);
             if (bundles.empty()) continue;

@@ -103,6 +103,24 @@ __device__ __forceinline__ void qc_step2_ps(double (&W)[3][qc_nherm(LAB)], const
     }
 }
 
+// Step 2 against a p.p ket in packed form (round 3), for the wave's Cartesian axis CAX of the ket's FIRST function: column d is the axis d of
+// the second function, and its expansion has four terms - on the s-type Hermite function, on the first-order functions of the axes CAX
+// and d, and on the second-order function of CAX + d (qc_system.cpp, packed record): 4 FMAs per (column, bra Hermite index) where the
+// dense 10 x 9 block would take 10.  c0[d] = A_c D_d + [c = d] kh, cc[d] = -kh D_d, cd = -hq A_c, ccd = khh (signs: odd ket orders).
+template <int LAB, int CAX>
+__device__ __forceinline__ void qc_step2_pp(double (&W)[3][qc_nherm(LAB)], const double (&c0)[3], const double (&cc)[3], const double cd, const double ccd,
+                                            const double (&R)[qc_nherm(LAB + 2)]) {
+    constexpr QcTuvTable T = qc_make_tuv();
+#pragma unroll
+    for (int h = 0; h < qc_nherm(LAB); ++h) {
+        const int t = T.t[h] + (CAX == 0), u = T.u[h] + (CAX == 1), v = T.v[h] + (CAX == 2);     // h + e_c
+        const double r0 = R[h], rc = R[qc_hidx(t, u, v)];
+        W[0][h] = fma(ccd, R[qc_hidx(t + 1, u, v)], fma(cd, R[qc_hidx(T.t[h] + 1, T.u[h], T.v[h])], fma(cc[0], rc, fma(c0[0], r0, W[0][h]))));
+        W[1][h] = fma(ccd, R[qc_hidx(t, u + 1, v)], fma(cd, R[qc_hidx(T.t[h], T.u[h] + 1, T.v[h])], fma(cc[1], rc, fma(c0[1], r0, W[1][h]))));
+        W[2][h] = fma(ccd, R[qc_hidx(t, u, v + 1)], fma(cd, R[qc_hidx(T.t[h], T.u[h], T.v[h] + 1)], fma(cc[2], rc, fma(c0[2], r0, W[2][h]))));
+    }
+}
+
 // One pass over the ket primitives for NIJ consecutive bra primitive pairs (NIJ = 2 shares every ket load between two
 // primitive quartets), followed by step 3 with the wave-uniform bra blocks.
 // Latencies a pass used to expose, and what hides them now (round 3; with ket chunks of <= 8 primitives a pass is only ~16 primitive
@@ -110,13 +128,13 @@ __device__ __forceinline__ void qc_step2_ps(double (&W)[3][qc_nherm(LAB)], const
 // primitive loop (`hd` carries them from pass to pass); the first ket record is loaded once per bundle (`hk0`, `ek0`); the rows of
 // step 3 come in pieces of QC_BM_PIECE scalars, each requested while the previous one is being used.
 constexpr int QC_BM_PIECE = 10;
-template <int LAB, int LCD, int NIJ>
+template <int LAB, int LCD, int NIJ, int CAX = 0>
 __device__ __forceinline__ void qc_bm_pass(const double *__restrict__ pd, const double *__restrict__ pdT, const double *__restrict__ Tb,
                                            const int bdoff, const int strideB, const int ij, const int ij_last, const int nab,
-                                           const double *__restrict__ ketBase, const double4 hk0, const double4 ek0,
+                                           const double *__restrict__ ketBase, const double4 hk0, const double4 ek0, const double4 ek0b, const double4 ek0c,
                                            const int K_cd, const int Kc1, const int maxK, double *const I, double (&hd)[2][4] QC_BT_ARGS) {
     constexpr int L = LAB + LCD, HAB = qc_nherm(LAB), NC = (LCD == 0) ? 1 : 3;
-    constexpr int strideK = (LCD == 0) ? qc_pair_stride(0, 1) : 8;
+    constexpr int strideK = (LCD == 0) ? qc_pair_stride(0, 1) : (LCD == 1 ? 8 : 16);
     constexpr int LS = 65;
     double p[NIJ], Px[NIJ], Py[NIJ], Pz[NIJ];
 #pragma unroll
@@ -153,18 +171,19 @@ __device__ __forceinline__ void qc_bm_pass(const double *__restrict__ pd, const 
     // the next ket primitive's record is requested one iteration ahead.  ss kets: pair-data block [q, Q | E]; ps kets:
     // packed record [q, Q | e0x, e0y, e0z, e1] (ketBase points into pspack, stride 8)
     double4 hk = hk0;
-    double4 ekn4 = ek0;
+    double4 ekn4 = ek0, ekn4b = ek0b, ekn4c = ek0c;
     double ekn = ek0.x;
     for (int kl = 0; kl < maxK; ++kl) {
         const bool valid = kl < K_cd;
         const double4 ck = hk;
         const double ek = ekn;
-        const double4 ek4 = ekn4;
+        const double4 ek4 = ekn4, ek4b = ekn4b, ek4c = ekn4c;
         {
             const double *__restrict__ kbn = ketBase + (size_t)min(kl + 1, Kc1) * strideK;
             hk = *reinterpret_cast<const double4 *>(kbn);
             if constexpr (LCD == 0) ekn = kbn[4];
             else ekn4 = *reinterpret_cast<const double4 *>(kbn + 4);
+            if constexpr (LCD == 2) { ekn4b = *reinterpret_cast<const double4 *>(kbn + 8); ekn4c = *reinterpret_cast<const double4 *>(kbn + 12); }
         }
         const double q = ck.x;
 #pragma unroll
@@ -180,9 +199,16 @@ __device__ __forceinline__ void qc_bm_pass(const double *__restrict__ pd, const 
                 const double e = ek * sc;               // ss ket: a single Hermite function, W[h] += e R_h
 #pragma unroll
                 for (int h = 0; h < qc_nherm(LAB); ++h) W[u][0][h] = fma(e, Rr[h], W[u][0][h]);
-            } else {
+            } else if constexpr (LCD == 1) {
                 const double e0[3] = {ek4.x * sc, ek4.y * sc, ek4.z * sc};
                 qc_step2_ps<LAB>(W[u], e0, -(ek4.w * sc), Rr);
+            } else {
+                // packed p.p record: ek4 = (A_x, A_y, A_z, kh), ek4b = (D_x, D_y, D_z, khh), ek4c = (hq A_x, hq A_y, hq A_z, -)
+                const double Ac = (CAX == 0 ? ek4.x : (CAX == 1 ? ek4.y : ek4.z)) * sc, hAc = (CAX == 0 ? ek4c.x : (CAX == 1 ? ek4c.y : ek4c.z)) * sc;
+                const double kh = ek4.w * sc;
+                const double c0[3] = {fma(Ac, ek4b.x, CAX == 0 ? kh : 0.0), fma(Ac, ek4b.y, CAX == 1 ? kh : 0.0), fma(Ac, ek4b.z, CAX == 2 ? kh : 0.0)};
+                const double cc[3] = {-(kh * ek4b.x), -(kh * ek4b.y), -(kh * ek4b.z)};
+                qc_step2_pp<LAB, CAX>(W[u], c0, cc, -hAc, ek4b.w * sc, Rr);
             }
         }
     }
@@ -274,11 +300,11 @@ __device__ __forceinline__ void qc_bm_pass(const double *__restrict__ pd, const 
 // one is being digested (qc_bm_segment).
 typedef int qc_v4i __attribute__((ext_vector_type(4)));
 typedef const __attribute__((address_space(4))) qc_v4i qc_cv4i;
-struct QcBmBundleRegs { int bra, ij_lo, ij_hi, first, nket, maxK, bdoff, offa, offb, na, nb, eq; };   // wave-uniform
+struct QcBmBundleRegs { int bra, ij_lo, ij_hi, first, nket, maxK, bdoff, offa, offb, na, nb, eq, cax; };   // wave-uniform (cax: p.p kets, axis of the first function)
 __device__ __forceinline__ QcBmBundleRegs qc_bm_load_bundle(const QcBundleDev *bundles, const int b) {
     const qc_cv4i *bp = (const qc_cv4i *)(bundles + b);
     const qc_v4i x = bp[0], y = bp[1], z = bp[2];
-    return QcBmBundleRegs{x.x, x.y, x.z, x.w, y.x, y.y, y.z, y.w, z.x, z.y & 0xff, (z.y >> 8) & 0xff, (z.y >> 16) & 1};
+    return QcBmBundleRegs{x.x, x.y, x.z, x.w, y.x, y.y, y.z, y.w, z.x, z.y & 0xff, (z.y >> 8) & 0xff, (z.y >> 16) & 1, z.z};
 }
 
 template <int LAB, int LCD>
@@ -306,7 +332,8 @@ __device__ __forceinline__ void qc_bm_body(const QcKernelArgs &a, const double *
     const bool nd1 = (ue.info >> 16) & 1;                      // (nc, nd) = (1,1), (3,1) [nd1] or (1,3)
     const bool keq = (ue.info >> 17) & 1;
     const int psperm = (ue.info >> 18) & 63;
-    const int c0 = ue.cd & 0xffff, d0 = (int)((unsigned)ue.cd >> 16);
+    // (p.p kets: the lane's three columns share the function of the wave's axis in the first shell - it moves into the column base)
+    const int c0 = (ue.cd & 0xffff) + (LCD == 2 ? ((ue.info >> (24 + 2 * bd.cax)) & 3) : 0), d0 = (int)((unsigned)ue.cd >> 16);
     const double *__restrict__ ketBase = ((LCD == 0) ? pd : pspack) + ue.koff;
     double *const I = Iw + lane;                              // I[x * LS], x = ab * NC + col
 
@@ -314,7 +341,9 @@ __device__ __forceinline__ void qc_bm_body(const QcKernelArgs &a, const double *
 
     // first ket record of the lane's chunk (the same for every pass) and the headers of the first two bra primitive pairs
     const double4 hk0 = *reinterpret_cast<const double4 *>(ketBase);
-    const double4 ek0 = (LCD == 1) ? *reinterpret_cast<const double4 *>(ketBase + 4) : double4{ketBase[4], 0.0, 0.0, 0.0};
+    const double4 ek0 = (LCD >= 1) ? *reinterpret_cast<const double4 *>(ketBase + 4) : double4{ketBase[4], 0.0, 0.0, 0.0};
+    const double4 ek0b = (LCD == 2) ? *reinterpret_cast<const double4 *>(ketBase + 8) : double4{0.0, 0.0, 0.0, 0.0};
+    const double4 ek0c = (LCD == 2) ? *reinterpret_cast<const double4 *>(ketBase + 12) : double4{0.0, 0.0, 0.0, 0.0};
     double hd[2][4];
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
@@ -323,9 +352,16 @@ __device__ __forceinline__ void qc_bm_body(const QcKernelArgs &a, const double *
     }
     QC_BT(0);
     int ij = ij_lo;
+    if constexpr (LCD == 2) {
+        // (the axis is wave-uniform: one of three instances of the pass)
+        if (bd.cax == 0) for (; ij < ij_hi; ++ij) qc_bm_pass<LAB, LCD, 1, 0>(pd, pdT, Tb, bdoff, strideB, ij, ij_hi - 1, nab, ketBase, hk0, ek0, ek0b, ek0c, K_cd, Kc1, maxK, I, hd QC_BT_PASS);
+        else if (bd.cax == 1) for (; ij < ij_hi; ++ij) qc_bm_pass<LAB, LCD, 1, 1>(pd, pdT, Tb, bdoff, strideB, ij, ij_hi - 1, nab, ketBase, hk0, ek0, ek0b, ek0c, K_cd, Kc1, maxK, I, hd QC_BT_PASS);
+        else for (; ij < ij_hi; ++ij) qc_bm_pass<LAB, LCD, 1, 2>(pd, pdT, Tb, bdoff, strideB, ij, ij_hi - 1, nab, ketBase, hk0, ek0, ek0b, ek0c, K_cd, Kc1, maxK, I, hd QC_BT_PASS);
+    } else {
     if constexpr (PAIRED)
-        for (; ij + 1 < ij_hi; ij += 2) qc_bm_pass<LAB, LCD, 2>(pd, pdT, Tb, bdoff, strideB, ij, ij_hi - 1, nab, ketBase, hk0, ek0, K_cd, Kc1, maxK, I, hd QC_BT_PASS);
-    for (; ij < ij_hi; ++ij) qc_bm_pass<LAB, LCD, 1>(pd, pdT, Tb, bdoff, strideB, ij, ij_hi - 1, nab, ketBase, hk0, ek0, K_cd, Kc1, maxK, I, hd QC_BT_PASS);
+        for (; ij + 1 < ij_hi; ij += 2) qc_bm_pass<LAB, LCD, 2>(pd, pdT, Tb, bdoff, strideB, ij, ij_hi - 1, nab, ketBase, hk0, ek0, ek0b, ek0c, K_cd, Kc1, maxK, I, hd QC_BT_PASS);
+    for (; ij < ij_hi; ++ij) qc_bm_pass<LAB, LCD, 1>(pd, pdT, Tb, bdoff, strideB, ij, ij_hi - 1, nab, ketBase, hk0, ek0, ek0b, ek0c, K_cd, Kc1, maxK, I, hd QC_BT_PASS);
+    }
 
     if (a.schwarz_out != nullptr) {
         // Schwarz factors: the bundles are (P|P) quartets, one ket per bundle; the largest element of the block is on its diagonal
@@ -586,6 +622,7 @@ __global__ __launch_bounds__(qc_bm_waves(LCD, HI) * 64) void qc_fock_bm_kernel(c
     if constexpr (LCD == 0 && HI == 1) { switch (a.seg_lab[s]) { QC_BM_CASE(3) QC_BM_CASE(4) default: break; } }
     if constexpr (LCD == 1 && HI == 0) { switch (a.seg_lab[s]) { QC_BM_CASE(1) QC_BM_CASE(2) default: break; } }
     if constexpr (LCD == 1 && HI == 1) { switch (a.seg_lab[s]) { QC_BM_CASE(3) default: break; } }
+    if constexpr (LCD == 2 && HI == 0) { switch (a.seg_lab[s]) { QC_BM_CASE(2) default: break; } }
 #undef QC_BM_CASE
 }
 
@@ -603,6 +640,7 @@ static int launch_bm(int grid, int nwaves, size_t lds, hipStream_t st, const QcB
 }
 
 int qc_launch_bm(int lcd, int hi, int grid, int nwaves, size_t lds, hipStream_t st, const QcBmArgs &a) {
+    if (lcd == 2) return hi ? QC_ERR_UNSUPPORTED : launch_bm<2, 0>(grid, nwaves, lds, st, a);
     if (lcd == 0) return hi ? launch_bm<0, 1>(grid, nwaves, lds, st, a) : launch_bm<0, 0>(grid, nwaves, lds, st, a);
     return hi ? launch_bm<1, 1>(grid, nwaves, lds, st, a) : launch_bm<1, 0>(grid, nwaves, lds, st, a);
 }

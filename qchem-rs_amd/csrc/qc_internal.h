@@ -36,7 +36,7 @@ constexpr int QC_TUNE_LOCAL = 128;        // local-search steps (move / swap of 
 #define QC_NSTREAMS_N 7
 #endif
 constexpr int QC_NSTREAMS = QC_NSTREAMS_N;  // class kernels of one build run concurrently on this many streams (compile-time: A/B builds)
-constexpr int QC_NUNITS = 2 * (QC_LPAIR + 1) + 4;   // launch units of one build: (LAB, tier) of the column kernels + 4 bra-major launches
+constexpr int QC_NUNITS = 2 * (QC_LPAIR + 1) + 6;   // launch units of one build: (LAB, tier) of the column kernels + the bra-major launches (ket ss / ps / pp x bra range)
 
 __host__ __device__ constexpr int qc_nherm(int L) { return (L + 1) * (L + 2) * (L + 3) / 6; }
 // Classes whose two Hermite contractions run as f64 MFMA tiles (one slot per wave): high-order kets against bras with
@@ -81,8 +81,8 @@ struct QcPairDesc {
     int offa, offb;
     int L;        // la + lb
     int shA_eq_shB;
-    int psoff;    // ps pairs: offset (doubles) of the packed primitive records in the pspack array, else -1
-    int psperm;   // ps pairs: basis function of Cartesian axis a = (psperm >> 2a) & 3
+    int psoff;    // ps and pp pairs: offset (doubles) of the packed primitive records in the pspack array, else -1
+    int psperm;   // ps pairs: basis function of Cartesian axis a = (psperm >> 2a) & 3; pp pairs: the same for shell A, and for shell B from bit 6
 };
 
 struct QcTask { int bra, ket; };  // pair indices; (bra|ket) is one unique shell quartet
@@ -109,6 +109,7 @@ struct QcClass {
     QcSlot *d_slots = nullptr;    // device copy of `slots`
     int slot_words = 0;           // LDS doubles per lane group
     int lds_bytes = 0;
+    int col_slot_words = 0, col_lds_bytes = 0, col_lgc = 0;   // the same for the column kernels (a pp-ket bra-major class goes through them in the set-up passes)
     // bra-run mode of the low-L column classes (qc_fock_body): slots grouped by bra, batches of G padded with null slots
     int run = 0;                  // batches per workgroup (0: independent slots)
     int rb_rows = 0;              // most bra functions (na + nb) of the class: rows of the LDS row buffer
@@ -197,6 +198,7 @@ struct qc_system {
     bool zombie = false;                     // qc_system_destroy was called while states were alive: the last qc_scf_end frees the handle
     int fock_mode = 0;                       // 0 direct (default), 1 stored tensor (the reference's own algorithm)
     int accum_fx = 1;                        // 1 (default): fixed-point, order-independent accumulation of G; 0: f64 atomics
+    bool pp_ok = true;                        // every p.p pair's expansion blocks have the packed form the pp-ket bra-major kernel assumes
     std::string last_error;
 };
 

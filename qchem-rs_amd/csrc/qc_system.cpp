@@ -189,6 +189,7 @@ void qc_build_model(qc_system *S) {
     // The pair part of the ERI prefactor 2 pi^{5/2} / (p q sqrt(p+q)) is folded in as sqrt(2) pi^{5/4} / p.
     const double half_pref = std::sqrt(2.0) * std::pow(M_PI, 1.25);
     S->pairs.clear(); S->pairA.clear(); S->pairB.clear(); S->pairKfull.clear(); S->pairdata.clear(); S->pairdataT.clear(); S->pspack.clear();
+    S->pp_ok = true;
     // Primitive pairs whose whole expansion block is below QC_PRIM_CUTOFF are not stored: with the Gaussian-product
     // factor exp(-mu R^2) and the coefficients folded into E, an integral is bounded by max|E_ab| max|E_cd| (times
     // O(10)), so a dropped primitive pair changes no integral by more than ~1e-16 - five orders below the 1e-10 parity
@@ -206,7 +207,25 @@ void qc_build_model(qc_system *S) {
             d.na = A.nfunc; d.nb = B.nfunc; d.offa = A.off; d.offb = B.off; d.L = A.L + B.L; d.shA_eq_shB = (a == b);
             d.psoff = -1; d.psperm = 0;
             const bool is_ps = (d.L == 1);
-            if (is_ps) d.psoff = (int)S->pspack.size();
+            const bool is_pp = (A.L == 1 && B.L == 1);
+            if (is_ps || is_pp) d.psoff = (int)S->pspack.size();
+            int ppermA = 0, ppermB = 0;                    // pp pairs: basis function of Cartesian axis x: (perm >> 2x) & 3, per shell
+            if (is_pp) {
+                auto axis_perm = [&](const QcShell &sh, int &perm) {
+                    bool ok = sh.nfunc == 3 && sh.ncart == 3;
+                    perm = 0;
+                    int seen = 0;
+                    for (int ax = 0; ax < 3 && ok; ++ax) {
+                        int f = 0;
+                        for (int g = 1; g < 3; ++g) if (std::fabs(sh.T[(size_t)g * 3 + ax]) > std::fabs(sh.T[(size_t)f * 3 + ax])) f = g;
+                        for (int g = 0; g < 3; ++g) if (g != f && sh.T[(size_t)g * 3 + ax] != 0.0) ok = false;
+                        perm |= f << (2 * ax); seen |= 1 << f;
+                    }
+                    return ok && seen == 7;
+                };
+                if (!axis_perm(A, ppermA) || !axis_perm(B, ppermB)) S->pp_ok = false;
+                d.psperm = ppermA | (ppermB << 6);
+            }
             const int nab = d.na * d.nb, stride = qc_pair_stride(d.L, nab), ne = qc_nherm(d.L) * nab;
             blkbuf.assign(stride, 0.0);
             for (int i = 0; i < A.nprim; ++i)
@@ -244,6 +263,40 @@ void qc_build_model(qc_system *S) {
                         const double rec[8] = {p, P[0], P[1], P[2], e0[0], e0[1], e0[2], e1};
                         S->pspack.insert(S->pspack.end(), rec, rec + 8);
                     }
+                    if (is_pp && S->pp_ok) {
+                        // Packed record of a p.p primitive pair (ket side of qc_fock_bm_kernel<2, 0>), 16 doubles:
+                        //   [q, Q | A_x, A_y, A_z, kh | D_x, D_y, D_z, khh | hA_x, hA_y, hA_z, 0],  A = K (Q - C), D = Q - D', hq = 1/(2q), kh = K hq,
+                        //   khh = K hq^2, hA = hq A:  the expansion of the function pair (axis c of the first shell, axis d of the second) is
+                        //   E_000 = A_c D_d + [c = d] kh,  E_{e_c} = kh D_d,  E_{e_d} = hA_c,  E_{e_c + e_d} = khh - everything else is zero.
+                        // K is read off the block (second-order coefficient of the x.x pair), and the whole block is checked against the form.
+                        const double hq = 0.5 / p;
+                        const double PC[3] = {P[0] - A.A[0], P[1] - A.A[1], P[2] - A.A[2]}, PD[3] = {P[0] - B.A[0], P[1] - B.A[1], P[2] - B.A[2]};
+                        auto fn = [&](int perm, int ax) { return (perm >> (2 * ax)) & 3; };
+                        auto Eb = [&](int t, int u, int v, int c, int dd) { return blkbuf[4 + (size_t)qc_hidx(t, u, v) * nab + fn(ppermA, c) * 3 + fn(ppermB, dd)]; };
+                        const double Kc = Eb(2, 0, 0, 0, 0) / (hq * hq);
+                        const double kh = Kc * hq, khh = Kc * hq * hq;
+                        double worst = 0.0, scale_e = 0.0;
+                        for (int c = 0; c < 3; ++c)
+                            for (int dd = 0; dd < 3; ++dd)
+                                for (int t = 0; t <= 2; ++t)
+                                    for (int u = 0; t + u <= 2; ++u)
+                                        for (int v = 0; t + u + v <= 2; ++v) {
+                                            const int tv[3] = {t, u, v};
+                                            int ec[3] = {0, 0, 0}, ed[3] = {0, 0, 0}, ecd[3] = {0, 0, 0};
+                                            ec[c] = 1; ed[dd] = 1; ecd[c] += 1; ecd[dd] += 1;
+                                            auto is = [&](const int *e) { return tv[0] == e[0] && tv[1] == e[1] && tv[2] == e[2]; };
+                                            double want = 0.0;
+                                            if (t + u + v == 0) want = Kc * PC[c] * PD[dd] + (c == dd ? kh : 0.0);
+                                            else if (t + u + v == 1) want = (is(ec) ? kh * PD[dd] : 0.0) + (is(ed) ? kh * PC[c] : 0.0);
+                                            else if (is(ecd)) want = khh;
+                                            worst = std::max(worst, std::fabs(want - Eb(t, u, v, c, dd)));
+                                            scale_e = std::max(scale_e, std::fabs(want));
+                                        }
+                        if (!(worst <= 1e-12 * std::max(scale_e, 1e-300))) S->pp_ok = false;
+                        const double rec[16] = {p, P[0], P[1], P[2], Kc * PC[0], Kc * PC[1], Kc * PC[2], kh, PD[0], PD[1], PD[2], khh,
+                                                hq * Kc * PC[0], hq * Kc * PC[1], hq * Kc * PC[2], 0.0};
+                        S->pspack.insert(S->pspack.end(), rec, rec + 16);
+                    }
                     const size_t t0 = S->pairdataT.size();
                     S->pairdataT.insert(S->pairdataT.end(), blkbuf.begin(), blkbuf.end());
                     for (int h = 0; h < nh; ++h)
@@ -270,12 +323,30 @@ void qc_build_model(qc_system *S) {
             const bool p_is_wide = (np_ > nq_) || (np_ == nq_ && dp.L >= dq.L);
             const int wide = p_is_wide ? P : Q, narrow = p_is_wide ? Q : P;
             const QcPairDesc &dn = S->pairs[narrow], &dw = S->pairs[wide];
+            // (round 3) p.p kets against p.p / d.s bras, total order 4: bra-major too - lane-per-quartet with the packed p.p records, three
+            // bundles per ket group (one per Cartesian axis of the ket's first function, three columns each); the pair that would be the
+            // ket of the column kernels (the wide one) stays the ket.  QC_NO_BM_PP: the column kernels keep them (A/B switch).
+            const bool no_bm_pp = getenv("QC_NO_BM_PP") != nullptr;
+            const bool w_is_pp = S->shells[S->pairA[wide]].L == 1 && S->shells[S->pairB[wide]].L == 1;
             if (dn.L <= 1 && dn.L + dw.L <= QC_LREG) {
                 bucket[(((dw.L * (QC_LPAIR + 1) + dn.L) * 7) + 0) * 2 + 1].push_back(QcTask{wide, narrow});
+            } else if (!no_bm_pp && S->pp_ok && dn.L == 2 && dw.L == 2 && w_is_pp && dw.K <= 63 && QC_LREG >= 4) {
+                bucket[(((2 * (QC_LPAIR + 1) + 2) * 7) + 0) * 2 + 1].push_back(QcTask{narrow, wide});
             } else {
                 bucket[(((dn.L * (QC_LPAIR + 1) + dw.L) * 7) + qc_lgc_for(dn.L, dw.L, dw.na * dw.nb)) * 2].push_back(QcTask{narrow, wide});
             }
         }
+    {   // The p.p-ket bra-major class pays where its list fills the chip (benzene/cc-pVDZ: 45 480 quartets, 0.148 ms against 0.186 ms in the
+        // column kernels, build -6 %); a small molecule's few hundred bundles are one more latency-bound launch (H2O/cc-pVTZ: 1526 quartets,
+        // no gain measured) - those stay with the column kernels.  QC_BM_PP_MIN overrides the threshold.
+        const long pp_min = getenv("QC_BM_PP_MIN") ? atol(getenv("QC_BM_PP_MIN")) : 8192;      // (read per system: a test switches it)
+        auto &ppb = bucket[(((2 * (QC_LPAIR + 1) + 2) * 7) + 0) * 2 + 1];
+        if (!ppb.empty() && (long)ppb.size() < pp_min) {
+            auto &colb = bucket[(((2 * (QC_LPAIR + 1) + 2) * 7) + qc_lgc_for(2, 2, 9)) * 2];
+            colb.insert(colb.end(), ppb.begin(), ppb.end());
+            ppb.clear();
+        }
+    }
     S->classes.clear();
     for (int b = 0; b < NB; ++b) {
         auto &v = bucket[b];
@@ -353,7 +424,9 @@ void qc_make_bundles(const qc_system *S, const std::vector<QcTask> &tasks, int i
                 // bra primitive pairs per bundle: about max(itmax, 32) primitive quartets per lane, so that the digestion of a partial block
                 // (two to three primitive quartets' worth of instructions) stays a small share
                 static const int pq_env = getenv("QC_BM_PQ") ? atoi(getenv("QC_BM_PQ")) : 32;           // (A/B switch)
-                const int rows = std::max(1, std::min(Kab, std::max(itmax, pq_env) / std::max(maxK, 1)));
+                static const int pq_pp_env = getenv("QC_BM_PP_PQ") ? atoi(getenv("QC_BM_PP_PQ")) : 32;  // (the same for the p.p-ket class)
+                const bool ket_pp = S->pairs[us[i].ket].L == 2;
+                const int rows = std::max(1, std::min(Kab, std::max(itmax, ket_pp ? pq_pp_env : pq_env) / std::max(maxK, 1)));
                 const int nparts = (Kab + rows - 1) / rows;
                 for (int sp = 0; sp < nparts; ++sp)
                     bundles.push_back(QcBundle{us[i].bra, (int)((int64_t)Kab * sp / nparts), (int)((int64_t)Kab * (sp + 1) / nparts), first, (int)(j - i), maxK, 0, 0});
@@ -444,12 +517,20 @@ void qc_build_shards(qc_system *S) {
                 // the list is tiny (H2O's 192 bundles).
                 auto cost = [](const std::vector<QcBundle> &bs) { int64_t t = 0; for (const auto &b : bs) t += (int64_t)(b.ij_hi - b.ij_lo) * b.maxK + 6; return t; };
                 std::vector<QcBundle> ub; std::vector<int> uk;
-                qc_make_bundles(S, c.shard, itmax, ub, uk, unit_env);
+                static const int unit_pp_env = getenv("QC_BM_PP_UNIT") ? atoi(getenv("QC_BM_PP_UNIT")) : 8;     // (the same for the p.p-ket class)
+                qc_make_bundles(S, c.shard, itmax, ub, uk, c.LCD == 2 ? unit_pp_env : unit_env);
                 static const int gain_env = getenv("QC_BM_GAIN") ? atoi(getenv("QC_BM_GAIN")) : 0;       // (A/B switch: percent of the old cost)
                 const bool high_bra = c.LAB >= 3;
                 const int gain = gain_env > 0 ? gain_env : (c.bundles.size() < 4096 ? 120 : 80);
                 const bool allowed = !high_bra || c.bundles.size() < 512;
                 if (!ub.empty() && allowed && cost(ub) * 100 < cost(c.bundles) * gain) { c.bundles.swap(ub); c.ketlist.swap(uk); }
+            }
+            if (c.LCD == 2) {   // p.p kets: every bundle three times, once per Cartesian axis of the ket's first function (QcBundle::pad0)
+                std::vector<QcBundle> b3;
+                b3.reserve(3 * c.bundles.size());
+                for (const auto &b : c.bundles)
+                    for (int ax = 0; ax < 3; ++ax) { QcBundle x = b; x.pad0 = ax; b3.push_back(x); }
+                c.bundles.swap(b3);
             }
         }
         else {
@@ -514,11 +595,22 @@ void qc_build_shards(qc_system *S) {
         }
         c.slot_words = words;
         c.lds_bytes = words * 8 * (64 >> c.LGC) + (qc_hoisted(c.LAB + c.LCD) ? 0 : qc_nplan(c.LAB + c.LCD) * 8);   // + the R recurrence plan
+        if (c.bm && c.LCD == 2) {   // (what the column kernels need for this class: the set-up passes run it through them)
+            c.col_lgc = qc_lgc_for(c.LAB, c.LCD, 9);
+            int cw = 0;
+            for (const auto &t : c.tasks) {
+                const QcPairDesc &b = S->pairs[t.bra], &k = S->pairs[t.ket];
+                const int ncd = k.na * k.nb, nab = b.na * b.nb, kt = b.na * k.na + b.na * k.nb + b.nb * k.na + b.nb * k.nb;
+                cw = std::max(cw, qc_region0(b.L + k.L, c.col_lgc) + nab * ncd + nab + ncd + 2 * kt);
+            }
+            c.col_slot_words = cw;
+            c.col_lds_bytes = cw * 8 * (64 >> c.col_lgc) + (qc_hoisted(c.LAB + c.LCD) ? 0 : qc_nplan(c.LAB + c.LCD) * 8);
+        }
         if (c.bm) {   // I[nab * ncd][65]: one column per lane
             int mx = 0;
             c.bm_rows = 0;
             for (const auto &t : c.shard) {
-                mx = std::max(mx, qc_bm_wave_words(c.LAB, S->pairs[t.bra].na * S->pairs[t.bra].nb, S->pairs[t.ket].na * S->pairs[t.ket].nb));
+                mx = std::max(mx, qc_bm_wave_words(c.LAB, S->pairs[t.bra].na * S->pairs[t.bra].nb, c.LCD == 2 ? 3 : S->pairs[t.ket].na * S->pairs[t.ket].nb));
                 c.bm_rows = std::max(c.bm_rows, S->pairs[t.bra].na + S->pairs[t.bra].nb);
             }
             c.slot_words = mx;

@@ -41,7 +41,7 @@ EXPORTS = ["qc_system_create", "qc_system_destroy", "qc_nbasis", "qc_nelectrons"
            "qc_fock_rhf_device", "qc_fock_uhf_device", "qc_sym_eig", "qc_scf_rhf", "qc_scf_uhf", "qc_comm_unique_id",
            "qc_comm_init", "qc_set_shard", "qc_plan_shard", "qc_set_stream", "qc_device_ready", "qc_work_stats_get",
            "qc_fock_profile", "qc_plan_shard_quartets", "qc_scf_begin_rhf", "qc_scf_begin_uhf", "qc_scf_iterate",
-           "qc_scf_orbital_energies", "qc_scf_density", "qc_scf_spin_square", "qc_scf_timings", "qc_scf_end", "qc_fock_profile_tiers", "qc_sym_eig_warm", "qc_set_fock_mode", "qc_scf_tensor_ms", "qc_set_accumulation", "qc_set_schwarz", "qc_scf_matrix", "qc_rccl_info", "qc_measure_peaks"]
+           "qc_scf_orbital_energies", "qc_scf_density", "qc_scf_spin_square", "qc_scf_timings", "qc_scf_end", "qc_fock_profile_tiers", "qc_unit_quartets", "qc_sym_eig_warm", "qc_set_fock_mode", "qc_scf_tensor_ms", "qc_set_accumulation", "qc_set_schwarz", "qc_scf_matrix", "qc_rccl_info", "qc_measure_peaks"]
 
 
 class QcError(RuntimeError):
@@ -116,6 +116,7 @@ def lib():
         L.qc_work_stats_get.argtypes = [vp, C.POINTER(WorkStats)]
         L.qc_fock_profile.argtypes = [vp, vp, vp, C.c_int, vp, vp, vp, vp, vp, vp]
         L.qc_fock_profile_tiers.argtypes = [vp, vp, vp, C.c_int, vp, vp, vp, vp, vp]
+        L.qc_unit_quartets.argtypes = [vp, vp]
         L.qc_set_fock_mode.argtypes = [vp, C.c_int]
         L.qc_set_accumulation.argtypes = [vp, C.c_int]
         L.qc_set_schwarz.argtypes = [vp, C.c_double]
@@ -239,6 +240,11 @@ class System:
 
     def set_stream(self, stream_ptr: int): _check(lib().qc_set_stream(self._h, C.c_void_p(stream_ptr)), "qc_set_stream")
 
+    def unit_quartets(self):
+        """Shell quartets of this rank's shard per launch unit (see unit_name)."""
+        nq = np.zeros(PROFILE_UNITS, np.int64)
+        _check(lib().qc_unit_quartets(self._h, nq.ctypes.data_as(C.c_void_p)), "qc_unit_quartets"); return nq
+
     def work_stats(self) -> WorkStats:
         ws = WorkStats(); _check(lib().qc_work_stats_get(self._h, C.byref(ws)), "qc_work_stats_get"); return ws
 
@@ -255,7 +261,7 @@ class System:
         return dict(class_ms=ms, class_id=cid, quartets=nq, bytes=by, flops=fl, total_ms=tot.value)
 
 
-PROFILE_UNITS = 18   # QC_PROFILE_UNITS in include/qchem_hip.h
+PROFILE_UNITS = 20   # QC_PROFILE_UNITS in include/qchem_hip.h
 
 
 def unit_name(u: int) -> str:

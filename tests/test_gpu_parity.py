@@ -87,6 +87,43 @@ def test_fock_uhf_matches_dense_contraction(mol, basis):
     assert np.abs(Gb - Gb_ref).max() < TOL_INT * scale
 
 
+@pytest.mark.parametrize("mol,basis", [("water", "cc-pVDZ"), ("ethylene", "6-31G_st_st"), ("oxygen", "cc-pVDZ"), ("water", "cc-pVTZ")])
+def test_pp_ket_bra_major_class_matches_dense_contraction(mol, basis, monkeypatch):
+    """The lane-per-quartet kernel for p.p kets (qc_fock_bm_kernel<2, 0>: (pp|pp), (ds|pp)) only takes lists that fill the chip, so the
+    small systems of this suite never reach it on their own: QC_BM_PP_MIN = 1 hands it every such quartet.  RHF and UHF digestion against
+    the oracle's dense contraction (rhf.rs:152-167, uhf.rs:210-227), and against the column kernels on the same quartets."""
+    import qchem_rs_amd as q
+    from oracle.oracle import Oracle
+    m = load_system(mol, basis)
+    o = Oracle(m)
+    I = o.eri()
+    monkeypatch.setenv("QC_BM_PP_MIN", "1")
+    s = q.System(m)
+    monkeypatch.delenv("QC_BM_PP_MIN")
+    monkeypatch.setenv("QC_NO_BM_PP", "1")
+    s_col = q.System(m)
+    monkeypatch.delenv("QC_NO_BM_PP")
+    names = [u for u in range(q.hf.PROFILE_UNITS) if q.hf.unit_name(u) == "qc_fock_bm_kernel<2, 0>"]
+    assert len(names) == 1
+    D = _rand_sym(s.n, 5)
+    G, G_col, G_ref = s.fock_rhf(D), s_col.fock_rhf(D), o.g_rhf(D, I)
+    scale = max(1.0, np.abs(G_ref).max())
+    assert np.abs(G - G_ref).max() < TOL_INT * scale
+    assert np.abs(G - G_col).max() < 1e-12 * scale
+    assert np.array_equal(G, G.T)
+    assert np.array_equal(G, s.fock_rhf(D)), "the build is bitwise reproducible with the class switched on"
+    Da, Db = _rand_sym(s.n, 6), _rand_sym(s.n, 7)
+    Ga, Gb = s.fock_uhf(Da, Db)
+    assert np.abs(Ga - o.g_uhf(Da, Db, I)).max() < TOL_INT * scale
+    assert np.abs(Gb - o.g_uhf(Db, Da, I)).max() < TOL_INT * scale
+    # the class really took quartets (and the column kernels lost exactly those)
+    ws, ws_col = s.work_stats(), s_col.work_stats()
+    assert ws.quartets == ws_col.quartets
+    tp = s.unit_quartets()
+    assert tp[names[0]] > 0 and s_col.unit_quartets()[names[0]] == 0
+    s.close(); s_col.close()
+
+
 @pytest.mark.parametrize("mol,basis", [("hydrogen", "STO-3G"), ("water", "6-31G_st_st"), ("water", "cc-pVTZ"), ("oxygen", "cc-pVDZ")])
 def test_one_electron_matrices_on_the_gpu(mol, basis):
     """S, T, V from qc_one_electron.hip (what the SCF drivers use) == the oracle's molint::overlap/kinetic/nuclear
