@@ -17,7 +17,8 @@ Workloads (BASELINE.json configs; inputs are the fixture files under data/, noth
   N = 1  -> H2O / cc-pVTZ RHF (configs[2], the configuration the metric is quoted on; 58 bf, 32 131 unique quartets)
   N > 1  -> C6H6 / cc-pVDZ RHF (configs[4]): the class-sorted quartet list is dealt across the ranks, every rank digests its
             shard and the partial Fock matrices are summed by one RCCL all-reduce per build (strong scaling).  The N = 1 line
-            carries the same workload's single-GPU numbers under "scaling_reference".
+            carries the same workload's single-GPU numbers under "scaling_reference", and every N > 1 line under
+            "same_workload_1gpu" (rank 0 times the unsharded workload on its own GPU before the sharded run, with the speed-up).
 `value` = unique shell quartets enumerated per step x K / elapsed (max over ranks), whole job.  `ms_per_step` = SCF-iteration time.
 
 Extra objects on the JSON line: "roofline" (the Fock build: hipEvent-timed inside the timed passes on the library's stream,
@@ -320,11 +321,13 @@ def compact_line(full, detail_path=None):
         line["stored_mode"] = {"ms_per_step": _r(sm["ms_per_step"]), "gemv_GBs": _r(sm["gemv_GBs"])}
     if "rccl" in full:
         line["rccl"] = str(full["rccl"])[:120]
+    if "same_workload_1gpu" in full:
+        line["same_workload_1gpu"] = {k: _r(v) for k, v in full["same_workload_1gpu"].items()}
     if detail_path:
         line["detail"] = detail_path
     n = len(json.dumps(line, separators=(",", ":")))
     if n >= MAX_LINE_BYTES:                       # never hand the driver a line it cannot keep: shed the optional blocks
-        for k in ("stored_mode", "scaling_reference", "rccl"):
+        for k in ("stored_mode", "scaling_reference", "rccl", "same_workload_1gpu"):
             line.pop(k, None)
     return line
 
@@ -423,6 +426,17 @@ def main():
     host = Host(world, torch, dist)
 
     key = args.workload if args.workload != "auto" else ("h2o_ccpvtz" if world == 1 else "c6h6_ccpvdz")
+    same_workload_1gpu = None
+    if world > 1 and not args.no_scaling_reference:
+        # The N = 1 line of this benchmark is H2O/cc-pVTZ (the configuration the metric is quoted on), the N > 1 lines are the sharded
+        # benzene workload: rank 0 first times the SAME workload unsharded on its own GPU (outside the timed region, the other ranks wait),
+        # so that every multi-GPU line carries the single-GPU figure its speed-up is measured against.
+        if rank == 0:
+            r1, _ = measure(torch, q, Host(1, torch, dist), key, max(8, min(args.steps, 24)), 2, 1, 0, None, with_units=False)
+            same_workload_1gpu = {"workload": WORKLOADS[key][2] + " direct-SCF iteration", "n_gpus": 1, "value": r1["value"],
+                                  "ms_per_step": r1["ms_per_step"], "fock_build_ms": r1["iter_breakdown_ms"]["fock_build"],
+                                  "diis_eig_density_ms": r1["iter_breakdown_ms"]["diis_eig_density"]}
+        host.barrier()
     res, mol = measure(torch, q, host, key, args.steps, args.warmup, world, rank, uid, with_units=not args.no_extras)
     line = {
         "metric": "ERI shell-quartets/sec through one SCF iteration (ms_per_step = SCF iter time), RHF",
@@ -441,6 +455,9 @@ def main():
         line["committed_counters"] = res["committed_counters"]
     if world > 1 and rank == 0:
         line["rccl"] = q.rccl_info()
+        if same_workload_1gpu:
+            same_workload_1gpu["speedup"] = res["value"] / same_workload_1gpu["value"]
+            line["same_workload_1gpu"] = same_workload_1gpu
     if world == 1 and not args.no_extras:
         line["accumulation"] = accumulation_ab(q, mol)
         if not args.no_scaling_reference and key == "h2o_ccpvtz":

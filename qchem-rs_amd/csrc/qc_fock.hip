@@ -167,6 +167,8 @@ static std::vector<int> qc_build_rplan() {
     return plan;
 }
 
+static int qc_join_probe(qc_system *S, bool *concurrent);
+
 int qc_device_init(qc_system *S) {
     if (S->device_ready) return QC_OK;
     if (qc_device_ready() != QC_OK) return QC_ERR_NO_DEVICE;
@@ -222,6 +224,13 @@ int qc_device_init(qc_system *S) {
     QC_HIP_CHECK(hipMemset(S->d_join, 0, 4 * sizeof(unsigned)));
     QC_HIP_CHECK(hipHostMalloc(&S->h_join_timeout, sizeof(int), hipHostMallocDefault));
     *S->h_join_timeout = 0; S->join_target = 0;
+    {
+        bool concurrent = true;
+        int prc = qc_join_probe(S, &concurrent);
+        if (prc != QC_OK) return prc;
+        S->join_by_events = !concurrent;
+        if (!concurrent && getenv("QC_SCF_DEBUG")) fprintf(stderr, "qchem_hip: kernels of different streams do not run concurrently here (profiler counters?): event join\n");
+    }
     QC_HIP_CHECK(hipMalloc(&S->d_fxs, 2 * sizeof(double)));
     // Schwarz factors of the pairs (once per geometry), then the screened work lists
     int rc = qc_schwarz_device(S);
@@ -334,13 +343,31 @@ struct QcIssuePool {
 __global__ void qc_join_mark_kernel(unsigned *cnt) {
     if (threadIdx.x == 0) (void)__hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
 }
-__global__ void qc_join_wait_kernel(unsigned *cnt, unsigned target, int *timeout_flag) {
+__global__ void qc_join_wait_kernel(unsigned *cnt, unsigned target, int *timeout_flag, long long limit) {
     if (threadIdx.x != 0) return;
     const long long t0 = wall_clock64();
     while ((int)(__hip_atomic_load(cnt, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) - target) < 0) {
         __builtin_amdgcn_s_sleep(4);
-        if (wall_clock64() - t0 > 200000000LL) { *timeout_flag = 1; __threadfence_system(); break; }
+        if (wall_clock64() - t0 > limit) { *timeout_flag = 1; __threadfence_system(); break; }
     }
+}
+constexpr long long QC_JOIN_LIMIT = 200000000LL;       // two seconds of the 100 MHz clock
+
+// The device-side join needs kernels of different streams to RUN concurrently: a waiting kernel whose marker cannot start would wait
+// out its limit.  That is the case whenever something serialises dispatches - rocprofv3 counter collection (--pmc) does, so do the
+// runtime's debugging switches.  Asked once per handle: a waiting kernel on one stream, then its marker on another; if the wait gives up
+// after 2 ms, this handle joins through events (as QC_EVENT_JOIN does).
+static int qc_join_probe(qc_system *S, bool *concurrent) {
+    *S->h_join_timeout = 0;
+    S->join_target += 1;
+    hipLaunchKernelGGL(qc_join_wait_kernel, dim3(1), dim3(64), 0, S->stream, S->d_join, S->join_target, S->h_join_timeout, 200000LL);
+    hipLaunchKernelGGL(qc_join_mark_kernel, dim3(1), dim3(64), 0, S->side[0], S->d_join);
+    if (hipGetLastError() != hipSuccess) return QC_ERR_HIP;
+    QC_HIP_CHECK(hipStreamSynchronize(S->stream));
+    QC_HIP_CHECK(hipStreamSynchronize(S->side[0]));
+    *concurrent = *S->h_join_timeout == 0;
+    *S->h_join_timeout = 0;
+    return QC_OK;
 }
 
 static QcKernelArgs base_args(qc_system *S, const QcFockArgs &fa) {
@@ -537,7 +564,8 @@ int qc_launch_fock_classes(qc_system *S, const QcFockArgs &fa, float *class_ms, 
         }
         // the most loaded chain runs on the handle's own stream: no fork hop before it, no join after it
         const int kmain = ks[0];
-        static const bool event_join = getenv("QC_EVENT_JOIN") != nullptr;           // (A/B switch: the event join of rounds 1-2)
+        static const bool event_join_env = getenv("QC_EVENT_JOIN") != nullptr;       // (A/B switch: the event join of rounds 1-2)
+        const bool event_join = event_join_env || S->join_by_events;
         if (!event_join && *S->h_join_timeout) return QC_ERR_HIP;    // an earlier build's join gave up: its result was not complete
         // launches of a set of streams, interleaved (first launch of every stream of the set before any second one), then the
         // streams' markers of the device-side join
@@ -606,7 +634,7 @@ int qc_launch_fock_classes(qc_system *S, const QcFockArgs &fa, float *class_ms, 
             }
         } else if (nside) {
             S->join_target += nside;
-            hipLaunchKernelGGL(qc_join_wait_kernel, dim3(1), dim3(64), 0, S->stream, S->d_join, S->join_target, S->h_join_timeout);
+            hipLaunchKernelGGL(qc_join_wait_kernel, dim3(1), dim3(64), 0, S->stream, S->d_join, S->join_target, S->h_join_timeout, QC_JOIN_LIMIT);
             if (hipGetLastError() != hipSuccess) return QC_ERR_HIP;
         }
         if (ev) QC_HIP_CHECK(hipEventRecord(ev[1], S->stream));
@@ -623,6 +651,16 @@ int qc_launch_fock_classes(qc_system *S, const QcFockArgs &fa, float *class_ms, 
         int rc = qc_launch_fock_classes(S, fa, nullptr, S->unit_ms.data());     // warm-up: first launches pay code upload
         if (rc == QC_OK) rc = qc_launch_fock_classes(S, fa, nullptr, S->unit_ms.data());   // serial, timed
         if (rc != QC_OK) return rc;
+        // (experiment switch: no tuning - longest-first on the durations alone over QC_TUNE_FIXED streams, the handle's stream 15 us ahead)
+        static const int fixed_w = getenv("QC_TUNE_FIXED") ? atoi(getenv("QC_TUNE_FIXED")) : 0;
+        if (fixed_w >= 1 && fixed_w <= QC_NSTREAMS) {
+            lpt(S->unit_ms, fixed_w, 0.015f);
+            S->cand_stream.clear(); S->cand_weight.clear(); S->cand_ms.clear(); S->cand_n.clear(); S->cand_frozen = true;
+            S->tuned_best_ms = 0.f; S->tune_count += 1; S->second_stage = 2;
+            if (fa.G0) QC_HIP_CHECK(hipMemsetAsync(fa.G0, 0, gbytes, S->stream));
+            nofork = false;
+            return launch_concurrent(nullptr, false);
+        }
         lpt(S->unit_ms, QC_NSTREAMS);
         EventList evl;
         if (evl.create(2 + 2 * units.size()) != QC_OK) return QC_ERR_HIP;
