@@ -391,7 +391,7 @@ def dry_run(args, world, rank):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=30)      # (two whole SCF runs of the headline workload: passes 0..14 twice)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="auto", choices=["auto"] + sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")

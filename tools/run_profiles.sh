@@ -10,7 +10,7 @@ O=$R/gpurun_out/prof_$TAG
 mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 for W in h2o_ccpvtz c6h6_ccpvdz; do
-  ARGS="$R/bench.py --workload $W --no-extras --no-cpu-baseline --steps 20 --warmup 3"
+  ARGS="$R/bench.py --workload $W --no-extras --no-cpu-baseline --steps 30 --warmup 3"
   python $ARGS > $O/${W}_bench.json 2> $O/${W}_bench.err || exit 1
   rocprofv3 --kernel-trace --stats --output-format csv -d $O/${W}_trace -- python $ARGS > $O/${W}_bench_under_rocprof.json 2> $O/${W}_trace.err || exit 1
   rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_ACTIVE_INST_VALU --output-format csv -d $O/${W}_sq -- python $ARGS > /dev/null 2> $O/${W}_sq.err || exit 1
