@@ -1,12 +1,16 @@
 set -o pipefail
 R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/s2; mkdir -p $O
-for T in 0.2 0.05; do
-QC_EIG_WARM_RMS=$T QC_SCF_DEBUG=1 timeout -k 10 120 python tools/scf_trace_probe.py water cc-pVTZ 16 > $O/warm_$T.out 2> $O/warm_$T.err
-echo "warm_rms $T:"; grep -o "ctl a: [0-9 -]*\|mode [0-9] cold [0-9]" $O/warm_$T.err | paste - - | head -8
-for i in 1 2 3; do
-QC_EIG_WARM_RMS=$T timeout -k 10 300 python bench.py --workload h2o_ccpvtz --no-extras --no-cpu-baseline --steps 30 2>/dev/null | python -c "
+for i in 1 2 3 4 5 6 7 8 9 10; do
+QC_TUNE_DEBUG=1 QCHEM_HIP_LIB=$R/qchem-rs_amd/libqchem_hip_base.so timeout -k 10 300 python bench.py --workload h2o_ccpvtz --no-extras --no-cpu-baseline --steps 30 2>$O/lot_$i.err | python -c "
 import json,sys
 d=json.loads(sys.stdin.readline()); b=d['iter_breakdown_ms']
-print('warm_rms $T iter %.4f  build %.4f  linalg %.4f  %s' % (d['ms_per_step'], b['fock_build'], b['diis_eig_density'], d['config']['passes'][-25:]))"
+print('run $i iter %.4f  build %.4f  linalg %.4f' % (d['ms_per_step'], b['fock_build'], b['diis_eig_density']))"
+grep "final cand\|online\|in-pass" $O/lot_$i.err | tr '\n' ';' ; echo
+done
+for r in 1 2 3; do for L in libqchem_hip_base.so libqchem_hip.so; do
+QCHEM_HIP_LIB=$R/qchem-rs_amd/$L timeout -k 10 300 python bench.py --workload c6h6_ccpvdz --no-extras --no-cpu-baseline --steps 30 2>/dev/null | python -c "
+import json,sys
+d=json.loads(sys.stdin.readline()); b=d['iter_breakdown_ms']
+print('c6h6 %-24s iter %.4f  build %.4f  linalg %.4f' % ('$L', d['ms_per_step'], b['fock_build'], b['diis_eig_density']))"
 done; done
