@@ -588,6 +588,7 @@ struct qc_scf_state {
     hipEvent_t ev0 = nullptr, ev1 = nullptr, ev2 = nullptr;
     double ms_fock = 0, ms_linalg = 0, ms_setup = 0;
     unsigned pass_seq = 0;                     // sequence number of the last pass whose end the host saw through the pinned word
+    bool event_wait = getenv("QC_EVENT_WAIT") != nullptr;      // (A/B switch, read per SCF state: the stream's event instead)
     bool linalg_pending = false;               // ... and whose linear-algebra time (ev1 -> ev2) has not been read yet
     ~qc_scf_state() {
         if (S && S->prep_owner == this) { S->prepared = false; S->prep_owner = nullptr; }
@@ -760,8 +761,7 @@ static int scf_iterate(qc_scf_state *st, double *energy, double *rms_out) {
     bool scale_in_kernel = false;
     // Single-rank runs on the one-workgroup path: the kernel that ends the pass stores the pass's sequence number into pinned memory
     // after the scalars and control words, and the host polls THAT instead of the event behind it (a few microseconds earlier per pass).
-    static const bool no_seq = getenv("QC_EVENT_WAIT") != nullptr;              // (A/B switch)
-    const bool seq_wait = W.small_fused && !multi && !no_seq;
+    const bool seq_wait = W.small_fused && !multi && !st->event_wait;
     unsigned *h_seq = reinterpret_cast<unsigned *>(W.h_scal + 2 * QC_SYNC_WORDS);
     if (W.small_fused) {
         for (int s = 0; s < nspin; ++s) {

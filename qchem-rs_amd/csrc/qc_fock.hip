@@ -228,7 +228,8 @@ int qc_device_init(qc_system *S) {
         bool concurrent = true;
         int prc = qc_join_probe(S, &concurrent);
         if (prc != QC_OK) return prc;
-        S->join_by_events = !concurrent;
+        S->join_by_events = !concurrent || getenv("QC_EVENT_JOIN") != nullptr;      // (A/B switch, read per handle: the event join of rounds 1-2)
+        S->issue_threads = getenv("QC_ISSUE_THREADS") ? atoi(getenv("QC_ISSUE_THREADS")) : -1;    // (0: never; n: always n helpers; read per handle)
         if (!concurrent && getenv("QC_SCF_DEBUG")) fprintf(stderr, "qchem_hip: kernels of different streams do not run concurrently here (profiler counters?): event join\n");
     }
     QC_HIP_CHECK(hipMalloc(&S->d_fxs, 2 * sizeof(double)));
@@ -564,8 +565,7 @@ int qc_launch_fock_classes(qc_system *S, const QcFockArgs &fa, float *class_ms, 
         }
         // the most loaded chain runs on the handle's own stream: no fork hop before it, no join after it
         const int kmain = ks[0];
-        static const bool event_join_env = getenv("QC_EVENT_JOIN") != nullptr;       // (A/B switch: the event join of rounds 1-2)
-        const bool event_join = event_join_env || S->join_by_events;
+        const bool event_join = S->join_by_events;                   // (QC_EVENT_JOIN, or dispatches are serialised here: qc_device_init)
         if (!event_join && *S->h_join_timeout) return QC_ERR_HIP;    // an earlier build's join gave up: its result was not complete
         // launches of a set of streams, interleaved (first launch of every stream of the set before any second one), then the
         // streams' markers of the device-side join
@@ -597,7 +597,7 @@ int qc_launch_fock_classes(qc_system *S, const QcFockArgs &fa, float *class_ms, 
         // Measured (alternating runs on one box, means of six / two): H2O/cc-pVTZ builds 0.227 ms with three helpers against 0.204 ms
         // issued by the caller alone - its 13 launches of 30-70 us each do better when they start 6-7 us apart than all at once -
         // benzene/cc-pVDZ 1.470 against 1.494 ms.  So the helpers are for builds whose launches are long against the issue time.
-        static const int nhelp_env = getenv("QC_ISSUE_THREADS") ? atoi(getenv("QC_ISSUE_THREADS")) : -1;    // (0: never; n: always n helpers)
+        const int nhelp_env = std::min(S->issue_threads, QC_NSTREAMS - 1);
         float serial_ms = 0.f;
         for (float x : S->unit_ms) serial_ms += x;
         const int nhelp_want = nhelp_env >= 0 ? nhelp_env : (serial_ms > 1.0f ? 3 : 0);

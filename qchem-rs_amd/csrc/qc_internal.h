@@ -166,6 +166,7 @@ struct qc_system {
     unsigned *d_join = nullptr;              // counter of the device-side join of a build's side streams (qc_join_mark / qc_join_wait)
     int *h_join_timeout = nullptr;           // pinned: set by a join that gave up (a side stream's launches never finished)
     unsigned join_target = 0;
+    int issue_threads = -1;                  // helper threads that issue a build's launches: -1 = by the size of the build (qc_fock.hip)
     bool join_by_events = false;             // dispatches are serialised here (qc_join_probe): the side streams are joined through events
     struct QcIssuePool *issue_pool = nullptr; // helper threads that issue a build's launches next to the caller (qc_fock.hip)
     void *comm = nullptr;                    // ncclComm_t

@@ -441,6 +441,33 @@ def test_fock_build_is_bitwise_reproducible():
     s2.close()
 
 
+def test_launch_structure_switches_do_not_change_a_bit(monkeypatch):
+    """How a build's launches are issued and joined is not allowed to show in the result (integer accumulation): the device-side join
+    of the side streams against the event join it replaced (QC_EVENT_JOIN - also what a handle falls back to when dispatches are
+    serialised, e.g. under rocprofv3 --pmc), helper threads issuing the side streams (QC_ISSUE_THREADS), and the end of an SCF pass
+    seen through the pinned sequence word against the stream's event (QC_EVENT_WAIT).  The switches are read per handle / per SCF state."""
+    import qchem_rs_amd as q
+    m = load_system("water", "cc-pVTZ")
+    D = _rand_sym(58, 43)
+    s0 = q.System(m)
+    G0 = s0.fock_rhf(D)
+    e0 = q.restricted_hartree_fock(s0, q.HartreeFockConfig(100, 1e-10))
+    for env in ({"QC_EVENT_JOIN": "1"}, {"QC_ISSUE_THREADS": "3"}, {"QC_ISSUE_THREADS": "2", "QC_EVENT_WAIT": "1"}):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        s = q.System(m)
+        for _ in range(3):
+            assert np.array_equal(s.fock_rhf(D), G0), env
+        Ga, Gb = s.fock_uhf(D, D)
+        assert np.array_equal(Ga, Gb)
+        e = q.restricted_hartree_fock(s, q.HartreeFockConfig(100, 1e-10))
+        assert e.iterations == e0.iterations and e.electronic_energy == e0.electronic_energy and e.orbital_energies == e0.orbital_energies, env
+        s.close()
+        for k in env:
+            monkeypatch.delenv(k)
+    s0.close()
+
+
 def test_scf_runs_are_bitwise_reproducible():
     q, s, o = _sys("water", "cc-pVDZ")
     outs = [q.restricted_hartree_fock(s, q.HartreeFockConfig(100, 1e-10)) for _ in range(2)]
