@@ -585,18 +585,19 @@ struct qc_scf_state {
     int twin = -1;                             // UHF spin-twin decision, taken at the first build
     double ms_tensor = 0;
     DeviceDiis *diis[2] = {nullptr, nullptr};
-    hipEvent_t ev0 = nullptr, ev1 = nullptr, ev2 = nullptr;
+    // timing events of a pass (start | build done | pass done), two sets used alternately: a pass whose end the host saw through the pinned
+    // sequence word reads none of them before it returns - the next pass does, after its own build has been issued
+    hipEvent_t evs[2][3] = {{nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr}};
+    int ev_cur = 0, pending_set = 0;
     double ms_fock = 0, ms_linalg = 0, ms_setup = 0;
     unsigned pass_seq = 0;                     // sequence number of the last pass whose end the host saw through the pinned word
     bool event_wait = getenv("QC_EVENT_WAIT") != nullptr;      // (A/B switch, read per SCF state: the stream's event instead)
-    bool linalg_pending = false;               // ... and whose linear-algebra time (ev1 -> ev2) has not been read yet
+    bool timing_pending = false;               // ... and whose event times (set `pending_set`) have not been read yet
     ~qc_scf_state() {
         if (S && S->prep_owner == this) { S->prepared = false; S->prep_owner = nullptr; }
         delete diis[0]; delete diis[1];
         if (S && S->stream) (void)hipStreamSynchronize(S->stream);
-        if (ev0) (void)hipEventDestroy(ev0);
-        if (ev1) (void)hipEventDestroy(ev1);
-        if (ev2) (void)hipEventDestroy(ev2);
+        for (auto &set : evs) for (hipEvent_t e : set) if (e) (void)hipEventDestroy(e);
     }
 };
 static void system_free(qc_system *S);
@@ -663,7 +664,7 @@ static int scf_begin(qc_system *S, bool uhf, int n_alpha, int n_beta, qc_scf_sta
         st->diis[s] = uhf ? new DeviceDiis(2, 8, n) : new DeviceDiis(4, 6, n);
         if ((rc = st->diis[s]->init()) != QC_OK) return rc;
     }
-    QC_HIP_CHECK(hipEventCreate(&st->ev0)); QC_HIP_CHECK(hipEventCreate(&st->ev1)); QC_HIP_CHECK(hipEventCreate(&st->ev2));
+    for (auto &set : st->evs) for (hipEvent_t &e : set) QC_HIP_CHECK(hipEventCreate(&e));
     int eig_flag = 0;                                                     // the eigensolves of X and of the Hueckel guess
     QC_HIP_CHECK(hipMemcpyAsync(&eig_flag, st->W.ctl + 9, sizeof(int), hipMemcpyDeviceToHost, S->stream));
     QC_HIP_CHECK(hipStreamSynchronize(S->stream));
@@ -673,12 +674,17 @@ static int scf_begin(qc_system *S, bool uhf, int n_alpha, int n_beta, qc_scf_sta
     return QC_OK;
 }
 
-// (a pass whose end the host saw through the pinned sequence word has not read its ev1 -> ev2 time yet: ev2 may still have been in flight)
+// (a pass whose end the host saw through the pinned sequence word has not read its event times yet: the last event may still have been
+// in flight, and asking costs host time between two passes.  The next pass asks once its own build is out.)
 static void scf_flush_timing(qc_scf_state *st) {
-    if (!st->linalg_pending) return;
-    st->linalg_pending = false;
-    float ms_l = 0;
-    if (hipEventSynchronize(st->ev2) == hipSuccess && hipEventElapsedTime(&ms_l, st->ev1, st->ev2) == hipSuccess) st->ms_linalg += ms_l;
+    if (!st->timing_pending) return;
+    st->timing_pending = false;
+    hipEvent_t *e = st->evs[st->pending_set];
+    float ms_f = 0, ms_l = 0;
+    if (hipEventSynchronize(e[2]) != hipSuccess) return;
+    if (hipEventElapsedTime(&ms_f, e[0], e[1]) == hipSuccess) st->ms_fock += ms_f;
+    if (hipEventElapsedTime(&ms_l, e[1], e[2]) == hipSuccess) st->ms_linalg += ms_l;
+    if (!st->stored && !st->S->comm) qc_fock_feedback(st->S, ms_f);
 }
 
 // Wait for an event by polling (what hipStreamSynchronize does too): a parked thread's wake-up latency is longer
@@ -703,8 +709,10 @@ static int scf_iterate(qc_scf_state *st, double *energy, double *rms_out) {
     const int nspin = st->uhf ? 2 : 1;
     int rc;
     const double th0 = now_ms();
-    scf_flush_timing(st);
-    QC_HIP_CHECK(hipEventRecord(st->ev0, sm));
+    st->ev_cur ^= 1;
+    hipEvent_t *const ev = st->evs[st->ev_cur];
+    hipEvent_t const ev0 = ev[0], ev1 = ev[1], ev2 = ev[2];
+    QC_HIP_CHECK(hipEventRecord(ev0, sm));
     double *dE[2] = {nullptr, nullptr}, *dF[2] = {nullptr, nullptr};       // this pass's DIIS sample buffers (error, Fock matrix) per spin
     for (int s = 0; s < nspin; ++s) st->diis[s]->next_sample(&dE[s], &dF[s]);
     bool have_F = false;
@@ -724,7 +732,8 @@ static int scf_iterate(qc_scf_state *st, double *energy, double *rms_out) {
     // (Enqueueing the *next* pass's build here, ahead of the wait below, was tried: its side-stream launches then sit
     // behind unsignalled barriers while the main queue still works, and with 8 hardware queues on 4 pipes the blocked
     // queues stall their pipe neighbours - 1.6 ms per pass instead of 0.6.)
-    QC_HIP_CHECK(hipEventRecord(st->ev1, sm));
+    scf_flush_timing(st);                                                 // (the previous pass's times, now that this pass's build is out)
+    QC_HIP_CHECK(hipEventRecord(ev1, sm));
     if (!W.small_fused)
         for (int s = 0; s < nspin; ++s)                                   // (the control words were cleared by the previous pass)
             if ((rc = roothaan_enqueue(S, W, *st->diis[s], st->G.p + s * nn, st->D[s].p, st->ws.p + s * n, st->Cs.p + s * nn, s, dE[s], dF[s], have_F)) != QC_OK) return rc;
@@ -779,20 +788,20 @@ static int scf_iterate(qc_scf_state *st, double *energy, double *rms_out) {
     // the next pass's build starts from Dn: its density-only preliminaries run while the host turns around
     auto prepare_next = [&]() -> int { return st->stored ? QC_OK : qc_fock_prepare_device(S, st->Dn[0].p, st->uhf ? st->Dn[1].p : nullptr, st->uhf, st, scale_in_kernel); };
     if ((rc = prepare_next()) != QC_OK) return rc;
-    QC_HIP_CHECK(hipEventRecord(st->ev2, sm));
+    QC_HIP_CHECK(hipEventRecord(ev2, sm));
     const double th1 = now_ms();
     if (seq_wait) {
         const unsigned want = st->pass_seq + 1;
         unsigned spins = 0;
         while (__atomic_load_n(h_seq, __ATOMIC_ACQUIRE) != want) {
             if ((++spins & 0xfff) == 0) {                   // (a failed launch or a fault never stores the word: the event knows)
-                const hipError_t e = hipEventQuery(st->ev2);
+                const hipError_t e = hipEventQuery(ev2);
                 if (e == hipErrorNotReady) continue;
                 if (e != hipSuccess || __atomic_load_n(h_seq, __ATOMIC_ACQUIRE) != want) { fprintf(stderr, "qchem_hip: the pass ended without its sequence word (%s)\n", hipGetErrorString(e)); return QC_ERR_HIP; }
             }
         }
         st->pass_seq = want;
-    } else QC_HIP_CHECK(wait_event(st->ev2));
+    } else QC_HIP_CHECK(wait_event(ev2));
     const double th2 = now_ms();
     if (!ranks_agree()) { fprintf(stderr, "qchem_hip: rank %d: the ranks' SCF scalars differ - replicated state diverged\n", S->rank); return QC_ERR_RCCL; }
     if (h_ctl[8] != 0) return QC_DIIS_SINGULAR;                          // "DIIS failed", rhf.rs:73
@@ -808,16 +817,12 @@ static int scf_iterate(qc_scf_state *st, double *energy, double *rms_out) {
         fprintf(stderr, "\n");
     }
     float ms_f = 0, ms_l = 0;
-    if (seq_wait) {
-        // ev1 lies before the kernel whose word has just arrived; ev2 behind it - its time is read when the next pass begins
-        (void)hipEventSynchronize(st->ev1);
-        (void)hipEventElapsedTime(&ms_f, st->ev0, st->ev1);
-        st->linalg_pending = true;
-    } else {
-        (void)hipEventElapsedTime(&ms_f, st->ev0, st->ev1);
-        (void)hipEventElapsedTime(&ms_l, st->ev1, st->ev2);
+    if (seq_wait) { st->timing_pending = true; st->pending_set = st->ev_cur; }     // (read by the next pass, scf_flush_timing)
+    else {
+        (void)hipEventElapsedTime(&ms_f, ev0, ev1);
+        (void)hipEventElapsedTime(&ms_l, ev1, ev2);
     }
-    if (!st->stored && !S->comm) qc_fock_feedback(S, ms_f);              // (multi-rank: every rank keeps its tuner's choice)
+    if (!seq_wait && !st->stored && !S->comm) qc_fock_feedback(S, ms_f);  // (multi-rank: every rank keeps its tuner's choice)
     bool redo = false;
     for (int s = 0; s < nspin; ++s) {
         const bool refined = W.cold[s] || (W.have_prev[s] && W.mode[s] == 0);       // the eigensolve reported through the control word
@@ -825,7 +830,7 @@ static int scf_iterate(qc_scf_state *st, double *energy, double *rms_out) {
         if (h_ctl[4 * s] == 1) { W.npass[s] = W.cold[s] ? 3 : std::max(1, std::min(3, h_ctl[4 * s + 3])); continue; }
         W.npass[s] = 3;
         // the refinement wanted rotations (large step, or a degenerate cluster): repeat this spin's eigensolve the careful way
-        if (!redo) { scf_flush_timing(st); QC_HIP_CHECK(hipEventRecord(st->ev1, sm)); }
+        if (!redo) { scf_flush_timing(st); QC_HIP_CHECK(hipEventRecord(ev1, sm)); }
         if ((rc = roothaan_redo_eig(S, W, st->ws.p + s * n, st->Cs.p + s * nn, s)) != QC_OK) return rc;
         if ((rc = density_and_scalars(s, false)) != QC_OK) return rc;
         redo = true;
@@ -838,12 +843,12 @@ static int scf_iterate(qc_scf_state *st, double *energy, double *rms_out) {
         if ((rc = publish_scalars()) != QC_OK) return rc;
         scale_in_kernel = false;
         if ((rc = prepare_next()) != QC_OK) return rc;                    // (the density changed)
-        QC_HIP_CHECK(hipEventRecord(st->ev2, sm));
-        QC_HIP_CHECK(wait_event(st->ev2));
+        QC_HIP_CHECK(hipEventRecord(ev2, sm));
+        QC_HIP_CHECK(wait_event(ev2));
         if (!ranks_agree()) return QC_ERR_RCCL;
         if (h_ctl[9] != 0) return QC_EIG_NOT_CONVERGED;                  // the repeat ran out of sweeps: no vectors to go on with
         float ms_r = 0;
-        (void)hipEventElapsedTime(&ms_r, st->ev1, st->ev2);
+        (void)hipEventElapsedTime(&ms_r, ev1, ev2);
         ms_l += ms_r;
     }
     double rms_sum = 0.0, e_sum = 0.0;

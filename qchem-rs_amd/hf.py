@@ -292,14 +292,18 @@ class ScfStepper:
             _check(lib().qc_scf_begin_uhf(system.handle, n_alpha, n_beta, C.byref(self._st)), "qc_scf_begin_uhf")
         else:
             _check(lib().qc_scf_begin_rhf(system.handle, C.byref(self._st)), "qc_scf_begin_rhf")
+        # (the per-pass call is a host's inner loop: the foreign function and its out-parameters are bound once)
+        self._iterate = lib().qc_scf_iterate
+        self._e, self._r = C.c_double(), C.c_double()
+        self._pe, self._pr = C.byref(self._e), C.byref(self._r)
 
     def iterate(self):
-        e, r = C.c_double(), C.c_double()
-        rc = lib().qc_scf_iterate(self._st, C.byref(e), C.byref(r))
-        if rc == QC_DIIS_SINGULAR:
-            raise RuntimeError("DIIS failed")
-        _check(rc, "qc_scf_iterate")
-        return e.value, r.value
+        rc = self._iterate(self._st, self._pe, self._pr)
+        if rc != 0:
+            if rc == QC_DIIS_SINGULAR:
+                raise RuntimeError("DIIS failed")
+            _check(rc, "qc_scf_iterate")
+        return self._e.value, self._r.value
 
     def orbital_energies(self, spin=0):
         w = np.zeros(self.system.n); _check(lib().qc_scf_orbital_energies(self._st, spin, w), "qc_scf_orbital_energies"); return w
