@@ -74,7 +74,10 @@ static void qc_bm_device_lists(const qc_system *S, int lcd, const std::vector<Qc
     }
 }
 
+struct QcLaunchPlan;
+static void drop_launch_plan(qc_system *S);
 static int upload_slots(qc_system *S) {
+    drop_launch_plan(S);
     for (auto &c : S->classes) {
         if (c.d_slots) { (void)hipFree(c.d_slots); c.d_slots = nullptr; }
         if (c.d_bundles) { (void)hipFree(c.d_bundles); c.d_bundles = nullptr; }
@@ -251,6 +254,7 @@ void qc_device_free(qc_system *S) {
     void *ptrs[] = {S->d_rplan, S->d_gidx, S->d_shells, S->d_pairdata, S->d_pairdataT, S->d_pspack, S->d_pairs, S->d_boys, S->d_D, S->d_G, S->d_Gtmp, S->d_Gred, S->d_Dj, S->d_flag, S->d_fxs};
     S->d_flag = nullptr; S->d_fxs = nullptr;
     delete S->issue_pool; S->issue_pool = nullptr;
+    drop_launch_plan(S);
     if (S->d_join) { (void)hipFree(S->d_join); S->d_join = nullptr; }
     if (S->h_join_timeout) { (void)hipHostFree(S->h_join_timeout); S->h_join_timeout = nullptr; }
     for (void *p : ptrs) if (p) (void)hipFree(p);
@@ -390,6 +394,10 @@ static Seg seg_of(const QcClass &c) {
     return sg;
 }
 
+struct QcLaunchPlan { std::vector<std::vector<int>> units; std::vector<std::vector<Seg>> segs; };
+
+static void drop_launch_plan(qc_system *S) { delete S->launch_plan; S->launch_plan = nullptr; }
+
 static int launch_segments(qc_system *S, int unit, const std::vector<Seg> &segs, hipStream_t st, const QcKernelArgs &base) {
     if (unit >= 2 * (QC_LPAIR + 1)) {      // bra-major launch
         QcBmArgs t{};
@@ -487,13 +495,18 @@ static void tier_units(qc_system *S, std::vector<std::vector<int>> &units) {
 // a hipEvent between consecutive launches; unit_ms (optional, 14 entries) times the real tier launches the same way.
 int qc_launch_fock_classes(qc_system *S, const QcFockArgs &fa, float *class_ms, float *unit_ms, bool nofork) {
     const QcKernelArgs a = base_args(S, fa);
-    std::vector<std::vector<int>> units;
-    tier_units(S, units);
-    auto segs_of = [&](const std::vector<int> &u) {
-        std::vector<Seg> v;
-        for (int ci : u) v.push_back(seg_of(S->classes[ci]));
-        return v;
-    };
+    // (the launch units and their segments only change with the work lists: kept between builds, dropped by upload_slots)
+    if (!S->launch_plan) {
+        S->launch_plan = new QcLaunchPlan();
+        tier_units(S, S->launch_plan->units);
+        for (const auto &u : S->launch_plan->units) {
+            std::vector<Seg> v;
+            for (int ci : u) v.push_back(seg_of(S->classes[ci]));
+            S->launch_plan->segs.push_back(std::move(v));
+        }
+    }
+    const std::vector<std::vector<int>> &units = S->launch_plan->units;
+    auto segs_of = [&](const std::vector<int> &u) -> const std::vector<Seg> & { return S->launch_plan->segs[&u - units.data()]; };
     if (class_ms || unit_ms) {
         const size_t nev = (class_ms ? S->classes.size() : units.size()) + 1;
         EventList evl;

@@ -168,6 +168,7 @@ struct qc_system {
     unsigned join_target = 0;
     int issue_threads = -1;                  // helper threads that issue a build's launches: -1 = by the size of the build (qc_fock.hip)
     bool join_by_events = false;             // dispatches are serialised here (qc_join_probe): the side streams are joined through events
+    struct QcLaunchPlan *launch_plan = nullptr; // launch units and their segments of the current work lists (qc_fock.hip)
     struct QcIssuePool *issue_pool = nullptr; // helper threads that issue a build's launches next to the caller (qc_fock.hip)
     void *comm = nullptr;                    // ncclComm_t
     std::vector<float> unit_ms;              // measured serial time of each launch unit (autotuned once per shard)
