@@ -607,13 +607,17 @@ int qc_launch_fock_classes(qc_system *S, const QcFockArgs &fa, float *class_ms, 
         int nused = 0;
         unsigned nside = 0;
         for (int k = 0; k < QC_NSTREAMS; ++k) if (!q[k].empty()) { ++nused; if (k != kmain) ++nside; }
-        // Measured (alternating runs on one box, means of six / two): H2O/cc-pVTZ builds 0.227 ms with three helpers against 0.204 ms
-        // issued by the caller alone - its 13 launches of 30-70 us each do better when they start 6-7 us apart than all at once -
-        // benzene/cc-pVDZ 1.470 against 1.494 ms.  So the helpers are for builds whose launches are long against the issue time.
+        // Measured (alternating runs on one box): H2O/cc-pVTZ builds 0.227 ms with three helpers against 0.204 ms issued by the caller
+        // alone (means of six) - its 13 launches of 30-70 us each do better when they start 6-7 us apart than all at once; benzene/cc-pVDZ
+        // iterations 1.646 against 1.641 ms (means of four; 1.470 against 1.494 ms of build in a first pair of runs), and on another box two
+        // of six runs with helpers showed 0.1-0.16 ms per pass outside the build and linear-algebra intervals.  Nothing gained: the
+        // helpers are OFF unless QC_ISSUE_THREADS asks for them (the code stays for larger systems, where the issue time of dozens of
+        // long launches could matter).
         const int nhelp_env = std::min(S->issue_threads, QC_NSTREAMS - 1);
         float serial_ms = 0.f;
         for (float x : S->unit_ms) serial_ms += x;
-        const int nhelp_want = nhelp_env >= 0 ? nhelp_env : (serial_ms > 1.0f ? 3 : 0);
+        const int nhelp_want = nhelp_env >= 0 ? nhelp_env : 0;
+        (void)serial_ms;
         const int nhelp = (event_join || (ev && per_unit) || nused < 3) ? 0 : std::min(nhelp_want, nused - 1);
         if (nhelp <= 0) {
             int used_set[QC_NSTREAMS], n = 0;
@@ -651,6 +655,13 @@ int qc_launch_fock_classes(qc_system *S, const QcFockArgs &fa, float *class_ms, 
             if (hipGetLastError() != hipSuccess) return QC_ERR_HIP;
         }
         if (ev) QC_HIP_CHECK(hipEventRecord(ev[1], S->stream));
+        static const bool join_check = getenv("QC_JOIN_CHECK") != nullptr;       // (diagnostic: after every build the device counter is the host's target)
+        if (join_check && !event_join) {
+            unsigned c = 0;
+            QC_HIP_CHECK(hipDeviceSynchronize());
+            QC_HIP_CHECK(hipMemcpy(&c, S->d_join, sizeof(c), hipMemcpyDeviceToHost));
+            if (c != S->join_target) { fprintf(stderr, "qchem_hip: join counter %u, target %u (%u side streams)\n", c, S->join_target, nside); return QC_ERR_HIP; }
+        }
         return QC_OK;
     };
     if (S->unit_ms.size() != units.size()) {
