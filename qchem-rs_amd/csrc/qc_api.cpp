@@ -421,14 +421,19 @@ int qc_eri_full(qc_system *S, double *out) {
 // the UHF density sum.  qc_fock_build_device recognises the densities and then goes straight to the class kernels.
 int qc_fock_prepare_device(qc_system *S, const double *dDa, const double *dDb, bool uhf, const void *owner, bool scale_done) {
     S->prepared = false;
+    S->prep_enqueued = false;
     if (!S->accum_fx) return QC_OK;
     const int n = S->nbasis;
     const size_t nn = (size_t)n * n, plane = (size_t)QC_NREP * (uhf ? 2 : 1) * nn;
     // (the closing fold of the last build zeroes the replicas it reads: no memset then)
-    if (!(S->gt_clean && S->gt_clean_nspin == (uhf ? 2 : 1))) QC_HIP_CHECK(hipMemsetAsync(S->d_Gtmp, 0, 2 * plane * sizeof(double), S->stream));
+    const bool zero = !(S->gt_clean && S->gt_clean_nspin == (uhf ? 2 : 1));
+    if (zero) QC_HIP_CHECK(hipMemsetAsync(S->d_Gtmp, 0, 2 * plane * sizeof(double), S->stream));
     S->gt_clean = true; S->gt_clean_nspin = uhf ? 2 : 1;
     if (!scale_done) qc_fx_scale(S->stream, n, dDa, uhf ? dDb : nullptr, S->imax, S->d_fxs);
     if (uhf) qc_axpby(S->stream, n, 1.0, dDa, 1.0, dDb, S->d_Dj);
+    // (the build that finds these preliminaries starts its side streams without a fork event: whoever lets the host go on before the
+    // handle's stream has drained must know that something was put on it here)
+    S->prep_enqueued = zero || !scale_done || uhf;
     S->prepared = true; S->prep_Da = dDa; S->prep_Db = uhf ? dDb : nullptr; S->prep_owner = owner;
     return QC_OK;
 }
@@ -801,6 +806,11 @@ static int scf_iterate(qc_scf_state *st, double *energy, double *rms_out) {
             }
         }
         st->pass_seq = want;
+        // The word says that the pass's last kernel is through.  If the preliminaries of the next build were put behind it (UHF: density
+        // sum and fixed-point unit; a memset after a mode change), the next build's side streams - which start without a fork event -
+        // must not overtake them: then the event behind them is waited for as well.  (RHF on this path has nothing there: the kernel
+        // leaves the fixed-point unit itself and the fold left the planes clean.)
+        if (!st->stored && S->prep_enqueued) QC_HIP_CHECK(wait_event(ev2));
     } else QC_HIP_CHECK(wait_event(ev2));
     const double th2 = now_ms();
     if (!ranks_agree()) { fprintf(stderr, "qchem_hip: rank %d: the ranks' SCF scalars differ - replicated state diverged\n", S->rank); return QC_ERR_RCCL; }

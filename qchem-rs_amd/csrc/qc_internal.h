@@ -167,6 +167,7 @@ struct qc_system {
     int *h_join_timeout = nullptr;           // pinned: set by a join that gave up (a side stream's launches never finished)
     unsigned join_target = 0;
     int issue_threads = -1;                  // helper threads that issue a build's launches: -1 = by the size of the build (qc_fock.hip)
+    bool prep_enqueued = false;              // qc_fock_prepare_device put work on the handle's stream (see scf_iterate)
     bool join_by_events = false;             // dispatches are serialised here (qc_join_probe): the side streams are joined through events
     struct QcLaunchPlan *launch_plan = nullptr; // launch units and their segments of the current work lists (qc_fock.hip)
     struct QcIssuePool *issue_pool = nullptr; // helper threads that issue a build's launches next to the caller (qc_fock.hip)
