@@ -1,5 +1,6 @@
 // qc_fock_bm.hip - "bra-major" ERI + Fock digestion kernels for the quartet classes whose narrower pair is an ss or a
-// ps pair and whose total Hermite order is <= QC_LREG (all tables in registers).  gfx950 / wave64.
+// ps pair and whose total Hermite order is <= QC_LREG (all tables in registers; ps kets against d.d / f.p bras reach order 5), and for the
+// p.p kets of large lists against p.p / d.s bras.  gfx950 / wave64.
 //
 // Same mathematics as qc_fock_kernel.h (molint::eri, rhf.rs:45, fused with compute_electronic_hamiltonian,
 // rhf.rs:152-167 / uhf.rs:210-227), different mapping.  The contraction inside the primitive-quartet loop costs
@@ -621,7 +622,7 @@ __global__ __launch_bounds__(qc_bm_waves(LCD, HI) * 64) void qc_fock_bm_kernel(c
     if constexpr (LCD == 0 && HI == 0) { switch (a.seg_lab[s]) { QC_BM_CASE(0) QC_BM_CASE(1) QC_BM_CASE(2) default: break; } }
     if constexpr (LCD == 0 && HI == 1) { switch (a.seg_lab[s]) { QC_BM_CASE(3) QC_BM_CASE(4) default: break; } }
     if constexpr (LCD == 1 && HI == 0) { switch (a.seg_lab[s]) { QC_BM_CASE(1) QC_BM_CASE(2) default: break; } }
-    if constexpr (LCD == 1 && HI == 1) { switch (a.seg_lab[s]) { QC_BM_CASE(3) default: break; } }
+    if constexpr (LCD == 1 && HI == 1) { switch (a.seg_lab[s]) { QC_BM_CASE(3) QC_BM_CASE(4) default: break; } }
     if constexpr (LCD == 2 && HI == 0) { switch (a.seg_lab[s]) { QC_BM_CASE(2) default: break; } }
 #undef QC_BM_CASE
 }

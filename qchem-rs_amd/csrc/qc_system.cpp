@@ -328,7 +328,13 @@ void qc_build_model(qc_system *S) {
             // ket of the column kernels (the wide one) stays the ket.  QC_NO_BM_PP: the column kernels keep them (A/B switch).
             const bool no_bm_pp = getenv("QC_NO_BM_PP") != nullptr;
             const bool w_is_pp = S->shells[S->pairA[wide]].L == 1 && S->shells[S->pairB[wide]].L == 1;
-            if (dn.L <= 1 && dn.L + dw.L <= QC_LREG) {
+            // (round 3: ps kets against d.d / f.p bras - total order 5: the table of 56 entries next to W[3][35] in a lane, one wave per SIMD
+            // like the d.p / f.s bras of that launch - in the bra-major form too.  The column kernels ran (ps|dd) at 1.7 TFLOP/s; measured,
+            // alternating runs on one box: H2O/cc-pVTZ iteration 0.3481 against 0.3529 ms (twelve runs each; the LCD = 4 bucket was 944 of the
+            // 1444 waves of its tier<1, 1> launch), benzene/cc-pVDZ build 1.398 against 1.390 ms (four each: one launch fewer, no change).
+            // QC_NO_BM_PS4 keeps them with the column kernels.)
+            const bool ps4 = getenv("QC_NO_BM_PS4") == nullptr && dn.L == 1 && dw.L == 4;
+            if ((dn.L <= 1 && dn.L + dw.L <= QC_LREG) || ps4) {
                 bucket[(((dw.L * (QC_LPAIR + 1) + dn.L) * 7) + 0) * 2 + 1].push_back(QcTask{wide, narrow});
             } else if (!no_bm_pp && S->pp_ok && dn.L == 2 && dw.L == 2 && w_is_pp && dw.K <= 63 && QC_LREG >= 4) {
                 bucket[(((2 * (QC_LPAIR + 1) + 2) * 7) + 0) * 2 + 1].push_back(QcTask{narrow, wide});
