@@ -1159,7 +1159,7 @@ int qc_fock_profile(qc_system *S, const double *dD, double *dG, int reps, float 
 int qc_unit_quartets(qc_system *S, int64_t *unit_quartets) {
     if (!S || !unit_quartets) return QC_ERR_INVALID;
     for (int u = 0; u < QC_NUNITS; ++u) unit_quartets[u] = 0;
-    for (const auto &c : S->classes) unit_quartets[qc_unit_of(c.LAB, c.LCD, c.bm)] += (int64_t)c.shard.size();
+    for (const auto &c : S->classes) unit_quartets[qc_build_unit_of(S, c.LAB, c.LCD, c.bm)] += (int64_t)c.shard.size();
     return QC_OK;
 }
 
@@ -1200,7 +1200,7 @@ int qc_fock_profile_tiers(qc_system *S, const double *dD, double *dG, int reps, 
     }
     for (const auto &c : S->classes) {
         if (c.shard.empty()) continue;
-        const int u = qc_unit_of(c.LAB, c.LCD, c.bm);
+        const int u = qc_build_unit_of(S, c.LAB, c.LCD, c.bm);
         if (unit_quartets) unit_quartets[u] += (int64_t)c.shard.size();
         if (unit_bytes) unit_bytes[u] += c.bytes_alg;
         if (unit_flops) unit_flops[u] += c.flops_alg;

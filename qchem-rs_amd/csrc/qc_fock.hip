@@ -21,6 +21,9 @@ int qc_launch_tier_lab3(int, int, size_t, hipStream_t, const QcTierArgs &);
 int qc_launch_tier_lab4(int, int, size_t, hipStream_t, const QcTierArgs &);
 int qc_launch_tier_lab5(int, int, size_t, hipStream_t, const QcTierArgs &);
 int qc_launch_tier_lab6(int, int, size_t, hipStream_t, const QcTierArgs &);
+int qc_launch_tier1_low(int, size_t, hipStream_t, const QcTierArgs &);
+int qc_launch_tier1_mid(int, size_t, hipStream_t, const QcTierArgs &);
+int qc_launch_tier1_hi(int, size_t, hipStream_t, const QcTierArgs &);
 
 // timing events that are destroyed on every path out of their scope
 struct EventList {
@@ -446,7 +449,7 @@ static int launch_segments(qc_system *S, int unit, const std::vector<Seg> &segs,
             static const int per_cu = getenv("QC_TIER_WG_PER_CU") ? std::max(1, atoi(getenv("QC_TIER_WG_PER_CU"))) : 32;     // (A/B switch)
             grid += std::min(waves, 256 * per_cu);
         }
-        t.seg_end[k] = grid; t.seg_code[k] = (sg.c->LCD << 4) | sg.c->LGC;
+        t.seg_end[k] = grid; t.seg_code[k] = (sg.c->LCD << 4) | sg.c->LGC; t.seg_lab[k] = sg.c->LAB;
         t.seg_nslots[k] = sg.nslots; t.seg_words[k] = sg.c->slot_words; t.seg_slots[k] = sg.d_slots;
         lds = std::max(lds, seg_lds);
         ++k;
@@ -455,6 +458,19 @@ static int launch_segments(qc_system *S, int unit, const std::vector<Seg> &segs,
     {   // (experiment switch: extra dynamic LDS per workgroup - does the build respond to the LDS the column kernels hold?)
         static const int pad_kb = getenv("QC_LDS_PAD_KB") ? atoi(getenv("QC_LDS_PAD_KB")) : 0;
         if (pad_kb > 0 && lds + pad_kb * 1024 <= QC_LDS_MAX) lds += pad_kb * 1024;
+    }
+    {   // segments of other bra classes than the unit's own: the merged wide-ket launch of the low bra classes
+        bool mixed = false;
+        for (const Seg &sg : segs) mixed = mixed || sg.c->LAB != unit / 2;
+        if (mixed) {
+            if (k > QC_MAXSEG) return QC_ERR_UNSUPPORTED;
+            static const bool lds_dbg2 = getenv("QC_LDS_DEBUG") != nullptr;
+            if (lds_dbg2) fprintf(stderr, "[lds] merged wide-ket launch of unit %d: %d workgroups (1 wave), %d bytes of LDS per workgroup, %d segments\n", unit, grid, lds, k);
+            if (unit == 2 * 2 + 1) return qc_launch_tier1_low(grid, (size_t)lds, st, t);
+            if (unit == 2 * 3 + 1) return qc_launch_tier1_mid(grid, (size_t)lds, st, t);
+            if (unit == 2 * 5 + 1) return qc_launch_tier1_hi(grid, (size_t)lds, st, t);
+            return QC_ERR_UNSUPPORTED;
+        }
     }
     // a wide-ket launch made of d.d / f.p-ket buckets only (no basis function above d): the kernel variant without the f-ket bodies
     int tier = unit % 2;
@@ -479,7 +495,7 @@ static void tier_units(qc_system *S, std::vector<std::vector<int>> &units) {
     for (size_t ci = 0; ci < S->classes.size(); ++ci) {
         const QcClass &c = S->classes[ci];
         if (c.slots.empty() && c.bundles.empty()) continue;
-        units[qc_unit_of(c.LAB, c.LCD, c.bm)].push_back((int)ci);
+        units[qc_build_unit_of(S, c.LAB, c.LCD, c.bm)].push_back((int)ci);
     }
     for (auto &u : units)
         std::stable_sort(u.begin(), u.end(), [&](int x, int y) {

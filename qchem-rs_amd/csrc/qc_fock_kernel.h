@@ -949,10 +949,11 @@ __device__ __forceinline__ void qc_fock_body(const QcKernelArgs &a, const QcSlot
 // footprint, several waves per SIMD) or LCD >= 4 (tier 1).  The grid is the concatenation of the buckets' block
 // ranges ("segments"); a workgroup finds its segment and runs that bucket's body.  Fewer, fuller launches: the eager
 // launch of ~35 separate class kernels was host-launch-bound (~10 us each).
-constexpr int QC_MAXSEG = 8;
+constexpr int QC_MAXSEG = 12;
 struct QcTierArgs {
     QcKernelArgs base;
     int nseg;
+    int seg_lab[QC_MAXSEG];        // bra class of the segment (the merged wide-ket launch of the low bra classes, qc_fock_tier1_low_kernel)
     int seg_end[QC_MAXSEG];        // exclusive prefix of workgroup counts
     int seg_code[QC_MAXSEG];       // (LCD << 4) | LGC
     int seg_nslots[QC_MAXSEG];
@@ -986,6 +987,58 @@ void qc_fock_tier_kernel(const QcTierArgs a) {
         switch (a.seg_code[s]) { QC_CASE(4, 5) QC_CASE(4, 6) default: break; }
     }
 #undef QC_CASE
+}
+
+// (round 3) ONE launch for the wide-ket buckets (LCD >= 4) of the bra classes LAB = 0, 1 and 2 of a basis with f functions: three launches of
+// 500-1100 one-wave workgroups at one wave per SIMD each, 27 + 35 + 54 us in-build on H2O/cc-pVTZ, chained on the side streams - their
+// workgroups now fill the chip together.  All three kernels ran at one wave per SIMD already (256 + 6 / 12 / 70 registers), so the merged
+// kernel costs no occupancy; every workgroup gets the largest segment's LDS (17 KB instead of 8-10 for the LAB <= 1 buckets: four waves per
+// CU, no limit).  The per-class launches of the profiling / set-up passes keep the per-LAB kernels.
+template <int V>     // (every instance lives in its own translation unit: gen/qc_fock_low1.hip, _mid1, _hi1)
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1)))
+void qc_fock_tier1_low_kernel(const QcTierArgs a) {
+    __builtin_amdgcn_s_setprio(3);
+    int s = 0;
+    while (s + 1 < a.nseg && (int)blockIdx.x >= a.seg_end[s]) ++s;
+    const int b0 = s ? a.seg_end[s - 1] : 0;
+    const int blk = blockIdx.x - b0, nblk = a.seg_end[s] - b0;
+    const QcSlot *slots = a.seg_slots[s];
+    const int nslots = a.seg_nslots[s], words = a.seg_words[s];
+#define QC_CASE(LAB, LCD, LGC) case ((LAB) << 8 | (LCD) << 4 | (LGC)): qc_fock_body<LAB, LCD, LGC>(a.base, slots, nslots, words, blk, nblk, a.seg_run[s], a.seg_rbrows[s]); break;
+    // V = 0: bra classes 0, 1, 2;  V = 1: 3 and 4 (994 + 350 workgroups on H2O/cc-pVTZ, 22 / 31 KB of LDS: still four per CU);  V = 2: 5 and 6
+    // (46 + 4 workgroups, 42 / 56 KB) - the f.d / f.f bras stay out of the launch of classes 3 and 4 because their LDS would halve its waves
+    if constexpr (V == 0) {
+        switch ((a.seg_lab[s] << 8) | a.seg_code[s]) {
+            QC_CASE(0, 5, 6) QC_CASE(0, 6, 6)
+            QC_CASE(1, 4, 5) QC_CASE(1, 4, 6) QC_CASE(1, 5, 6) QC_CASE(1, 6, 6)
+            QC_CASE(2, 4, 5) QC_CASE(2, 4, 6) QC_CASE(2, 5, 6) QC_CASE(2, 6, 6)
+            default: break;
+        }
+    } else if constexpr (V == 1) {
+        switch ((a.seg_lab[s] << 8) | a.seg_code[s]) {
+            QC_CASE(3, 4, 5) QC_CASE(3, 4, 6) QC_CASE(3, 5, 6) QC_CASE(3, 6, 6)
+            QC_CASE(4, 4, 5) QC_CASE(4, 4, 6) QC_CASE(4, 5, 6) QC_CASE(4, 6, 6)
+            default: break;
+        }
+    } else {
+        switch ((a.seg_lab[s] << 8) | a.seg_code[s]) {
+            QC_CASE(5, 4, 5) QC_CASE(5, 4, 6) QC_CASE(5, 5, 6) QC_CASE(5, 6, 6)
+            QC_CASE(6, 4, 5) QC_CASE(6, 4, 6) QC_CASE(6, 5, 6) QC_CASE(6, 6, 6)
+            default: break;
+        }
+    }
+#undef QC_CASE
+}
+template <int V>
+int qc_launch_tier1_low_impl(int grid, size_t lds, hipStream_t st, const QcTierArgs &a) {
+    static std::atomic<bool> raised{false};
+    if (lds > 48 * 1024 && !raised.load(std::memory_order_acquire)) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(qc_fock_tier1_low_kernel<V>), hipFuncAttributeMaxDynamicSharedMemorySize, QC_LDS_MAX);
+        if (e != hipSuccess) return QC_ERR_HIP;
+        raised.store(true, std::memory_order_release);
+    }
+    hipLaunchKernelGGL(qc_fock_tier1_low_kernel<V>, dim3(grid), dim3(64), lds, st, a);
+    return hipGetLastError() == hipSuccess ? QC_OK : QC_ERR_HIP;
 }
 
 template <int LAB, int TIER>

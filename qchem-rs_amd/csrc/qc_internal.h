@@ -202,6 +202,7 @@ struct qc_system {
     bool zombie = false;                     // qc_system_destroy was called while states were alive: the last qc_scf_end frees the handle
     int fock_mode = 0;                       // 0 direct (default), 1 stored tensor (the reference's own algorithm)
     int accum_fx = 1;                        // 1 (default): fixed-point, order-independent accumulation of G; 0: f64 atomics
+    bool merge_t1 = false;                    // the wide-ket launches of the bra classes 0, 1, 2 are one launch (set with the class lists)
     bool pp_ok = true;                        // every p.p pair's expansion blocks have the packed form the pp-ket bra-major kernel assumes
     std::string last_error;
 };
@@ -304,6 +305,12 @@ void qc_make_slots(const qc_system *S, const std::vector<QcTask> &tasks, int itm
 // (unit > 0: lanes take chunks of at most `unit` primitives of a ket pair, packed into the ketlist entry; 0: whole pairs)
 void qc_make_bundles(const qc_system *S, const std::vector<QcTask> &tasks, int itmax, std::vector<QcBundle> &bundles, std::vector<int> &ketlist, int unit = 0);
 inline int qc_unit_of(int LAB, int LCD, bool bm) { return bm ? 2 * (QC_LPAIR + 1) + 2 * LCD + (LAB >= 3 ? 1 : 0) : 2 * LAB + (LCD >= 4 ? 1 : 0); }
+// the launch a class belongs to inside a build: with `merge_t1` (bases with f functions) the wide-ket buckets of the bra classes 0 and 1 ride
+// in the launch of bra class 2, those of class 4 in the launch of class 3, those of class 6 in the launch of class 5 (qc_fock_tier1_low_kernel); the per-class launches of the profiling / set-up passes use qc_unit_of
+inline int qc_build_unit_of(const qc_system *S, int LAB, int LCD, bool bm) {
+    if (S->merge_t1 && !bm && LCD >= 4) return qc_unit_of(LAB <= 2 ? 2 : (LAB <= 4 ? 3 : 5), LCD, false);
+    return qc_unit_of(LAB, LCD, bm);
+}
 void qc_dots(hipStream_t st, int n, const double *x, const double *const *ys, int ny, double *out);  // device ptr list
 void qc_lincomb(hipStream_t st, int n, const double *const *Fs, const double *c, int m, double *out);   // out = sum c_i Fs_i
 void qc_scale_cols_invsqrt(hipStream_t st, int n, const double *U, const double *Lam, double *out);

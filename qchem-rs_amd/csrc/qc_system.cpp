@@ -363,6 +363,12 @@ void qc_build_model(qc_system *S) {
         c.tasks = std::move(v);
         S->classes.push_back(std::move(c));
     }
+    {   // one launch for the wide-ket buckets of the low bra classes (qc_fock_tier1_low_kernel) where there are f-ket buckets among them -
+        // without f functions those launches are the two-waves-per-SIMD variants and stay apart.  QC_NO_T1_MERGE: off (A/B switch).
+        int nseg[3] = {0, 0, 0}; bool fket = false;
+        for (const auto &c : S->classes) if (!c.bm && c.LCD >= 4) { ++nseg[c.LAB <= 2 ? 0 : (c.LAB <= 4 ? 1 : 2)]; fket = fket || c.LCD >= 5; }
+        S->merge_t1 = fket && std::max(nseg[0], std::max(nseg[1], nseg[2])) <= 12 && getenv("QC_NO_T1_MERGE") == nullptr;
+    }
     qc_build_shards(S);
 }
 
