@@ -420,7 +420,7 @@ static int launch_segments(qc_system *S, int unit, const std::vector<Seg> &segs,
             // persistent workgroups of `nw` waves: at most ~12 waves per CU, each wave strides through the bundle list
             static const int capw = getenv("QC_BM_WAVES_PER_CU") ? std::max(4, atoi(getenv("QC_BM_WAVES_PER_CU"))) : 12;   // (A/B switch)
             grid += std::min((sg.nslots + nw - 1) / nw, 256 * capw / nw);
-            t.seg_end[k] = grid; t.seg_lab[k] = sg.c->LAB; t.seg_bundles[k] = sg.d_bundles; t.seg_ketlist[k] = sg.d_ketlist;
+            t.seg_end[k] = grid; t.seg_lab[k] = sg.c->LAB; t.seg_lcd[k] = sg.c->LCD; t.seg_bundles[k] = sg.d_bundles; t.seg_ketlist[k] = sg.d_ketlist;
             t.seg_nbundles[k] = sg.nslots; t.seg_iwords[k] = sg.lds / 8;
             t.seg_rows[k] = rows;
             ++k;
@@ -429,6 +429,11 @@ static int launch_segments(qc_system *S, int unit, const std::vector<Seg> &segs,
         const int lds = QC_BM_LDS_TABLE + nw * wbytes;
         static const bool lds_dbg = getenv("QC_LDS_DEBUG") != nullptr;
         if (lds_dbg) fprintf(stderr, "[lds] bm<%d,%d>: %d workgroups x %d waves, %d bytes of LDS per workgroup (table %d, per wave %d)\n", v / 2, v % 2, grid, nw, lds, QC_BM_LDS_TABLE, wbytes);
+        {   // ss-ket segments in the launch of the ps kets / low bras: the merged kernel
+            bool mixed = false;
+            for (const Seg &sg : segs) mixed = mixed || sg.c->LCD != v / 2;
+            if (mixed) return (v == 2 && k <= QC_MAXSEG) ? qc_launch_bm(3, 0, grid, nw, (size_t)lds, st, t) : QC_ERR_UNSUPPORTED;
+        }
         return qc_launch_bm(v / 2, v % 2, grid, nw, (size_t)lds, st, t);
     }
     QcTierArgs t{};

@@ -15,6 +15,7 @@ struct QcBmArgs {
     int nseg;
     int seg_end[QC_MAXSEG];            // exclusive prefix of workgroup counts
     int seg_lab[QC_MAXSEG];
+    int seg_lcd[QC_MAXSEG];            // ket type of the segment (the merged launch qc_fock_bm_kernel<3, 0>: ss kets / high bras + ps kets / low bras)
     int seg_nbundles[QC_MAXSEG];
     int seg_iwords[QC_MAXSEG];         // doubles of one wave's I block (nab * ncd * 65)
     int seg_rows[QC_MAXSEG];           // most bra functions (na + nb) of the segment's bundles: rows of a wave's exchange buffer (0: none)

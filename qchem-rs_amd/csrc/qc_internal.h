@@ -202,6 +202,7 @@ struct qc_system {
     bool zombie = false;                     // qc_system_destroy was called while states were alive: the last qc_scf_end frees the handle
     int fock_mode = 0;                       // 0 direct (default), 1 stored tensor (the reference's own algorithm)
     int accum_fx = 1;                        // 1 (default): fixed-point, order-independent accumulation of G; 0: f64 atomics
+    bool merge_bm = false;                    // ... and the ss-ket / high-bra bundles ride in the launch of the ps kets / low bras
     bool merge_t1 = false;                    // the wide-ket launches of the bra classes 0, 1, 2 are one launch (set with the class lists)
     bool pp_ok = true;                        // every p.p pair's expansion blocks have the packed form the pp-ket bra-major kernel assumes
     std::string last_error;
@@ -309,6 +310,7 @@ inline int qc_unit_of(int LAB, int LCD, bool bm) { return bm ? 2 * (QC_LPAIR + 1
 // in the launch of bra class 2, those of class 4 in the launch of class 3, those of class 6 in the launch of class 5 (qc_fock_tier1_low_kernel); the per-class launches of the profiling / set-up passes use qc_unit_of
 inline int qc_build_unit_of(const qc_system *S, int LAB, int LCD, bool bm) {
     if (S->merge_t1 && !bm && LCD >= 4) return qc_unit_of(LAB <= 2 ? 2 : (LAB <= 4 ? 3 : 5), LCD, false);
+    if (S->merge_bm && bm && LCD == 0 && LAB >= 3) return qc_unit_of(2, 1, true);       // ss kets / high bras ride with the ps kets / low bras (qc_fock_bm_kernel<3, 0>)
     return qc_unit_of(LAB, LCD, bm);
 }
 void qc_dots(hipStream_t st, int n, const double *x, const double *const *ys, int ny, double *out);  // device ptr list

@@ -368,6 +368,9 @@ void qc_build_model(qc_system *S) {
         int nseg[3] = {0, 0, 0}; bool fket = false;
         for (const auto &c : S->classes) if (!c.bm && c.LCD >= 4) { ++nseg[c.LAB <= 2 ? 0 : (c.LAB <= 4 ? 1 : 2)]; fket = fket || c.LCD >= 5; }
         S->merge_t1 = fket && std::max(nseg[0], std::max(nseg[1], nseg[2])) <= 12 && getenv("QC_NO_T1_MERGE") == nullptr;
+        bool has01 = false, has10 = false;
+        for (const auto &c : S->classes) if (c.bm) { has01 = has01 || (c.LCD == 0 && c.LAB >= 3); has10 = has10 || (c.LCD == 1 && c.LAB <= 2); }
+        S->merge_bm = has01 && has10 && getenv("QC_NO_BM_MERGE") == nullptr;
     }
     qc_build_shards(S);
 }
