@@ -23,7 +23,7 @@ import shutil
 import sys
 
 FP64_PEAK_TF, HBM_PEAK_GBS, CLOCK_GHZ, N_SIMD = 78.6, 8000.0, 2.4, 256 * 4
-FOCK = ("qc_fock_tier_kernel", "qc_fock_bm_kernel")
+FOCK = ("qc_fock_tier_kernel", "qc_fock_bm_kernel", "qc_fock_tier1_low_kernel")       # (the last: merged wide-ket launches of round 3)
 
 
 def short(name):
