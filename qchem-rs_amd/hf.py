@@ -265,7 +265,9 @@ PROFILE_UNITS = 20   # QC_PROFILE_UNITS in include/qchem_hip.h
 
 
 def unit_name(u: int) -> str:
-    """Kernel instantiation behind launch unit `u` of qc_fock_profile_tiers."""
+    """Kernel instantiation behind launch unit `u` of qc_fock_profile_tiers.  (Inside a build some units share a launch - the wide-ket
+    buckets of several bra classes, the ss-ket / high-bra with the ps-ket / low-bra bundles, DESIGN.md 3.1 - and are then reported under
+    the unit of the group's last member: its name here, the merged kernel qc_fock_tier1_low_kernel<V> / qc_fock_bm_kernel<3, 0> in a trace.)"""
     return "qc_fock_tier_kernel<%d, %d>" % (u // 2, u % 2) if u < 14 else "qc_fock_bm_kernel<%d, %d>" % ((u - 14) // 2, (u - 14) % 2)
 
 
