@@ -76,7 +76,7 @@ def timed_scf_passes(q, sysh, host, sync, steps, warmup):
     """`steps` timed passes of real SCF runs (see the module docstring); returns elapsed seconds and what the passes were."""
     # warm-up: one whole SCF run (code upload, stream tuning, Schwarz pass), at least `warmup` passes; it also tells how many
     # runs the timed region needs
-    st = q.ScfStepper(sysh)
+    st = q.ScfStepper(sysh, stop_rule=EPS)
     kconv = None
     for k in range(max(warmup, 200)):
         _, rms = st.iterate()
@@ -86,7 +86,9 @@ def timed_scf_passes(q, sysh, host, sync, steps, warmup):
             break
     st.close()
     per_run = (kconv + 1) if kconv is not None else steps
-    runs = [q.ScfStepper(sysh) for _ in range((steps + per_run - 1) // per_run)]          # set-up outside the timed region
+    # (stop_rule: this loop ends a run once rms < EPS - said to the library, which issues each pass's successor build ahead of time and
+    # can then empty the one queued behind a converging pass on the device instead of running it for nothing)
+    runs = [q.ScfStepper(sysh, stop_rule=EPS) for _ in range((steps + per_run - 1) // per_run)]          # set-up outside the timed region
     host.barrier(); sync()
     t0 = time.perf_counter()
     done, cur, passes, restarts = 0, 0, [], 0
@@ -99,13 +101,16 @@ def timed_scf_passes(q, sysh, host, sync, steps, warmup):
             cur += 1; k_in_run = 0; restarts += 1
     sync(); host.barrier()
     dt = host.max(time.perf_counter() - t0)
-    fock = sum(r.timings()["fock"] for r in runs) / steps          # hipEvent ms inside the passes
-    linalg = sum(r.timings()["linalg"] for r in runs) / steps
+    cs = [r.counters() for r in runs]
+    fock = sum(c["fock"] for c in cs) / max(1.0, sum(c["builds_timed"] for c in cs))          # hipEvent ms inside the passes
+    linalg = sum(c["linalg"] for c in cs) / steps
     D = runs[0].density(0)
     for r in runs:
         r.close()
     info = {"passes_timed": "SCF passes %s of %d run(s) from the Hueckel guess, stopping rule rms < %g (converges at pass %s)"
-            % ("0..%d" % max(passes), restarts + 1, EPS, kconv), "converges_at_pass": kconv}
+            % ("0..%d" % max(passes), restarts + 1, EPS, kconv), "converges_at_pass": kconv,
+            "speculative_builds": {"consumed": int(sum(c["spec_hits"] for c in cs)), "discarded": int(sum(c["spec_lost"] for c in cs)),
+                                   "builds_timed": int(sum(c["builds_timed"] for c in cs))}}
     return dt, fock, linalg, D, info
 
 
@@ -446,7 +451,7 @@ def main():
         "data": "fixture molecule + basis files under data/ (no randomness); densities are the SCF's own iterates from the Hueckel guess",
         "config": {"workload": WORKLOADS[key][2] + " direct-SCF iteration", "n_basis": res["n_basis"], "unique_quartets": res["unique_quartets"],
                    "quartets_after_schwarz": res["quartets_after_schwarz"], "schwarz_tau": res["schwarz_tau"],
-                   "passes": res["timed"]["passes_timed"],
+                   "passes": res["timed"]["passes_timed"], "spec": res["timed"].get("speculative_builds"),
                    "parallelism": "1 GPU" if world == 1 else "quartet shards over %d GPUs + 1 RCCL all-reduce of G per build" % world},
         "iter_breakdown_ms": res["iter_breakdown_ms"],
         "roofline": res["roofline"],

@@ -115,6 +115,7 @@ typedef struct {
     size_t iterations;               /* 0-based index of the converging iteration (rhf.rs:101) */
     /* timings of the run, milliseconds (not in the reference; the CLI prints its own wall-clock, main.rs:79-101) */
     double ms_setup, ms_fock_total, ms_linalg_total, ms_total;
+    double ms_tuner;                 /* of ms_total: host time of the builds that tuned the stream assignment (first build of a geometry) */
 } qc_hf_output;
 
 int qc_scf_rhf(qc_system *sys, const qc_hf_config *cfg, qc_hf_output *out);
@@ -140,6 +141,15 @@ int qc_scf_matrix(qc_scf_state *st, int which, double *out_nxn);
  * n_alpha / n_beta extension.  RHF states return 0. */
 int qc_scf_spin_square(qc_scf_state *st, double *s2);
 int qc_scf_timings(qc_scf_state *st, double *ms_setup, double *ms_fock, double *ms_linalg);
+/* The stopping rule of the host's loop, told to the library: "I stop calling qc_scf_iterate once rms < epsilon (RHF, rhf.rs:94) /
+ * rms / 2 < epsilon (UHF, uhf.rs:139)".  Optional, and it changes no result.  qc_scf_iterate issues the NEXT pass's Fock build behind
+ * the pass it is asked for, before it knows how that pass ends (the host is then off the pass boundary); with the rule known, the
+ * kernel that ends a pass evaluates it on the device and empties the build queued behind a converging pass instead of running it for
+ * nothing.  A host that goes on regardless gets a regular build.  epsilon = 0 (default): no rule; qc_scf_rhf / qc_scf_uhf set theirs. */
+int qc_scf_set_stop_rule(qc_scf_state *st, double epsilon);
+/* out[0..7] = ms_setup, ms_fock (builds that contained a tuner run are left out), ms_linalg, builds counted in ms_fock, host ms of
+ * the tuner runs, passes done, speculative builds consumed, speculative builds discarded */
+int qc_scf_counters(qc_scf_state *st, double out[8]);
 void qc_scf_end(qc_scf_state *st);
 
 /* ---- Fock mode of the SCF drivers on this handle.  0 (default): direct - quartets are evaluated and digested every pass.

@@ -105,6 +105,11 @@ struct DeviceDiis {
         slots.push_front(s);
         *d_err = pool[2 * s]; *d_fock = pool[2 * s + 1];
     }
+    // the buffers next_sample will hand out next (the speculative build of the next pass writes its F = H + G there)
+    void peek_next(double **d_err, double **d_fock) const {
+        const int s = (int)slots.size() == maxlen ? slots.back() : (int)slots.size();
+        *d_err = pool[2 * s]; *d_fock = pool[2 * s + 1];
+    }
     // enqueues: new row of B, coefficient solve, extrapolated Fock matrix into d_out
     int extrapolate(hipStream_t st, double *d_out, int *d_flag) {
         const int m = (int)slots.size();
@@ -252,7 +257,8 @@ int roothaan_enqueue(qc_system *S, ScfWork &W, DeviceDiis &diis, const double *d
 
 // The same step for n <= QC_SMALL_MAXN, density / energy / rms of rhf.rs:78-88 included: one launch when the eigensolve is a refinement from
 // the previous vectors, pre | tridiagonal start | refine + post when it starts cold, pre | Jacobi kernel | post for the rotation-only runs.
-struct SmallTail { int nocc; double dfac; double *Dn; const double *Dold; double *scal_out; int *ctl_all, *ctl_out; double *fxs_out; unsigned *seq_out = nullptr; unsigned seq = 0; };
+struct SmallTail { int nocc; double dfac; double *Dn; const double *Dold; double *scal_out; int *ctl_all, *ctl_out; double *fxs_out; unsigned *seq_out = nullptr; unsigned seq = 0;
+                   unsigned *fork_words = nullptr; unsigned fork_seq = 0; double eps = 0.0; unsigned *h_cancel = nullptr; };
 int roothaan_small(qc_system *S, ScfWork &W, DeviceDiis &diis, const double *dG, const double *dD, double *dw_out, double *dC, int spin,
                    double *dE, double *dF, bool have_F, const SmallTail &tl) {
     const int n = S->nbasis;
@@ -270,6 +276,7 @@ int roothaan_small(qc_system *S, ScfWork &W, DeviceDiis &diis, const double *dG,
     a.Cp_out = W.CpNew[spin].p; a.w_out = dw_out; a.C_out = dC; a.Dn = tl.Dn; a.Dold = tl.Dold; a.nocc = tl.nocc; a.dfac = tl.dfac;
     a.scal_out = tl.scal_out; a.ctl_all = tl.ctl_all; a.ctl_out = tl.ctl_out; a.fxs_out = tl.fxs_out; a.imax = S->imax;
     a.seq_out = tl.seq_out; a.seq = tl.seq;
+    a.fork_words = tl.fork_words; a.fork_seq = tl.fork_seq; a.eps = tl.eps; a.h_cancel = tl.h_cancel;
     W.cold[spin] = false;
     static const bool force_jacobi = getenv("QC_EIG_JACOBI") != nullptr;
     int rc;
@@ -278,7 +285,7 @@ int roothaan_small(qc_system *S, ScfWork &W, DeviceDiis &diis, const double *dG,
         return qc_scf_small_launch(st, a);
     }
     QcSmallArgs pre = a;
-    pre.phases = 1; pre.ctl_all = nullptr; pre.seq_out = nullptr;
+    pre.phases = 1; pre.ctl_all = nullptr; pre.seq_out = nullptr; pre.fork_words = nullptr;
     if ((rc = qc_scf_small_launch(st, pre)) != QC_OK) return rc;
     if (qc_tri_ok(n) && !force_jacobi && !W.rotations_only) {
         W.cold[spin] = true;
@@ -439,7 +446,7 @@ int qc_fock_prepare_device(qc_system *S, const double *dDa, const double *dDb, b
 }
 
 int qc_fock_build_device(qc_system *S, const double *dDa, const double *dDb, double *dGa, double *dGb, bool uhf, int *twin_cache,
-                         const double *dH, double *dFa, double *dFb, bool *f_done, const void *owner) {
+                         const double *dH, double *dFa, double *dFb, bool *f_done, const void *owner, unsigned fork_seq) {
     const int n = S->nbasis;
     const size_t nn = (size_t)n * n;
     hipStream_t st = S->stream;
@@ -470,8 +477,11 @@ int qc_fock_build_device(qc_system *S, const double *dDa, const double *dDb, dou
     const size_t plane = (size_t)QC_NREP * nspin * nn;          // one accumulator plane: [replica][spin][n*n]
     const bool ready = fx && S->prepared && owner != nullptr && S->prep_owner == owner && S->prep_Da == dDa && S->prep_Db == (uhf ? dDb : nullptr);   // qc_fock_prepare_device ran for these
     S->prepared = false;
+    // (a speculative build starts on the device's word, not on the host's: its preliminaries must be in the stream in front of the
+    // kernel that releases the fork word - qc_fock_prepare_device for exactly these densities - and the planes clean)
+    if (fork_seq && !(ready && S->gt_clean)) return QC_ERR_INVALID;
     QcFockArgs a{};
-    a.nrep = QC_NREP; a.rep_stride = nspin * nn; a.fxs = fxs; a.fx_lo = plane;
+    a.nrep = QC_NREP; a.rep_stride = nspin * nn; a.fxs = fxs; a.fx_lo = plane; a.fork_seq = fork_seq;
     if (!ready) {
         QC_HIP_CHECK(hipMemsetAsync(S->d_Gtmp, 0, (fx ? 2 : 1) * plane * sizeof(double), st));
         if (fx) qc_fx_scale(st, n, dDa, uhf ? dDb : nullptr, S->imax, S->d_fxs);      // this build's fixed-point unit, from its densities
@@ -498,8 +508,10 @@ int qc_fock_build_device(qc_system *S, const double *dDa, const double *dDb, dou
     qc_reduce_replicas(st, nspin * nn, QC_NREP, nspin * nn, S->d_Gtmp, S->d_Gred, fx, plane);
     if (S->comm) {
         // partial Fock matrices -> full, one all-reduce per build ([Ga|Gb] concatenated for UHF; hi and lo planes back to
-        // back).  Fixed-point partials are summed as integers: the result is bit-identical on every rank and to the
-        // single-GPU build, whatever the ring order.
+        // back).  Fixed-point partials are summed as integers: the result is bit-identical on every rank, whatever the ring
+        // order.  (Against a build with another shard layout - the single-GPU build included - it agrees to ~1e-13, not bit for
+        // bit: the bra-major kernels pre-sum the exchange rows of a 64-ket bundle in an f64 LDS buffer, and which kets share a
+        // bundle depends on the shard.)
         if (qc_rccl().AllReduce(S->d_Gred, S->d_Gred, (fx ? 2 : 1) * nspin * nn, fx ? ncclInt64 : ncclDouble, ncclSum, (ncclComm_t)S->comm, st) != ncclSuccess) return QC_ERR_RCCL;
     }
     qc_symmetrize_add(st, n, S->d_Gred, nspin * nn, dGa, dH, dH ? dFa : nullptr, fxs);
@@ -534,6 +546,8 @@ int qc_fock_rhf(qc_system *S, const double *D, double *G) {
     if (rc != QC_OK) return rc;
     QC_HIP_CHECK(hipMemcpyAsync(G, S->d_G, nn * sizeof(double), hipMemcpyDeviceToHost, S->stream));
     QC_HIP_CHECK(hipStreamSynchronize(S->stream));
+    if ((rc = qc_join_check(S)) != QC_OK) return rc;        // (a join that gave up folded an incomplete matrix: this call fails)
+    qc_gate_quiet(S);
     return QC_OK;
 }
 
@@ -549,6 +563,8 @@ int qc_fock_uhf(qc_system *S, const double *Da, const double *Db, double *Ga, do
     QC_HIP_CHECK(hipMemcpyAsync(Ga, S->d_G, nn * sizeof(double), hipMemcpyDeviceToHost, S->stream));
     QC_HIP_CHECK(hipMemcpyAsync(Gb, S->d_G + nn, nn * sizeof(double), hipMemcpyDeviceToHost, S->stream));
     QC_HIP_CHECK(hipStreamSynchronize(S->stream));
+    if ((rc = qc_join_check(S)) != QC_OK) return rc;
+    qc_gate_quiet(S);
     return QC_OK;
 }
 
@@ -584,7 +600,18 @@ struct qc_scf_state {
     bool uhf = false;
     int nocc[2] = {0, 0};
     ScfWork W;
-    DevBuf D[2], Dn[2], G, Cs, ws;             // densities are double-buffered per spin: D <-> Dn swap when a pass is accepted
+    DevBuf D[2], Dn[2], Gb[2], Cs, ws;         // densities are double-buffered per spin: D <-> Dn swap when a pass is accepted
+    int g_cur = 0;                             // G of this pass lives in Gb[g_cur]; the speculative build of the next pass writes Gb[g_cur ^ 1]
+    double eps_hint = 0.0;                     // > 0: the host stops once the reference's stopping rule holds at this epsilon (qc_scf_set_stop_rule)
+    unsigned *h_cancel = nullptr;              // pinned: number of the speculative build the device cancelled (the pass in front of it met the rule)
+    // Speculative build of the next pass behind this pass's Roothaan step (scf_iterate).  OFF by default: built, parity-tested, and
+    // measured SLOWER on MI355X (H2O/cc-pVTZ 0.38-0.44 ms per iteration against 0.31) - DESIGN.md 3.1 says why.  QC_SPEC=1 (read per
+    // SCF state) switches it on.
+    bool spec_on = getenv("QC_SPEC") != nullptr && getenv("QC_NO_SPEC") == nullptr;
+    int64_t spec_hits = 0, spec_lost = 0, builds_timed = 0, passes = 0;
+    double ms_tuner = 0;
+    bool cur_build_tuned = false, pend_build_tuned = false;   // the build of the current / the pending timing set contained a tuner run
+    unsigned cur_build_gen = 0, pend_build_gen = 0;           // ... and ran under this stream assignment (qc_system::assign_gen)
     DevBuf T4, TK, Dtot;                       // stored mode: RHF T = I - I^x / 2; UHF I and its exchange-permuted copy
     bool stored = false;
     int twin = -1;                             // UHF spin-twin decision, taken at the first build
@@ -601,8 +628,10 @@ struct qc_scf_state {
     ~qc_scf_state() {
         if (S && S->prep_owner == this) { S->prepared = false; S->prep_owner = nullptr; }
         delete diis[0]; delete diis[1];
-        if (S && S->stream) (void)hipStreamSynchronize(S->stream);
+        if (S && S->spec.owner == this) { S->spec.pending = false; S->spec.owner = nullptr; }
+        if (S && S->stream) { (void)hipStreamSynchronize(S->stream); qc_gate_quiet(S); }
         for (auto &set : evs) for (hipEvent_t e : set) if (e) (void)hipEventDestroy(e);
+        if (h_cancel) (void)hipHostFree(h_cancel);
     }
 };
 static void system_free(qc_system *S);
@@ -636,7 +665,9 @@ static int scf_begin(qc_system *S, bool uhf, int n_alpha, int n_beta, qc_scf_sta
     st->W.small_fused = n <= QC_SMALL_MAXN && !st->W.rotations_only && getenv("QC_NO_SMALL_FUSED") == nullptr;
     if ((rc = st->W.init(n)) != QC_OK) return rc;
     for (int s = 0; s < nspin; ++s) if (st->D[s].alloc(nn) != QC_OK || st->Dn[s].alloc(nn) != QC_OK) return QC_ERR_HIP;
-    if (st->G.alloc(nspin * nn) != QC_OK || st->Cs.alloc(nspin * nn) != QC_OK || st->ws.alloc(nspin * n) != QC_OK) return QC_ERR_HIP;
+    if (st->Gb[0].alloc(nspin * nn) != QC_OK || st->Gb[1].alloc(nspin * nn) != QC_OK || st->Cs.alloc(nspin * nn) != QC_OK || st->ws.alloc(nspin * n) != QC_OK) return QC_ERR_HIP;
+    QC_HIP_CHECK(hipHostMalloc(&st->h_cancel, sizeof(unsigned), hipHostMallocDefault));
+    *st->h_cancel = 0;
     std::vector<double> h_eht;
     if ((rc = scf_setup(S, st->W, h_eht)) != QC_OK) return rc;           // rhf.rs:41-49
     for (int s = 0; s < nspin; ++s)                                       // rhf.rs:50 / uhf.rs:60-63
@@ -687,16 +718,33 @@ static void scf_flush_timing(qc_scf_state *st) {
     hipEvent_t *e = st->evs[st->pending_set];
     float ms_f = 0, ms_l = 0;
     if (hipEventSynchronize(e[2]) != hipSuccess) return;
-    if (hipEventElapsedTime(&ms_f, e[0], e[1]) == hipSuccess) st->ms_fock += ms_f;
+    const bool have_f = hipEventElapsedTime(&ms_f, e[0], e[1]) == hipSuccess;
     if (hipEventElapsedTime(&ms_l, e[1], e[2]) == hipSuccess) st->ms_linalg += ms_l;
-    if (!st->stored && !st->S->comm) qc_fock_feedback(st->S, ms_f);
+    if (!have_f) return;
+    // (a build that contained a tuner run is not a sample of the build time: neither for the totals nor for the tuner's online choice)
+    if (st->pend_build_tuned) return;
+    st->ms_fock += ms_f; st->builds_timed += 1;
+    if (!st->stored && !st->S->comm) qc_fock_feedback(st->S, ms_f, st->pend_build_gen);
 }
 
 // Wait for an event by polling (what hipStreamSynchronize does too): a parked thread's wake-up latency is longer
-// than a whole SCF pass of a small molecule.
+// than a whole SCF pass of a small molecule.  Not for ever: a kernel that never finishes is an error of the call, not a host core
+// pinned for good (QC_HOST_WAIT_LIMIT_S, default 120 s; the device-side waits give up earlier and say why).
+static double host_wait_limit_ms() {
+    static const double lim = getenv("QC_HOST_WAIT_LIMIT_S") ? atof(getenv("QC_HOST_WAIT_LIMIT_S")) * 1e3 : 120e3;
+    return lim;
+}
 static hipError_t wait_event(hipEvent_t ev) {
     hipError_t e;
-    while ((e = hipEventQuery(ev)) == hipErrorNotReady) {}
+    unsigned spins = 0;
+    double t0 = 0.0;
+    while ((e = hipEventQuery(ev)) == hipErrorNotReady) {
+        if ((++spins & 0x3fff) == 0) {
+            const double t = now_ms();
+            if (t0 == 0.0) t0 = t;
+            else if (t - t0 > host_wait_limit_ms()) { fprintf(stderr, "qchem_hip: an SCF pass did not finish within %.0f s\n", host_wait_limit_ms() * 1e-3); return hipErrorLaunchTimeOut; }
+        }
+    }
     return e;
 }
 
@@ -705,7 +753,21 @@ static hipError_t wait_event(hipEvent_t ev) {
 // The whole pass is enqueued without looking at the device; one synchronisation at its end returns the energy, the rms
 // and the control words (DIIS failure, eigen-refinement outcome).  Launch latency of ~50 small kernels then overlaps with
 // their execution instead of adding to it.
-static int scf_iterate(qc_scf_state *st, double *energy, double *rms_out) {
+//
+// Round 4: the host leaves the pass boundary.  Behind the pass's Roothaan step - before waiting for it - the NEXT pass's Fock build is
+// issued speculatively from the density buffer the step is about to fill: its side streams start with a one-lane kernel that waits for
+// the fork word which the step's last kernel releases (qc_fock.hip, "Device-side fork"), the handle's own chain simply follows in
+// stream order.  All launches of build k + 1 then sit in their queues when pass k's densities become final (before: 26 us of idle GPU per
+// pass while the host saw the pass end and turned around, and launches arriving 8 us apart).  The next call of this function finds its
+// build in flight and goes straight to the Roothaan step.  What makes it safe:
+//  * G is double-buffered (the repeat branch below still needs the old G for the energy); F = H + G goes to the DIIS slot the next pass
+//    will claim, which this pass only reads in front of it in stream order;
+//  * a repeat of the eigensolve (rotations wanted) changes the density: the speculative build is then discarded - it ran into the
+//    accumulator planes and its closing kernel left them clean - and the next pass builds again;
+//  * when the host has said where it stops (qc_scf_set_stop_rule; scf_run does), the kernel that ends the pass evaluates the same
+//    rule and cancels the build behind a converged pass on the device: its class kernels return at once;
+//  * may_continue = false (scf_run's last allowed pass): nothing is issued behind the pass.
+static int scf_iterate(qc_scf_state *st, double *energy, double *rms_out, bool may_continue = true) {
     qc_system *S = st->S;
     ScfWork &W = st->W;
     const int n = S->nbasis;
@@ -717,31 +779,52 @@ static int scf_iterate(qc_scf_state *st, double *energy, double *rms_out) {
     st->ev_cur ^= 1;
     hipEvent_t *const ev = st->evs[st->ev_cur];
     hipEvent_t const ev0 = ev[0], ev1 = ev[1], ev2 = ev[2];
-    QC_HIP_CHECK(hipEventRecord(ev0, sm));
+    double *const Gcur = st->Gb[st->g_cur].p, *const Gnext = st->Gb[st->g_cur ^ 1].p;
     double *dE[2] = {nullptr, nullptr}, *dF[2] = {nullptr, nullptr};       // this pass's DIIS sample buffers (error, Fock matrix) per spin
     for (int s = 0; s < nspin; ++s) st->diis[s]->next_sample(&dE[s], &dF[s]);
     bool have_F = false;
+    // the build of this pass may be in flight already (issued speculatively by the previous pass)
+    bool spec_hit = false;
+    {
+        qc_system::QcSpec &sp = S->spec;
+        if (sp.pending && sp.owner == st) {
+            const bool cancelled = __atomic_load_n(st->h_cancel, __ATOMIC_ACQUIRE) == sp.seq;     // (the host goes on although its own rule held: build again)
+            spec_hit = !st->stored && !cancelled && sp.Da == st->D[0].p && sp.Db == (st->uhf ? st->D[1].p : nullptr) && sp.Ga == Gcur;
+            sp.pending = false;
+            if (spec_hit) { have_F = sp.f_done; st->spec_hits += 1; }
+            else { st->spec_lost += 1; S->prepared = false; }      // (its kernels may still run: the build below forks off the handle's stream)
+        }
+    }
     // G of every spin from the *old* densities
-    if (st->stored) {
+    if (spec_hit) {
+        // (ev0 / ev1 of this set were recorded around the build when it was issued)
+    } else if (st->stored) {
+        QC_HIP_CHECK(hipEventRecord(ev0, sm));
         if (st->uhf) {   // uhf.rs:216-226: G_s = <I, D_s + D_s'> - <I^x, D_s>
             qc_axpby(sm, n, 1.0, st->D[0].p, 1.0, st->D[1].p, st->Dtot.p);
             qc_axpby(sm, n, -1.0, st->D[0].p, 0.0, nullptr, W.t1.p);
-            qc_tensor_gemv(sm, n, st->T4.p, st->Dtot.p, st->TK.p, W.t1.p, st->G.p);
+            qc_tensor_gemv(sm, n, st->T4.p, st->Dtot.p, st->TK.p, W.t1.p, Gcur);
             qc_axpby(sm, n, -1.0, st->D[1].p, 0.0, nullptr, W.t1.p);
-            qc_tensor_gemv(sm, n, st->T4.p, st->Dtot.p, st->TK.p, W.t1.p, st->G.p + nn);
+            qc_tensor_gemv(sm, n, st->T4.p, st->Dtot.p, st->TK.p, W.t1.p, Gcur + nn);
         } else {
-            qc_tensor_gemv(sm, n, st->T4.p, st->D[0].p, nullptr, nullptr, st->G.p);   // rhf.rs:152-167
+            qc_tensor_gemv(sm, n, st->T4.p, st->D[0].p, nullptr, nullptr, Gcur);   // rhf.rs:152-167
         }
-    } else if ((rc = qc_fock_build_device(S, st->D[0].p, st->uhf ? st->D[1].p : nullptr, st->G.p, st->uhf ? st->G.p + nn : nullptr, st->uhf,
-                                          &st->twin, W.H.p, dF[0], dF[1], &have_F, st)) != QC_OK) return rc;
-    // (Enqueueing the *next* pass's build here, ahead of the wait below, was tried: its side-stream launches then sit
-    // behind unsignalled barriers while the main queue still works, and with 8 hardware queues on 4 pipes the blocked
-    // queues stall their pipe neighbours - 1.6 ms per pass instead of 0.6.)
+        st->cur_build_tuned = false; st->cur_build_gen = S->assign_gen;
+    } else {
+        QC_HIP_CHECK(hipEventRecord(ev0, sm));
+        const int tunes0 = S->tune_count;
+        const double tt0 = now_ms();
+        if ((rc = qc_fock_build_device(S, st->D[0].p, st->uhf ? st->D[1].p : nullptr, Gcur, st->uhf ? Gcur + nn : nullptr, st->uhf,
+                                       &st->twin, W.H.p, dF[0], dF[1], &have_F, st)) != QC_OK) return rc;
+        st->cur_build_tuned = S->tune_count != tunes0;
+        if (st->cur_build_tuned) st->ms_tuner += now_ms() - tt0;
+        st->cur_build_gen = S->assign_gen;
+    }
     scf_flush_timing(st);                                                 // (the previous pass's times, now that this pass's build is out)
-    QC_HIP_CHECK(hipEventRecord(ev1, sm));
+    if (!spec_hit) QC_HIP_CHECK(hipEventRecord(ev1, sm));
     if (!W.small_fused)
         for (int s = 0; s < nspin; ++s)                                   // (the control words were cleared by the previous pass)
-            if ((rc = roothaan_enqueue(S, W, *st->diis[s], st->G.p + s * nn, st->D[s].p, st->ws.p + s * n, st->Cs.p + s * nn, s, dE[s], dF[s], have_F)) != QC_OK) return rc;
+            if ((rc = roothaan_enqueue(S, W, *st->diis[s], Gcur + s * nn, st->D[s].p, st->ws.p + s * n, st->Cs.p + s * nn, s, dE[s], dF[s], have_F)) != QC_OK) return rc;
     int *h_ctl = reinterpret_cast<int *>(W.h_scal + 4);
     // Multi-rank runs take every decision (convergence, DIIS failure, eigensolve mode, repeat) from the SAME numbers on every
     // rank: the pass scalars go to device memory, are all-reduced as bit patterns (max) together with their complements - so a
@@ -755,7 +838,7 @@ static int scf_iterate(qc_scf_state *st, double *energy, double *rms_out) {
         if (st->nocc[s] > 0) qc_gemm(sm, n, n, st->nocc[s], st->uhf ? 1.0 : 2.0, st->Cs.p + s * nn, n, false, st->Cs.p + s * nn, n, true, 0.0, st->Dn[s].p, n);
         else QC_HIP_CHECK(hipMemsetAsync(st->Dn[s].p, 0, nn * sizeof(double), sm));
         // energy and rms straight into pinned host memory; the last spin's kernel also hands over and clears the control words
-        qc_energy_rms(sm, n, st->Dn[s].p, st->D[s].p, W.H.p, st->G.p + s * nn, scal_out + 2 * s, hand_over ? W.ctl : nullptr, ctl_out);
+        qc_energy_rms(sm, n, st->Dn[s].p, st->D[s].p, W.H.p, Gcur + s * nn, scal_out + 2 * s, hand_over ? W.ctl : nullptr, ctl_out);
         return QC_OK;
     };
     auto publish_scalars = [&]() -> int {
@@ -775,8 +858,14 @@ static int scf_iterate(qc_scf_state *st, double *energy, double *rms_out) {
     bool scale_in_kernel = false;
     // Single-rank runs on the one-workgroup path: the kernel that ends the pass stores the pass's sequence number into pinned memory
     // after the scalars and control words, and the host polls THAT instead of the event behind it (a few microseconds earlier per pass).
-    const bool seq_wait = W.small_fused && !multi && !st->event_wait;
     unsigned *h_seq = reinterpret_cast<unsigned *>(W.h_scal + 2 * QC_SYNC_WORDS);
+    // speculative build of the next pass: decided before the Roothaan step goes out (the one-workgroup kernel releases the fork word itself)
+    const bool want_spec = may_continue && st->spec_on && !st->stored && qc_fock_can_speculate(S);
+    // (with a speculative build behind the pass every launch sequence ends in a kernel that can store the word - the release kernel - and
+    // should: the event behind a kernel that retires while the next build's side chains start is signalled up to 100 us late)
+    const bool seq_wait = ((W.small_fused && !multi) || want_spec) && !st->event_wait;
+    const unsigned spec_seq = want_spec ? ++S->fork_seq : 0;
+    const bool release_in_kernel = want_spec && W.small_fused && !st->uhf && !multi && !st->event_wait;
     if (W.small_fused) {
         for (int s = 0; s < nspin; ++s) {
             // (RHF, direct fixed-point builds: the kernel that forms the new density also leaves the next build's fixed-point unit)
@@ -784,8 +873,11 @@ static int scf_iterate(qc_scf_state *st, double *energy, double *rms_out) {
             scale_in_kernel = scale_here;
             SmallTail tl{st->nocc[s], st->uhf ? 1.0 : 2.0, st->Dn[s].p, st->D[s].p, scal_out + 2 * s, s == nspin - 1 ? W.ctl : nullptr, ctl_out,
                          scale_here ? S->d_fxs : nullptr};
-            if (seq_wait && s == nspin - 1) { tl.seq_out = h_seq; tl.seq = st->pass_seq + 1; }
-            if ((rc = roothaan_small(S, W, *st->diis[s], st->G.p + s * nn, st->D[s].p, st->ws.p + s * n, st->Cs.p + s * nn, s, dE[s], dF[s], have_F, tl)) != QC_OK) return rc;
+            // (when a release kernel follows - closed-shell UHF with a speculative build behind the pass - IT stores the sequence word:
+            // the host must not look at the cancel word before the kernel that writes it has run)
+            if (seq_wait && s == nspin - 1 && !(want_spec && !release_in_kernel)) { tl.seq_out = h_seq; tl.seq = st->pass_seq + 1; }
+            if (release_in_kernel) { tl.fork_words = S->d_join; tl.fork_seq = spec_seq; tl.eps = st->eps_hint; tl.h_cancel = st->h_cancel; }
+            if ((rc = roothaan_small(S, W, *st->diis[s], Gcur + s * nn, st->D[s].p, st->ws.p + s * n, st->Cs.p + s * nn, s, dE[s], dF[s], have_F, tl)) != QC_OK) return rc;
         }
     } else
         for (int s = 0; s < nspin; ++s) if ((rc = density_and_scalars(s, s == nspin - 1)) != QC_OK) return rc;
@@ -793,31 +885,59 @@ static int scf_iterate(qc_scf_state *st, double *energy, double *rms_out) {
     // the next pass's build starts from Dn: its density-only preliminaries run while the host turns around
     auto prepare_next = [&]() -> int { return st->stored ? QC_OK : qc_fock_prepare_device(S, st->Dn[0].p, st->uhf ? st->Dn[1].p : nullptr, st->uhf, st, scale_in_kernel); };
     if ((rc = prepare_next()) != QC_OK) return rc;
+    // (the pass's scalars as the device sees them: pinned host memory, or the all-reduced words of a multi-rank run)
+    if (want_spec && !release_in_kernel)
+        qc_spec_release(sm, S->d_join, spec_seq, multi ? reinterpret_cast<const double *>(W.d_sync) : W.h_scal, n, nspin, st->eps_hint, st->h_cancel,
+                        seq_wait ? h_seq : nullptr, st->pass_seq + 1);
     QC_HIP_CHECK(hipEventRecord(ev2, sm));
+    if (want_spec) {
+        // the next pass's build, behind everything above in the handle's stream and behind the fork word on the side streams
+        hipEvent_t *const evn = st->evs[st->ev_cur ^ 1];
+        double *nE[2] = {nullptr, nullptr}, *nF[2] = {nullptr, nullptr};
+        for (int s = 0; s < nspin; ++s) st->diis[s]->peek_next(&nE[s], &nF[s]);
+        bool f_done = false;
+        scf_flush_timing(st);                       // (the other event set is about to be recorded again)
+        QC_HIP_CHECK(hipEventRecord(evn[0], sm));
+        rc = qc_fock_build_device(S, st->Dn[0].p, st->uhf ? st->Dn[1].p : nullptr, Gnext, st->uhf ? Gnext + nn : nullptr, st->uhf,
+                                  &st->twin, W.H.p, nF[0], nF[1], &f_done, st, spec_seq);
+        if (rc != QC_OK) return rc;
+        QC_HIP_CHECK(hipEventRecord(evn[1], sm));
+        qc_system::QcSpec &sp = S->spec;
+        sp.pending = true; sp.owner = st; sp.Da = st->Dn[0].p; sp.Db = st->uhf ? st->Dn[1].p : nullptr; sp.Ga = Gnext; sp.Gb = st->uhf ? Gnext + nn : nullptr;
+        sp.f_done = f_done; sp.seq = spec_seq;
+    }
     const double th1 = now_ms();
     if (seq_wait) {
         const unsigned want = st->pass_seq + 1;
         unsigned spins = 0;
+        double t0 = 0.0;
         while (__atomic_load_n(h_seq, __ATOMIC_ACQUIRE) != want) {
             if ((++spins & 0xfff) == 0) {                   // (a failed launch or a fault never stores the word: the event knows)
                 const hipError_t e = hipEventQuery(ev2);
-                if (e == hipErrorNotReady) continue;
+                if (e == hipErrorNotReady) {
+                    const double t = now_ms();
+                    if (t0 == 0.0) t0 = t;
+                    else if (t - t0 > host_wait_limit_ms()) { fprintf(stderr, "qchem_hip: an SCF pass did not finish within %.0f s\n", host_wait_limit_ms() * 1e-3); return QC_ERR_HIP; }
+                    continue;
+                }
                 if (e != hipSuccess || __atomic_load_n(h_seq, __ATOMIC_ACQUIRE) != want) { fprintf(stderr, "qchem_hip: the pass ended without its sequence word (%s)\n", hipGetErrorString(e)); return QC_ERR_HIP; }
             }
         }
         st->pass_seq = want;
         // The word says that the pass's last kernel is through.  If the preliminaries of the next build were put behind it (UHF: density
-        // sum and fixed-point unit; a memset after a mode change), the next build's side streams - which start without a fork event -
-        // must not overtake them: then the event behind them is waited for as well.  (RHF on this path has nothing there: the kernel
-        // leaves the fixed-point unit itself and the fold left the planes clean.)
-        if (!st->stored && S->prep_enqueued) QC_HIP_CHECK(wait_event(ev2));
+        // sum and fixed-point unit; a memset after a mode change), a NON-speculative next build's side streams - which start without a
+        // fork event - must not overtake them: then the event behind them is waited for as well.  (RHF on this path has nothing there:
+        // the kernel leaves the fixed-point unit itself and the fold left the planes clean.  A speculative build waits on the device.)
+        if (!st->stored && S->prep_enqueued && !want_spec) QC_HIP_CHECK(wait_event(ev2));
     } else QC_HIP_CHECK(wait_event(ev2));
     const double th2 = now_ms();
+    if ((rc = qc_join_check(S)) != QC_OK) return rc;                     // (the join of this pass's build is in front of everything waited for)
+    if (!want_spec) qc_gate_quiet(S);                                    // (nothing of this handle waits on the device any more)
     if (!ranks_agree()) { fprintf(stderr, "qchem_hip: rank %d: the ranks' SCF scalars differ - replicated state diverged\n", S->rank); return QC_ERR_RCCL; }
     if (h_ctl[8] != 0) return QC_DIIS_SINGULAR;                          // "DIIS failed", rhf.rs:73
     if (h_ctl[9] != 0) return QC_EIG_NOT_CONVERGED;
     static const bool dbg = getenv("QC_SCF_DEBUG") != nullptr;
-    if (dbg) fprintf(stderr, "[scf] ctl a: %d %d %d %d  b: %d %d %d %d  npass %d %d have_prev %d mode %d cold %d | host enqueue %.0f us, then waited %.0f us\n", h_ctl[0], h_ctl[1], h_ctl[2], h_ctl[3], h_ctl[4], h_ctl[5], h_ctl[6], h_ctl[7], W.npass[0], W.npass[1], (int)W.have_prev[0], W.mode[0], (int)W.cold[0], (th1 - th0) * 1e3, (th2 - th1) * 1e3);
+    if (dbg) fprintf(stderr, "[scf] ctl a: %d %d %d %d  b: %d %d %d %d  npass %d %d have_prev %d mode %d cold %d spec %s/%s | host enqueue %.0f us, then waited %.0f us\n", h_ctl[0], h_ctl[1], h_ctl[2], h_ctl[3], h_ctl[4], h_ctl[5], h_ctl[6], h_ctl[7], W.npass[0], W.npass[1], (int)W.have_prev[0], W.mode[0], (int)W.cold[0], spec_hit ? "hit" : "-", want_spec ? "issued" : "-", (th1 - th0) * 1e3, (th2 - th1) * 1e3);
     if (dbg) {   // the pass's DIIS coefficients (diis.rs:50-51), newest sample first
         double c[12] = {0};
         const int m = (int)st->diis[0]->slots.size();
@@ -826,13 +946,12 @@ static int scf_iterate(qc_scf_state *st, double *energy, double *rms_out) {
         for (int j = 0; j < m; ++j) fprintf(stderr, " %.3e", c[j]);
         fprintf(stderr, "\n");
     }
-    float ms_f = 0, ms_l = 0;
-    if (seq_wait) { st->timing_pending = true; st->pending_set = st->ev_cur; }     // (read by the next pass, scf_flush_timing)
-    else {
-        (void)hipEventElapsedTime(&ms_f, ev0, ev1);
-        (void)hipEventElapsedTime(&ms_l, ev1, ev2);
-    }
-    if (!seq_wait && !st->stored && !S->comm) qc_fock_feedback(S, ms_f);  // (multi-rank: every rank keeps its tuner's choice)
+    // the pass's event times are read by the next pass (scf_flush_timing): the last event may still be in flight when the host has seen
+    // the sequence word, and with a speculative build behind the pass nothing should keep the host here
+    st->timing_pending = true; st->pending_set = st->ev_cur;
+    st->pend_build_tuned = st->cur_build_tuned; st->pend_build_gen = st->cur_build_gen;
+    // (what the NEXT pass's timing set will describe, if its build is the one just issued)
+    st->cur_build_tuned = false; st->cur_build_gen = S->assign_gen;
     bool redo = false;
     for (int s = 0; s < nspin; ++s) {
         const bool refined = W.cold[s] || (W.have_prev[s] && W.mode[s] == 0);       // the eigensolve reported through the control word
@@ -840,7 +959,12 @@ static int scf_iterate(qc_scf_state *st, double *energy, double *rms_out) {
         if (h_ctl[4 * s] == 1) { W.npass[s] = W.cold[s] ? 3 : std::max(1, std::min(3, h_ctl[4 * s + 3])); continue; }
         W.npass[s] = 3;
         // the refinement wanted rotations (large step, or a degenerate cluster): repeat this spin's eigensolve the careful way
-        if (!redo) { scf_flush_timing(st); QC_HIP_CHECK(hipEventRecord(ev1, sm)); }
+        if (!redo) {
+            // (the density is about to change: a speculative build from the old one is worthless - it is left to run out, its closing
+            // kernel leaves the accumulator planes clean, and everything below queues behind it on the handle's stream)
+            if (S->spec.pending && S->spec.owner == st) { S->spec.pending = false; st->spec_lost += 1; }
+            scf_flush_timing(st); QC_HIP_CHECK(hipEventRecord(ev1, sm));
+        }
         if ((rc = roothaan_redo_eig(S, W, st->ws.p + s * n, st->Cs.p + s * nn, s)) != QC_OK) return rc;
         if ((rc = density_and_scalars(s, false)) != QC_OK) return rc;
         redo = true;
@@ -855,11 +979,13 @@ static int scf_iterate(qc_scf_state *st, double *energy, double *rms_out) {
         if ((rc = prepare_next()) != QC_OK) return rc;                    // (the density changed)
         QC_HIP_CHECK(hipEventRecord(ev2, sm));
         QC_HIP_CHECK(wait_event(ev2));
+        if ((rc = qc_join_check(S)) != QC_OK) return rc;
+        qc_gate_quiet(S);
         if (!ranks_agree()) return QC_ERR_RCCL;
         if (h_ctl[9] != 0) return QC_EIG_NOT_CONVERGED;                  // the repeat ran out of sweeps: no vectors to go on with
         float ms_r = 0;
         (void)hipEventElapsedTime(&ms_r, ev1, ev2);
-        ms_l += ms_r;
+        st->ms_linalg += ms_r;
     }
     double rms_sum = 0.0, e_sum = 0.0;
     for (int s = 0; s < nspin; ++s) {
@@ -877,8 +1003,8 @@ static int scf_iterate(qc_scf_state *st, double *energy, double *rms_out) {
         std::swap(W.CpPrev[s].p, W.CpNew[s].p);
         W.have_prev[s] = true;
     }
-    st->ms_fock += ms_f;
-    st->ms_linalg += ms_l;
+    st->g_cur ^= 1;
+    st->passes += 1;
     if (energy) *energy = e_sum;
     if (rms_out) *rms_out = st->uhf ? rms_sum / 2.0 : rms_sum;
     return QC_OK;
@@ -896,9 +1022,10 @@ static int scf_run(qc_system *S, const qc_hf_config *cfg, qc_hf_output *out, boo
     out->nuclear_repulsion = qc_nuclear_repulsion(S);                    // rhf.rs:39
     out->electronic_energy = 0.0; out->iterations = 0;
     int status = QC_NOT_CONVERGED;
+    st->eps_hint = cfg->epsilon;                                         // (the rule below, told to the device: see scf_iterate)
     for (size_t it = 0; it <= cfg->max_iterations; ++it) {               // inclusive range, rhf.rs:66 / uhf.rs:80
         double e = 0.0, rms = 0.0;
-        rc = scf_iterate(st, &e, &rms);
+        rc = scf_iterate(st, &e, &rms, it < cfg->max_iterations);
         if (rc != QC_OK) { status = rc; break; }
         // the reference's per-iteration log line (rhf.rs:90-92, uhf.rs:138; `log::info!`, silent unless a logger is installed): QC_LOG=1
         static const bool log_info = getenv("QC_LOG") != nullptr;
@@ -915,6 +1042,7 @@ static int scf_run(qc_system *S, const qc_hf_config *cfg, qc_hf_output *out, boo
     scf_flush_timing(st);
     out->ms_setup = st->ms_setup; out->ms_fock_total = st->ms_fock; out->ms_linalg_total = st->ms_linalg;
     out->ms_total = now_ms() - t_begin;
+    out->ms_tuner = st->ms_tuner;
     return status;
 }
 
@@ -995,6 +1123,18 @@ int qc_scf_timings(qc_scf_state *st, double *ms_setup, double *ms_fock, double *
     return QC_OK;
 }
 void qc_scf_end(qc_scf_state *st) { scf_state_delete(st); }
+int qc_scf_set_stop_rule(qc_scf_state *st, double epsilon) {
+    if (!st || !(epsilon >= 0.0)) return QC_ERR_INVALID;
+    st->eps_hint = epsilon;
+    return QC_OK;
+}
+int qc_scf_counters(qc_scf_state *st, double out[8]) {
+    if (!st || !out) return QC_ERR_INVALID;
+    scf_flush_timing(st);
+    out[0] = st->ms_setup; out[1] = st->ms_fock; out[2] = st->ms_linalg; out[3] = (double)st->builds_timed;
+    out[4] = st->ms_tuner; out[5] = (double)st->passes; out[6] = (double)st->spec_hits; out[7] = (double)st->spec_lost;
+    return QC_OK;
+}
 
 // sorted_eigs with a starting guess: V0 = eigenvectors of a nearby matrix (what the SCF loop uses from its second pass on)
 int qc_sym_eig_warm(qc_system *S, int n, const double *A, const double *V0, double *V, double *w) {

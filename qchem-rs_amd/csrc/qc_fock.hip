@@ -106,6 +106,8 @@ int qc_device_reshard(qc_system *S) {
     S->unit_ms.clear(); S->unit_stream.clear();
     S->cand_stream.clear(); S->cand_weight.clear(); S->cand_ms.clear(); S->cand_n.clear(); S->cand_frozen = false; S->cand_skip = false; S->cand_cur = 0;
     S->second_stage = 0; S->tune_count = 0; S->inpass_sum = 0.0; S->inpass_n = 0; S->builds_seen = 0;
+    S->assign_gen += 1;
+    if (S->spec.pending) { if (S->stream) (void)hipStreamSynchronize(S->stream); S->spec.pending = false; }     // (it digests the old lists)
     qc_build_shards(S);
     if (!S->device_ready) return QC_OK;
     return upload_slots(S);
@@ -174,6 +176,10 @@ static std::vector<int> qc_build_rplan() {
 }
 
 static int qc_join_probe(qc_system *S, bool *concurrent);
+static int qc_lane_probe(qc_system *S);
+__global__ void qc_join_mark_kernel(unsigned *cnt);
+static void qc_gate_forget(qc_system *S);
+static void qc_issue_pool_drop(qc_system *S);
 
 int qc_device_init(qc_system *S) {
     if (S->device_ready) return QC_OK;
@@ -228,8 +234,9 @@ int qc_device_init(qc_system *S) {
     QC_HIP_CHECK(hipMalloc(&S->d_flag, 4 * sizeof(int)));
     QC_HIP_CHECK(hipMalloc(&S->d_join, 4 * sizeof(unsigned)));
     QC_HIP_CHECK(hipMemset(S->d_join, 0, 4 * sizeof(unsigned)));
-    QC_HIP_CHECK(hipHostMalloc(&S->h_join_timeout, sizeof(int), hipHostMallocDefault));
+    QC_HIP_CHECK(hipHostMalloc(&S->h_join_timeout, 4 * sizeof(int), hipHostMallocDefault));
     *S->h_join_timeout = 0; S->join_target = 0;
+    S->h_hold = reinterpret_cast<unsigned *>(S->h_join_timeout + 1); *S->h_hold = 0; S->hold_seq = 0;
     {
         bool concurrent = true;
         int prc = qc_join_probe(S, &concurrent);
@@ -237,6 +244,7 @@ int qc_device_init(qc_system *S) {
         S->join_by_events = !concurrent || getenv("QC_EVENT_JOIN") != nullptr;      // (A/B switch, read per handle: the event join of rounds 1-2)
         S->issue_threads = getenv("QC_ISSUE_THREADS") ? atoi(getenv("QC_ISSUE_THREADS")) : -1;    // (0: never; n: always n helpers; read per handle)
         if (!concurrent && getenv("QC_SCF_DEBUG")) fprintf(stderr, "qchem_hip: kernels of different streams do not run concurrently here (profiler counters?): event join\n");
+        if (concurrent) { prc = qc_lane_probe(S); if (prc != QC_OK) return prc; }
     }
     QC_HIP_CHECK(hipMalloc(&S->d_fxs, 2 * sizeof(double)));
     // Schwarz factors of the pairs (once per geometry), then the screened work lists
@@ -249,6 +257,9 @@ int qc_device_init(qc_system *S) {
 }
 
 void qc_device_free(qc_system *S) {
+    if (S->stream) (void)hipStreamSynchronize(S->stream);
+    qc_gate_forget(S);
+    S->spec.pending = false;
     for (auto &c : S->classes) {
         if (c.d_slots) { (void)hipFree(c.d_slots); c.d_slots = nullptr; }
         if (c.d_bundles) { (void)hipFree(c.d_bundles); c.d_bundles = nullptr; }
@@ -256,7 +267,7 @@ void qc_device_free(qc_system *S) {
     }
     void *ptrs[] = {S->d_rplan, S->d_gidx, S->d_shells, S->d_pairdata, S->d_pairdataT, S->d_pspack, S->d_pairs, S->d_boys, S->d_D, S->d_G, S->d_Gtmp, S->d_Gred, S->d_Dj, S->d_flag, S->d_fxs};
     S->d_flag = nullptr; S->d_fxs = nullptr;
-    delete S->issue_pool; S->issue_pool = nullptr;
+    qc_issue_pool_drop(S);
     drop_launch_plan(S);
     if (S->d_join) { (void)hipFree(S->d_join); S->d_join = nullptr; }
     if (S->h_join_timeout) { (void)hipHostFree(S->h_join_timeout); S->h_join_timeout = nullptr; }
@@ -343,32 +354,239 @@ struct QcIssuePool {
     }
 };
 
+static void qc_issue_pool_drop(qc_system *S) { delete S->issue_pool; S->issue_pool = nullptr; }
+
+// ---- Dispatch lanes.  Measured on MI355X (tools/probes/pipe_probe.hip): with GPU_MAX_HW_QUEUES=8, eight HIP streams land on eight hardware
+// queues that sit in PAIRS on four dispatch pipes, and a pipe works on one dispatch packet until every workgroup of that grid has been
+// launched - a one-workgroup kernel on stream j completes in 12 us while a grid of 8192 workgroups dispatches on an unrelated stream, and
+// only after 160 us (the grid's whole dispatch) when j's queue shares the pipe of that stream (pairs (i, i + 4) in creation order; with the
+// runtime's default of four queues the pairs share a QUEUE).  So at most four kernels dispatch at a time, a launch on a fifth stream waits
+// for its pipe neighbour, and which streams are neighbours is the runtime's business.  It is measured, once per handle: a busy grid on one
+// stream, a marker on the other, the marker's latency against the grid's own duration.  The assignment of launch units then uses
+// `nlanes` (<= 4) slots on distinct pipes instead of drawing among seven streams that are not what they seem (QC_NO_LANES: the old draw).
+__global__ void qc_probe_busy_kernel(long long ticks) {
+    extern __shared__ char probe_lds[];
+    if (threadIdx.x == 0) probe_lds[0] = 1;
+    const long long t0 = wall_clock64();
+    while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(16);
+}
+static int qc_lane_probe(qc_system *S) {
+    for (int k = 0; k < QC_NSTREAMS; ++k) S->slot_side[k] = k;
+    S->nlanes = QC_NSTREAMS; S->lane0_is_main = false;
+    if (getenv("QC_NO_LANES")) return QC_OK;
+    using clk = std::chrono::steady_clock;
+    auto us = [](clk::time_point a, clk::time_point b) { return std::chrono::duration<double, std::micro>(b - a).count(); };
+    const int grid = 8192; const long long ticks = 500;                  // 8192 one-wave workgroups of 5 us, 40 KB of LDS each: four per CU
+    auto busy = [&](hipStream_t st) { hipLaunchKernelGGL(qc_probe_busy_kernel, dim3(grid), dim3(64), 40 * 1024, st, ticks); };
+    auto mark = [&](hipStream_t st) { hipLaunchKernelGGL(qc_join_mark_kernel, dim3(1), dim3(64), 0, st, S->d_join + 3); };
+    // warm-up (code upload, queue creation), then the grid alone
+    busy(S->stream); mark(S->stream);
+    for (int k = 0; k < QC_NSTREAMS; ++k) mark(S->side[k]);
+    QC_HIP_CHECK(hipDeviceSynchronize());
+    double d_alone = 1e30;
+    for (int rep = 0; rep < 2; ++rep) {
+        const auto t0 = clk::now();
+        busy(S->stream);
+        QC_HIP_CHECK(hipStreamSynchronize(S->stream));
+        d_alone = std::min(d_alone, us(t0, clk::now()));
+    }
+    // coupled(x, y): a marker on y waits for the grid on x
+    auto coupled = [&](hipStream_t x, hipStream_t y, bool *out) -> int {
+        double lat = 1e30;
+        for (int rep = 0; rep < 2; ++rep) {
+            busy(x);
+            const auto t1 = clk::now();
+            mark(y);
+            QC_HIP_CHECK(hipStreamSynchronize(y));
+            lat = std::min(lat, us(t1, clk::now()));
+            QC_HIP_CHECK(hipStreamSynchronize(x));
+        }
+        *out = lat > 0.5 * d_alone;
+        return QC_OK;
+    };
+    std::vector<std::vector<int>> lanes;      // side-stream indices per pipe; -1 stands for the handle's own stream
+    lanes.push_back({-1});
+    for (int k = 0; k < QC_NSTREAMS; ++k) {
+        bool placed = false;
+        for (auto &L : lanes) {
+            bool c = false;
+            int rc = coupled(L[0] < 0 ? S->stream : S->side[L[0]], S->side[k], &c);
+            if (rc != QC_OK) return rc;
+            if (c) { L.push_back(k); placed = true; break; }
+        }
+        if (!placed) lanes.push_back({k});
+    }
+    // slots: one side stream per pipe first (the pipe of the handle's own stream in front, if a side stream shares it), then the rest
+    int n = 0;
+    bool used[QC_NSTREAMS] = {};
+    S->lane0_is_main = lanes[0].size() > 1;
+    for (auto &L : lanes)
+        for (int k : L) if (k >= 0) { S->slot_side[n++] = k; used[k] = true; break; }
+    S->nlanes = n;
+    for (int k = 0; k < QC_NSTREAMS; ++k) if (!used[k]) S->slot_side[n++] = k;
+    if (getenv("QC_TUNE_DEBUG") || getenv("QC_SCF_DEBUG")) {
+        fprintf(stderr, "[lanes] %d dispatch lanes (grid alone %.0f us):", S->nlanes, d_alone);
+        for (auto &L : lanes) { fprintf(stderr, " {"); for (int k : L) fprintf(stderr, k < 0 ? " main" : " s%d", k); fprintf(stderr, " }"); }
+        fprintf(stderr, "  slots:"); for (int k = 0; k < QC_NSTREAMS; ++k) fprintf(stderr, " %d", S->slot_side[k]); fprintf(stderr, "\n");
+    }
+    return QC_OK;
+}
+
 // Device-side join of a build's side streams.  Joining through events costs the cross-queue signal path - event packet on the side
 // queue, barrier packet on the handle's queue, ~20 us between the last class kernel and the fold on the H2O/cc-pVTZ trace.  Instead every
 // side stream ends with a one-lane marker kernel that counts itself (in-queue dependency: a few us), and the handle's stream runs a
-// one-lane kernel that waits for the count of this build (monotonic counter, signed comparison) before the fold.  The wait gives up after
-// two seconds of the constant 100 MHz clock - only possible when a side stream's launches never complete - and says so in pinned memory.
+// one-lane kernel that waits for the count of this build (monotonic counter, signed comparison) before the fold.
+//
+// Device-side fork (round 4): the side streams of a SPECULATIVE build - the next SCF pass's build, issued behind this pass's Roothaan step
+// before the host has seen the pass end (scf_iterate) - start with the same one-lane waiting kernel, on the fork word (d_join[1]) that the
+// kernel which leaves the pass's densities releases.  The host is then off the pass boundary: all launches of the next build sit in their
+// queues when the densities become final.
+//
+// A wait gives up after S->wait_limit ticks of the constant 100 MHz clock (qc_wait_limit: 20 s, or fifty times the build's serial time if
+// that is longer) - only possible when the launches it waits for never complete - and says so in pinned memory.  Every host wait that
+// follows looks at that word (qc_join_check) and fails THAT call: a build whose join gave up has folded an incomplete matrix.
 __global__ void qc_join_mark_kernel(unsigned *cnt) {
     if (threadIdx.x == 0) (void)__hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
 }
-__global__ void qc_join_wait_kernel(unsigned *cnt, unsigned target, int *timeout_flag, long long limit) {
+// (the poll is a RELAXED agent-scope load - it goes past the non-coherent cache levels without invalidating anything; an acquire load
+// in the loop invalidates the waiter's L2 every time round, and five waiters doing that every 100 ns through a whole Roothaan step cost
+// the kernels running beside them 30 % - measured: iteration 0.33 -> 0.46 ms.  One acquire fence once the word is there.)
+// (`delay`, ticks of the 100 MHz clock: a fork waiter lets that much time pass after the word has arrived - the side chains of a build
+// start a few microseconds apart, heaviest first, as they do when the host issues them one by one: released all at once they take each
+// other's wave slots from the first cycle and the chain that ends the build loses its head start - measured, see launch_concurrent)
+__global__ void qc_join_wait_kernel(unsigned *cnt, unsigned target, int *timeout_flag, long long limit, int delay) {
     if (threadIdx.x != 0) return;
     const long long t0 = wall_clock64();
-    while ((int)(__hip_atomic_load(cnt, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) - target) < 0) {
-        __builtin_amdgcn_s_sleep(4);
-        if (wall_clock64() - t0 > limit) { *timeout_flag = 1; __threadfence_system(); break; }
+    while ((int)(__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - target) < 0) {
+        __builtin_amdgcn_s_sleep(8);
+        if (wall_clock64() - t0 > limit) { __hip_atomic_store(timeout_flag, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM); break; }
+    }
+    if (delay > 0) {
+        const long long t1 = wall_clock64();
+        while (wall_clock64() - t1 < delay) __builtin_amdgcn_s_sleep(4);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+}
+// (tuner: a kernel on the handle's stream that holds everything behind it until the host has finished issuing - the tuner's builds then
+// start the way a speculative build inside an SCF pass starts: every launch already in its queue when the fork word is released)
+__global__ void qc_hold_kernel(const unsigned *h_word, unsigned target, long long limit) {
+    if (threadIdx.x != 0) return;
+    const long long t0 = wall_clock64();
+    while ((int)(__hip_atomic_load(h_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) - target) < 0) {
+        __builtin_amdgcn_s_sleep(16);
+        if (wall_clock64() - t0 > limit) break;
     }
 }
-constexpr long long QC_JOIN_LIMIT = 200000000LL;       // two seconds of the 100 MHz clock
+// The word that ends an SCF pass on the device, for the launch sequences that have no kernel of their own to do it in (the one-workgroup
+// Roothaan kernel of small closed-shell runs does the same at its end, qc_scf_small.hip): decide whether the host - which has promised to
+// stop once the reference's stopping rule holds at `eps` (rhf.rs:94 / uhf.rs:139) - will take another pass; if not, the speculative build
+// behind this kernel is cancelled (cancel word = its number: the class kernels return at once), and the host is told so in pinned memory
+// before it sees the pass end; then release the fork word.  scal: [0.5 tr(D(2H+G)), sum_i dD_ii^2] per spin, wherever the pass left them.
+__global__ void qc_spec_release_kernel(unsigned *words, unsigned seq, const double *scal, int n, int nspin, double eps, unsigned *h_cancel,
+                                       unsigned *h_seq, unsigned seqval) {
+    if (threadIdx.x != 0) return;
+    bool stop = false;
+    if (eps > 0.0) {
+        double rms = 0.0;
+        for (int s = 0; s < nspin; ++s) rms += sqrt(scal[2 * s + 1] / n);
+        // (uhf.rs:137-139: density_rms = (rms_a + rms_b) / 2, test rms / 2 < eps;  rhf.rs:94: rms < eps)
+        stop = nspin == 2 ? (rms / 2.0 / 2.0 < eps) : (rms < eps);
+    }
+    if (stop) {
+        __hip_atomic_store(words + 2, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (h_cancel) __hip_atomic_store(h_cancel, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+    __hip_atomic_store(words + 1, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    // (h_seq: this kernel also ends the pass for a host that polls the pinned sequence word - after the cancel word it may look at)
+    if (h_seq) __hip_atomic_store(h_seq, seqval, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+void qc_spec_release(hipStream_t st, unsigned *words, unsigned seq, const double *scal, int n, int nspin, double eps, unsigned *h_cancel,
+                     unsigned *h_seq, unsigned seqval) {
+    hipLaunchKernelGGL(qc_spec_release_kernel, dim3(1), dim3(64), 0, st, words, seq, scal, n, nspin, eps, h_cancel, h_seq, seqval);
+}
+
+// twenty seconds of the 100 MHz clock, or fifty times the serial time of the build's launches when that is longer (a side chain of a
+// very large system may legitimately end seconds after the handle's own); QC_WAIT_LIMIT_MS overrides (tests force a tiny limit)
+static long long qc_wait_limit(const qc_system *S) {
+    const char *env = getenv("QC_WAIT_LIMIT_MS");          // (read per build: a test switches it on and off inside one process)
+    const double env_ms = env ? atof(env) : 0.0;
+    if (env_ms > 0.0) return std::max(1LL, (long long)(env_ms * 1e5));
+    double serial_ms = 0.0;
+    for (float x : S->unit_ms) serial_ms += x;
+    return (long long)(std::max(20000.0, 50.0 * serial_ms) * 1e5);
+}
+
+// ---- One handle at a time may have device-side waits in flight on a device.  A waiting kernel sits at the head of its hardware queue
+// until the kernel that releases it has run; the argument that this cannot deadlock - every wait is issued after everything it depends
+// on, and a hardware queue runs in issue order - holds for ONE issuing sequence.  Two handles issuing from two threads (the header
+// allows that) can park handle A's waiter in front of handle B's marker and B's waiter in front of A's: both then wait out their limit.
+// So the issue of a build - the only place where cross-stream dependencies are created - goes through a per-device gate: the issuing
+// thread holds the gate's mutex while it issues, and if ANOTHER handle still has waits in flight it first waits for that handle's
+// stream (those waits finish without any help from the host: everything they depend on was issued before them).  Uncontended cost: one
+// mutex per build.
+struct QcGate { std::mutex mu; qc_system *owner = nullptr; };
+static QcGate &qc_gate_of(int device) {
+    static QcGate gates[64];
+    return gates[(device >= 0 && device < 64) ? device : 0];
+}
+struct QcGateHold {
+    QcGate &g;
+    qc_system *S;
+    bool waits = false;                       // the issue under this hold put device-side waits in flight
+    explicit QcGateHold(qc_system *S_) : g(qc_gate_of(S_->device)), S(S_) {
+        g.mu.lock();
+        if (g.owner && g.owner != S) {
+            if (g.owner->stream) (void)hipStreamSynchronize(g.owner->stream);      // (the join wait is the last thing of a build on it)
+            g.owner->waits_in_flight = false;
+            g.owner = nullptr;
+        }
+    }
+    ~QcGateHold() {
+        if (waits) { g.owner = S; S->waits_in_flight = true; }
+        g.mu.unlock();
+    }
+};
+// the host has seen the handle's stream drained past its last build: nothing of this handle waits on the device any more
+void qc_gate_quiet(qc_system *S) {
+    if (!S->waits_in_flight) return;
+    QcGate &g = qc_gate_of(S->device);
+    std::lock_guard<std::mutex> lk(g.mu);
+    if (g.owner == S) g.owner = nullptr;
+    S->waits_in_flight = false;
+}
+static void qc_gate_forget(qc_system *S) {          // the handle goes away
+    QcGate &g = qc_gate_of(S->device);
+    std::lock_guard<std::mutex> lk(g.mu);
+    if (g.owner == S) g.owner = nullptr;
+    S->waits_in_flight = false;
+}
+
+// After a host wait that follows a device-joined build: did one of its waits give up?  Then the matrix it folded was not complete: the
+// call fails (last_error says why), the accumulator planes are no longer known to be clean, the counter and the host's target meet
+// again, and this handle joins through events from now on.
+int qc_join_check(qc_system *S) {
+    if (!S->h_join_timeout || !__atomic_load_n(S->h_join_timeout, __ATOMIC_ACQUIRE)) return QC_OK;
+    S->last_error = "a device-side wait of the Fock build gave up (QC_WAIT_LIMIT_MS): a launch it depended on never finished; "
+                    "this handle joins its streams through events from now on";
+    fprintf(stderr, "qchem_hip: %s\n", S->last_error.c_str());
+    (void)hipDeviceSynchronize();
+    unsigned c[3] = {0, 0, 0};
+    if (hipMemcpy(c, S->d_join, sizeof(c), hipMemcpyDeviceToHost) == hipSuccess) { S->join_target = c[0]; S->fork_seq = std::max(S->fork_seq, c[1]); }
+    __atomic_store_n(S->h_join_timeout, 0, __ATOMIC_RELEASE);
+    S->join_by_events = true;
+    S->gt_clean = false; S->prepared = false; S->spec.pending = false;
+    return QC_ERR_HIP;
+}
 
 // The device-side join needs kernels of different streams to RUN concurrently: a waiting kernel whose marker cannot start would wait
 // out its limit.  That is the case whenever something serialises dispatches - rocprofv3 counter collection (--pmc) does, so do the
 // runtime's debugging switches.  Asked once per handle: a waiting kernel on one stream, then its marker on another; if the wait gives up
 // after 2 ms, this handle joins through events (as QC_EVENT_JOIN does).
 static int qc_join_probe(qc_system *S, bool *concurrent) {
+    QcGateHold hold(S);
     *S->h_join_timeout = 0;
     S->join_target += 1;
-    hipLaunchKernelGGL(qc_join_wait_kernel, dim3(1), dim3(64), 0, S->stream, S->d_join, S->join_target, S->h_join_timeout, 200000LL);
+    hipLaunchKernelGGL(qc_join_wait_kernel, dim3(1), dim3(64), 0, S->stream, S->d_join, S->join_target, S->h_join_timeout, 200000LL, 0);
     hipLaunchKernelGGL(qc_join_mark_kernel, dim3(1), dim3(64), 0, S->side[0], S->d_join);
     if (hipGetLastError() != hipSuccess) return QC_ERR_HIP;
     QC_HIP_CHECK(hipStreamSynchronize(S->stream));
@@ -383,6 +601,7 @@ static QcKernelArgs base_args(qc_system *S, const QcFockArgs &fa) {
     a.pairs = S->d_pairs; a.pairdata = S->d_pairdata; a.pairdataT = S->d_pairdataT; a.boys = S->d_boys; a.rplan = reinterpret_cast<const int2 *>(S->d_rplan); a.gidx = reinterpret_cast<const uint4 *>(S->d_gidx); a.n = S->nbasis;
     a.Dj = fa.Dj; a.Dk0 = fa.Dk0; a.Dk1 = fa.Dk1; a.G0 = fa.G0; a.G1 = fa.G1; a.cK = fa.cK; a.eri_out = fa.eri_out;
     a.nrep = fa.nrep > 0 ? fa.nrep : 1; a.rep_stride = fa.rep_stride; a.fxs = fa.fxs; a.fx_lo = fa.fx_lo; a.schwarz_out = fa.schwarz_out;
+    a.cancel = fa.fork_seq ? S->d_join + 2 : nullptr; a.cancel_seq = fa.fork_seq;
     return a;
 }
 
@@ -515,7 +734,8 @@ static void tier_units(qc_system *S, std::vector<std::vector<int>> &units) {
 // Profiling mode (class_ms != nullptr): one single-segment launch per class bucket, serial on the handle's stream with
 // a hipEvent between consecutive launches; unit_ms (optional, 14 entries) times the real tier launches the same way.
 int qc_launch_fock_classes(qc_system *S, const QcFockArgs &fa, float *class_ms, float *unit_ms, bool nofork) {
-    const QcKernelArgs a = base_args(S, fa);
+    const QcKernelArgs a0 = base_args(S, fa);
+    const QcKernelArgs &a = a0;
     // (the launch units and their segments only change with the work lists: kept between builds, dropped by upload_slots)
     if (!S->launch_plan) {
         S->launch_plan = new QcLaunchPlan();
@@ -562,6 +782,7 @@ int qc_launch_fock_classes(qc_system *S, const QcFockArgs &fa, float *class_ms, 
     // and a build that ends on the handle's stream goes straight on to the fold, while one that ends on a side stream first pays the
     // cross-queue signal - event packet, barrier packets, ~20 us on the H2O/cc-pVTZ trace.)
     auto lpt = [&](const std::vector<float> &w, int nstreams, float head_start = 0.f) {
+        nstreams = std::min(nstreams, S->nlanes);              // (slots beyond the dispatch lanes share a pipe with an earlier one)
         std::vector<int> ord;
         for (size_t u = 0; u < units.size(); ++u) if (!units[u].empty()) ord.push_back((int)u);
         std::stable_sort(ord.begin(), ord.end(), [&](int x, int y) { return w[x] > w[y]; });
@@ -577,12 +798,19 @@ int qc_launch_fock_classes(qc_system *S, const QcFockArgs &fa, float *class_ms, 
     };
     // one concurrent build: fork the side streams off the handle's stream, launch every unit on its stream (heaviest
     // first), join.  `ev` (tuning only): [0] fork, [1] join, [2 + 2u], [3 + 2u] around unit u.
-    auto launch_concurrent = [&](hipEvent_t *ev, bool per_unit) -> int {
+    auto launch_concurrent = [&](hipEvent_t *ev, bool per_unit, unsigned fork_seq) -> int {
+        QcGateHold gate(S);
+        QcKernelArgs a = a0;                       // (a speculative / spec-form build carries its number: the cancel word may empty it)
+        a.cancel = fork_seq ? S->d_join + 2 : nullptr; a.cancel_seq = fork_seq;                        // (cross-stream dependencies are created here and nowhere else: see QcGate)
         if (ev) QC_HIP_CHECK(hipEventRecord(ev[0], S->stream));
         // (nofork: everything the launches depend on has completed - the host waited for the handle's stream after it was enqueued)
         static const bool force_fork = getenv("QC_FORCE_FORK") != nullptr;          // (A/B switch)
-        const bool fork = ev != nullptr || !nofork || force_fork;
+        // device-side fork (speculative build): the side streams' first kernels wait for the fork word instead of an event of the
+        // handle's stream - what they depend on has not even started when they are issued
+        const bool devfork = fork_seq != 0;
+        const bool fork = !devfork && (ev != nullptr || !nofork || force_fork);
         if (fork) QC_HIP_CHECK(hipEventRecord(S->ev_fork, S->stream));
+        S->wait_limit = qc_wait_limit(S);
         // Issue order (the host needs ~8 us per launch, so it matters): inside a stream heaviest first; across streams the
         // first launch of every stream before any second one, streams in the order of their total load - the chain that
         // ends the build gets going first and no stream sits empty while another one's queue is being filled.
@@ -597,10 +825,19 @@ int qc_launch_fock_classes(qc_system *S, const QcFockArgs &fa, float *class_ms, 
             for (int k = 0; k < QC_NSTREAMS; ++k) ks[k] = k;
             std::stable_sort(ks, ks + QC_NSTREAMS, [&](int x, int y) { return load[x] > load[y]; });
         }
-        // the most loaded chain runs on the handle's own stream: no fork hop before it, no join after it
-        const int kmain = ks[0];
+        // the most loaded chain runs on the handle's own stream: no fork hop before it, no join after it.
+        // NOT in a speculative build: there the kernel in front of the build - the Roothaan step that releases the fork word before it
+        // ends - retires slowly once the side chains have started (its end-of-kernel cache write-back competes with their traffic: 100 us
+        // instead of 5 on the H2O/cc-pVTZ trace), and a chain queued behind it on the handle's stream starts that much later.  All chains
+        // of a speculative build go to side streams; the handle's stream carries the wait and the fold, which have to wait anyway.
+        // (with the dispatch lanes known, slot 0 is the slot on the pipe of the handle's own stream: its chain is the one that runs there -
+        // any other choice would put two chains on one pipe; the longest-first rule gives slot 0 the heaviest launch anyway)
+        const int kmain = devfork ? -1 : (S->lane0_is_main ? (q[0].empty() ? -1 : 0) : ks[0]);
         const bool event_join = S->join_by_events;                   // (QC_EVENT_JOIN, or dispatches are serialised here: qc_device_init)
-        if (!event_join && *S->h_join_timeout) return QC_ERR_HIP;    // an earlier build's join gave up: its result was not complete
+        if (devfork && event_join) return QC_ERR_INVALID;            // (the caller asks qc_fock_can_speculate first)
+        // an earlier ASYNCHRONOUS build's wait gave up (qc_fock_*_device return before their build has run; every call that waits on the
+        // host has looked at the word itself, qc_join_check): its result was not complete, and this is the first call that can say so
+        if (!event_join) { int jrc = qc_join_check(S); if (jrc != QC_OK) return jrc; }
         // launches of a set of streams, interleaved (first launch of every stream of the set before any second one), then the
         // streams' markers of the device-side join
         auto issue = [&](const int *set, int nset) -> int {
@@ -611,8 +848,14 @@ int qc_launch_fock_classes(qc_system *S, const QcFockArgs &fa, float *class_ms, 
                     const int k = set[i];
                     if (pos >= q[k].size()) continue;
                     const int u = q[k][pos];
-                    hipStream_t st = k == kmain ? S->stream : S->side[k];
+                    hipStream_t st = k == kmain ? S->stream : S->side[S->slot_side[k]];
                     if (pos == 0 && k != kmain && fork) QC_HIP_CHECK(hipStreamWaitEvent(st, S->ev_fork, 0));
+                    if (pos == 0 && k != kmain && devfork) {
+                        // (side chains in the order of their load, QC_FORK_STAGGER_US apart - default 6 us, the host's own issue rate)
+                        static const double stagger_us = getenv("QC_FORK_STAGGER_US") ? atof(getenv("QC_FORK_STAGGER_US")) : 6.0;
+                        const int delay = (int)(stagger_us * 100.0 * (double)i);
+                        hipLaunchKernelGGL(qc_join_wait_kernel, dim3(1), dim3(64), 0, st, S->d_join + 1, fork_seq, S->h_join_timeout, S->wait_limit, delay);
+                    }
                     if (ev && per_unit) QC_HIP_CHECK(hipEventRecord(ev[2 + 2 * u], st));
                     int rc = launch_segments(S, u, segs_of(units[u]), st, a);
                     if (rc != QC_OK) return rc;
@@ -620,7 +863,7 @@ int qc_launch_fock_classes(qc_system *S, const QcFockArgs &fa, float *class_ms, 
                 }
             if (!event_join) {
                 for (int i = 0; i < nset; ++i)
-                    if (set[i] != kmain && !q[set[i]].empty()) hipLaunchKernelGGL(qc_join_mark_kernel, dim3(1), dim3(64), 0, S->side[set[i]], S->d_join);
+                    if (set[i] != kmain && !q[set[i]].empty()) hipLaunchKernelGGL(qc_join_mark_kernel, dim3(1), dim3(64), 0, S->side[S->slot_side[set[i]]], S->d_join);
                 if (hipGetLastError() != hipSuccess) return QC_ERR_HIP;
             }
             return QC_OK;
@@ -639,7 +882,7 @@ int qc_launch_fock_classes(qc_system *S, const QcFockArgs &fa, float *class_ms, 
         for (float x : S->unit_ms) serial_ms += x;
         const int nhelp_want = nhelp_env >= 0 ? nhelp_env : 0;
         (void)serial_ms;
-        const int nhelp = (event_join || (ev && per_unit) || nused < 3) ? 0 : std::min(nhelp_want, nused - 1);
+        const int nhelp = (event_join || devfork || (ev && per_unit) || nused < 3) ? 0 : std::min(nhelp_want, nused - 1);
         if (nhelp <= 0) {
             int used_set[QC_NSTREAMS], n = 0;
             for (int k : ks) if (!q[k].empty()) used_set[n++] = k;
@@ -655,7 +898,7 @@ int qc_launch_fock_classes(qc_system *S, const QcFockArgs &fa, float *class_ms, 
                 for (int k : ks) if (k != kmain && !q[k].empty()) { sets[h][nset[h]++] = k; h = (h + 1) % nhelp; }
             }
             for (int h = 0; h < nhelp; ++h) P.start(h, [&, h]() -> int { return issue(sets[h], nset[h]); });
-            int rc = issue(&kmain, 1);
+            int rc = kmain >= 0 ? issue(&kmain, 1) : QC_OK;
             for (int h = 0; h < nhelp; ++h) { const int r = P.wait(h); if (rc == QC_OK) rc = r; }       // (every helper is waited for, whatever happened)
             if (rc != QC_OK) {
                 // some markers of this build may be out, others not: the counter and the host's target meet again before anything else waits
@@ -667,13 +910,14 @@ int qc_launch_fock_classes(qc_system *S, const QcFockArgs &fa, float *class_ms, 
         if (event_join) {
             for (int k = 0; k < QC_NSTREAMS; ++k) {
                 if (q[k].empty() || k == kmain) continue;
-                QC_HIP_CHECK(hipEventRecord(S->ev_join[k], S->side[k]));
+                QC_HIP_CHECK(hipEventRecord(S->ev_join[k], S->side[S->slot_side[k]]));
                 QC_HIP_CHECK(hipStreamWaitEvent(S->stream, S->ev_join[k], 0));
             }
         } else if (nside) {
             S->join_target += nside;
-            hipLaunchKernelGGL(qc_join_wait_kernel, dim3(1), dim3(64), 0, S->stream, S->d_join, S->join_target, S->h_join_timeout, QC_JOIN_LIMIT);
+            hipLaunchKernelGGL(qc_join_wait_kernel, dim3(1), dim3(64), 0, S->stream, S->d_join, S->join_target, S->h_join_timeout, S->wait_limit, 0);
             if (hipGetLastError() != hipSuccess) return QC_ERR_HIP;
+            gate.waits = true;
         }
         if (ev) QC_HIP_CHECK(hipEventRecord(ev[1], S->stream));
         static const bool join_check = getenv("QC_JOIN_CHECK") != nullptr;       // (diagnostic: after every build the device counter is the host's target)
@@ -692,6 +936,8 @@ int qc_launch_fock_classes(qc_system *S, const QcFockArgs &fa, float *class_ms, 
         // each proposes the next assignment (longest-first on the durations seen *inside* the build, over 4 to 7 streams - fewer
         // concurrent kernels disturb each other less), the fastest is kept.
         S->unit_ms.assign(units.size(), 0.f);
+        // (a tuner run that fails half-way leaves nothing behind: the next build tunes again)
+        struct Untuned { qc_system *S; bool keep = false; ~Untuned() { if (!keep) { S->unit_ms.clear(); S->unit_stream.clear(); } } } untuned{S};
         const size_t gbytes = (fa.fxs ? 2 : 1) * (size_t)a.nrep * a.rep_stride * sizeof(double);   // (hi and lo planes are contiguous)
         int rc = qc_launch_fock_classes(S, fa, nullptr, S->unit_ms.data());     // warm-up: first launches pay code upload
         if (rc == QC_OK) rc = qc_launch_fock_classes(S, fa, nullptr, S->unit_ms.data());   // serial, timed
@@ -701,10 +947,11 @@ int qc_launch_fock_classes(qc_system *S, const QcFockArgs &fa, float *class_ms, 
         if (fixed_w >= 1 && fixed_w <= QC_NSTREAMS) {
             lpt(S->unit_ms, fixed_w, 0.015f);
             S->cand_stream.clear(); S->cand_weight.clear(); S->cand_ms.clear(); S->cand_n.clear(); S->cand_frozen = true;
-            S->tuned_best_ms = 0.f; S->tune_count += 1; S->second_stage = 2;
+            S->tuned_best_ms = 0.f; S->tune_count += 1; S->second_stage = 2; S->assign_gen += 1;
             if (fa.G0) QC_HIP_CHECK(hipMemsetAsync(fa.G0, 0, gbytes, S->stream));
             nofork = false;
-            return launch_concurrent(nullptr, false);
+            untuned.keep = true;
+            return launch_concurrent(nullptr, false, 0);
         }
         lpt(S->unit_ms, QC_NSTREAMS);
         EventList evl;
@@ -714,11 +961,34 @@ int qc_launch_fock_classes(qc_system *S, const QcFockArgs &fa, float *class_ms, 
         std::vector<std::vector<float>> weight;
         std::vector<float> total;
         static const bool dbg = getenv("QC_TUNE_DEBUG") != nullptr;
+        // One build as the steady state runs it, timed.  Inside SCF passes that is the speculative form (scf_iterate): every launch of the
+        // build is in its queue when the fork word is released, the side chains start a few microseconds apart on the device.  The tuner's
+        // builds take the same form - a holding kernel on the handle's stream keeps the release back until the host has issued everything -
+        // because which assignment wins depends on how the launches start (measured: assignments tuned with host-issued, event-forked
+        // builds ran 15 % slower in the speculative form than in their own).  QC_NO_SPEC / event joins / f64 atomics: the host-issued form.
+        const bool spec_form = !S->join_by_events && fa.fxs != nullptr && getenv("QC_SPEC") != nullptr && getenv("QC_NO_SPEC") == nullptr && getenv("QC_TUNE_EVENT_FORM") == nullptr;
+        auto steady_build = [&](float &t) -> int {
+            if (fa.G0) QC_HIP_CHECK(hipMemsetAsync(fa.G0, 0, gbytes, S->stream));
+            unsigned q = 0;
+            if (spec_form) {
+                S->hold_seq += 1;
+                hipLaunchKernelGGL(qc_hold_kernel, dim3(1), dim3(64), 0, S->stream, S->h_hold, S->hold_seq, 5000000LL);     // (gives up after 50 ms)
+                q = ++S->fork_seq;
+                qc_spec_release(S->stream, S->d_join, q, nullptr, S->nbasis, 0, 0.0, nullptr, nullptr, 0);
+            }
+            int r = launch_concurrent(ev.data(), false, q);
+            if (spec_form) __atomic_store_n(S->h_hold, S->hold_seq, __ATOMIC_RELEASE);
+            if (r != QC_OK) return r;
+            QC_HIP_CHECK(hipEventSynchronize(ev[1]));
+            if ((r = qc_join_check(S)) != QC_OK) return r;
+            QC_HIP_CHECK(hipEventElapsedTime(&t, ev[0], ev[1]));
+            return QC_OK;
+        };
         for (int round = 0; round < QC_TUNE_ROUNDS; ++round) {
             for (int rep = 0; rep < 2; ++rep) {             // the second run of a candidate is the one that counts
                 if (fa.G0) QC_HIP_CHECK(hipMemsetAsync(fa.G0, 0, gbytes, S->stream));
-                if ((rc = launch_concurrent(ev.data(), true)) != QC_OK) return rc;
-                QC_HIP_CHECK(hipEventSynchronize(ev[1]));
+                if ((rc = launch_concurrent(ev.data(), true, 0)) != QC_OK) return rc;
+                QC_HIP_CHECK(hipEventSynchronize(ev[1])); if ((rc = qc_join_check(S)) != QC_OK) return rc;
             }
             float tot = 0.f;
             QC_HIP_CHECK(hipEventElapsedTime(&tot, ev[0], ev[1]));
@@ -756,11 +1026,8 @@ int qc_launch_fock_classes(qc_system *S, const QcFockArgs &fa, float *class_ms, 
                 S->unit_stream = cand[i]; S->unit_weight = weight[i];
                 float tmin = 1e30f;
                 for (int rep = 0; rep < 3; ++rep) {
-                    if (fa.G0) QC_HIP_CHECK(hipMemsetAsync(fa.G0, 0, gbytes, S->stream));
-                    if ((rc = launch_concurrent(ev.data(), false)) != QC_OK) return rc;
-                    QC_HIP_CHECK(hipEventSynchronize(ev[1]));
                     float t = 0.f;
-                    QC_HIP_CHECK(hipEventElapsedTime(&t, ev[0], ev[1]));
+                    if ((rc = steady_build(t)) != QC_OK) return rc;
                     if (rep > 0) tmin = std::min(tmin, t);
                 }
                 total[i] = tmin;
@@ -780,12 +1047,9 @@ int qc_launch_fock_classes(qc_system *S, const QcFockArgs &fa, float *class_ms, 
                 S->unit_stream = assign; S->unit_weight = w;
                 t = 1e30f;
                 for (int rep = 0; rep < 2; ++rep) {
-                    if (fa.G0) QC_HIP_CHECK(hipMemsetAsync(fa.G0, 0, gbytes, S->stream));
-                    int r = launch_concurrent(ev.data(), false);
-                    if (r != QC_OK) return r;
-                    QC_HIP_CHECK(hipEventSynchronize(ev[1]));
                     float x = 0.f;
-                    QC_HIP_CHECK(hipEventElapsedTime(&x, ev[0], ev[1]));
+                    int r = steady_build(x);
+                    if (r != QC_OK) return r;
                     t = std::min(t, x);
                 }
                 return QC_OK;
@@ -801,7 +1065,7 @@ int qc_launch_fock_classes(qc_system *S, const QcFockArgs &fa, float *class_ms, 
                 std::vector<int> trial = cur;
                 const int u = act[next() % act.size()];
                 if (next() & 1) {
-                    const int k = (int)(next() % QC_NSTREAMS);
+                    const int k = (int)(next() % std::min(QC_NSTREAMS, S->nlanes));
                     if (k == trial[u]) continue;
                     trial[u] = k;
                 } else {
@@ -831,11 +1095,8 @@ int qc_launch_fock_classes(qc_system *S, const QcFockArgs &fa, float *class_ms, 
             S->unit_stream = cand[rank[r]]; S->unit_weight = weight[rank[r]];
             float tmin = 1e30f;
             for (int rep = 0; rep < 3; ++rep) {
-                if (fa.G0) QC_HIP_CHECK(hipMemsetAsync(fa.G0, 0, gbytes, S->stream));
-                if ((rc = launch_concurrent(ev.data(), false)) != QC_OK) return rc;
-                QC_HIP_CHECK(hipEventSynchronize(ev[1]));
                 float t = 0.f;
-                QC_HIP_CHECK(hipEventElapsedTime(&t, ev[0], ev[1]));
+                if ((rc = steady_build(t)) != QC_OK) return rc;
                 tmin = std::min(tmin, t);
             }
             if (dbg) fprintf(stderr, "[tune] final cand %zu: %.3f ms\n", rank[r], tmin);
@@ -851,11 +1112,13 @@ int qc_launch_fock_classes(qc_system *S, const QcFockArgs &fa, float *class_ms, 
         }
         S->unit_stream = cand[best]; S->unit_weight = weight[best];
         S->tuned_best_ms = best_t; S->tune_count += 1; S->inpass_sum = 0.0; S->inpass_n = 0;
-        S->cand_skip = true;                             // (the time of THIS build contains the tuning)
+        S->assign_gen += 1;
+        S->cand_skip = true;                             // (the first build under the new assignment is not a sample)
         if (fa.G0) QC_HIP_CHECK(hipMemsetAsync(fa.G0, 0, gbytes, S->stream));
         nofork = false;                                  // the side streams must see that memset (and the tuner's builds) finished
+        untuned.keep = true;
     }
-    return launch_concurrent(nullptr, false);
+    return launch_concurrent(nullptr, false, fa.fork_seq);
 }
 
 // Online choice between the tuner's finalists.  The tuning builds run back to back; inside an SCF pass a build follows ~20 small
@@ -865,16 +1128,27 @@ int qc_launch_fock_classes(qc_system *S, const QcFockArgs &fa, float *class_ms, 
 // change results (integer accumulation), only time.
 constexpr int QC_ONLINE_SAMPLES = 3;
 constexpr int QC_INPASS_SAMPLES = 4;
-void qc_fock_feedback(qc_system *S, float build_ms) {
+// A build may be issued speculatively (device-side fork, scf_iterate) when nothing of it needs the host: the stream assignment is tuned
+// (a tuner run waits for its builds), the side streams are joined on the device, and the accumulation is the fixed-point one whose
+// closing fold leaves the planes clean (the f64 mode starts with a memset the side streams would have to wait for).
+bool qc_fock_can_speculate(const qc_system *S) {
+    return S->device_ready && !S->join_by_events && S->accum_fx && S->launch_plan && !S->unit_ms.empty() &&
+           S->unit_ms.size() == S->launch_plan->units.size();
+}
+// (`gen`: the stream assignment the build ran under.  With the pass end seen through the sequence word - and with speculative builds -
+// a build's time arrives one or two builds after it was issued; a sample of an assignment that has been replaced since is dropped,
+// and so is the first one of a new assignment.)
+void qc_fock_feedback(qc_system *S, float build_ms, unsigned gen) {
     int nc = (int)S->cand_stream.size();
     if (S->unit_stream.empty()) return;
+    if (gen != S->assign_gen) return;
     S->builds_seen += 1;
     // (the second tuner run keeps its own best: no sampling of finalists, the whole procedure ends within a dozen builds)
     if (S->second_stage == 1 && nc >= 2 && !S->cand_frozen) { S->cand_frozen = true; nc = 0; }
     static const bool no_second = getenv("QC_TUNE_ONCE") != nullptr;           // (A/B switch)
     if ((nc < 2 || S->cand_frozen) && S->second_stage < 2 && !no_second) {
         // second opinion: in-pass mean of the current assignment against the tuner's figure
-        if (S->cand_skip) { S->cand_skip = false; return; }
+        if (S->cand_skip) { S->cand_skip = false; return; }      // (first build under this assignment)
         S->inpass_sum += build_ms; S->inpass_n += 1;
         if (S->inpass_n < QC_INPASS_SAMPLES) return;
         const double mean = S->inpass_sum / S->inpass_n;
@@ -884,11 +1158,12 @@ void qc_fock_feedback(qc_system *S, float build_ms) {
             if (dbg) fprintf(stderr, "[tune] in-pass builds %.3f ms vs %.3f ms tuned: one more tuner run\n", mean, S->tuned_best_ms);
             S->first_mean = mean; S->first_stream = S->unit_stream; S->first_weight = S->unit_weight;
             S->second_stage = 1;
-            S->unit_ms.clear();                            // the next build tunes again (its time is not counted: cand_skip)
+            S->assign_gen += 1;                            // (builds already issued under the first choice are no samples of the second)
+            S->unit_ms.clear();                            // the next build tunes again (its time is not a sample: the caller leaves builds with a tuner run out)
             S->cand_stream.clear(); S->cand_weight.clear(); S->cand_ms.clear(); S->cand_n.clear(); S->cand_frozen = false; S->cand_cur = 0;
         } else {
             if (dbg) fprintf(stderr, "[tune] in-pass builds: first choice %.3f ms, second %.3f ms\n", S->first_mean, mean);
-            if (S->first_mean < mean) { S->unit_stream = S->first_stream; S->unit_weight = S->first_weight; S->cand_stream.clear(); S->cand_frozen = true; }
+            if (S->first_mean < mean) { S->unit_stream = S->first_stream; S->unit_weight = S->first_weight; S->cand_stream.clear(); S->cand_frozen = true; S->assign_gen += 1; }
             S->second_stage = 2;
         }
         return;
@@ -907,7 +1182,7 @@ void qc_fock_feedback(qc_system *S, float build_ms) {
         static const bool dbg = getenv("QC_TUNE_DEBUG") != nullptr;
         if (dbg) { fprintf(stderr, "[tune] online:"); for (int k = 0; k < nc; ++k) fprintf(stderr, " cand %d %.3f ms", k, S->cand_ms[k] / S->cand_n[k]); fprintf(stderr, " -> %d\n", next); }
     }
-    if (next != c) { S->cand_cur = next; S->unit_stream = S->cand_stream[next]; S->unit_weight = S->cand_weight[next]; S->cand_skip = true; }
+    if (next != c) { S->cand_cur = next; S->unit_stream = S->cand_stream[next]; S->unit_weight = S->cand_weight[next]; S->cand_skip = true; S->assign_gen += 1; }
 }
 
 // temporary device buffer of the two set-up passes below: released on every return path

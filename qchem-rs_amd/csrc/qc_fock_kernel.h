@@ -46,7 +46,14 @@ struct QcKernelArgs {
                               // the scale 2^S of this build at fxs[0] (qc_fx_scale_kernel); null = f64 atomics
     size_t fx_lo;             // doubles from an element of the hi plane to the same element of the lo plane
     double *schwarz_out;      // if non-null: no digestion - the slots are (P|P) quartets and sqrt(max |(ab|cd)|) goes to [P]
+    const unsigned *cancel;   // non-null: a speculative build (issued before the host knew that the SCF pass in front of it would not be the
+    unsigned cancel_seq;      // last one) - its kernels return at once when *cancel == cancel_seq (qc_spec_release_kernel, qc_scf_small.hip)
 };
+
+// (every class kernel starts with this: one scalar load)
+__device__ __forceinline__ bool qc_build_cancelled(const QcKernelArgs &a) {
+    return a.cancel != nullptr && __hip_atomic_load(a.cancel, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == a.cancel_seq;
+}
 
 // ---- order-independent, exact accumulation.  The digestion adds ~10^3 contributions from different waves into every
 // element of Gt; with f64 atomics the sum depends on the order the memory system happens to serve them in, so two builds
@@ -969,6 +976,7 @@ struct QcTierArgs {
 template <int LAB, int TIER>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(((TIER == 0 && LAB <= 2) || TIER == 2) ? 2 : 1)))
 void qc_fock_tier_kernel(const QcTierArgs a) {
+    if (qc_build_cancelled(a.base)) return;
     // the high-L tiers are few, long, latency-bound waves: let them win issue arbitration against the many short
     // low-L waves they share a SIMD with
     if constexpr (TIER >= 1) __builtin_amdgcn_s_setprio(3);
@@ -994,9 +1002,13 @@ void qc_fock_tier_kernel(const QcTierArgs a) {
 // workgroups now fill the chip together.  All three kernels ran at one wave per SIMD already (256 + 6 / 12 / 70 registers), so the merged
 // kernel costs no occupancy; every workgroup gets the largest segment's LDS (17 KB instead of 8-10 for the LAB <= 1 buckets: four waves per
 // CU, no limit).  The per-class launches of the profiling / set-up passes keep the per-LAB kernels.
+#ifndef QC_T1LOW_WAVES
+#define QC_T1LOW_WAVES(V) 1
+#endif
 template <int V>     // (every instance lives in its own translation unit: gen/qc_fock_low1.hip, _mid1, _hi1)
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1)))
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(QC_T1LOW_WAVES(V))))
 void qc_fock_tier1_low_kernel(const QcTierArgs a) {
+    if (qc_build_cancelled(a.base)) return;
     __builtin_amdgcn_s_setprio(3);
     int s = 0;
     while (s + 1 < a.nseg && (int)blockIdx.x >= a.seg_end[s]) ++s;

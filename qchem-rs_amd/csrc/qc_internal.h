@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <atomic>
 #include <cstdint>
 #include <cstdio>
 #include <string>
@@ -149,6 +150,12 @@ struct qc_system {
     hipStream_t stream = nullptr;
     bool own_stream = false;
     hipStream_t side[QC_NSTREAMS] = {};
+    // Dispatch lanes (qc_lane_probe): the chip dispatches at most FOUR kernels at a time - hardware queues sit in pairs on four pipes, and a
+    // pipe works on one dispatch until all its workgroups are launched.  slot_side[k] = side stream behind assignment slot k; the first
+    // `nlanes` slots are on distinct pipes, slot 0 on the pipe of the handle's own stream (when one of the side streams shares it).
+    int slot_side[QC_NSTREAMS] = {0, 1, 2, 3, 4, 5, 6};
+    int nlanes = QC_NSTREAMS;
+    bool lane0_is_main = false;
     hipEvent_t ev_fork = nullptr, ev_join[QC_NSTREAMS] = {};
     double *d_pairdata = nullptr, *d_pairdataT = nullptr, *d_pspack = nullptr;
     void *d_shells = nullptr;                // shells / primitives / transforms / nuclei for the one-electron kernels (one blob)
@@ -163,9 +170,24 @@ struct qc_system {
     double *d_Dj = nullptr;
     double *d_fxs = nullptr;                 // [2^S, 2^-S]: fixed-point scale of the current build
     int *d_flag = nullptr;
-    unsigned *d_join = nullptr;              // counter of the device-side join of a build's side streams (qc_join_mark / qc_join_wait)
-    int *h_join_timeout = nullptr;           // pinned: set by a join that gave up (a side stream's launches never finished)
+    unsigned *d_join = nullptr;              // [0] counter of the device-side join of a build's side streams (qc_join_mark / qc_join_wait);
+                                             // [1] fork word: number of the last pass whose densities are final (device-side fork of a speculative build);
+                                             // [2] number of the speculative build that was cancelled on the device (its class kernels return at once)
+    int *h_join_timeout = nullptr;           // pinned: set by a device-side wait that gave up (the launches it waited for never finished)
     unsigned join_target = 0;
+    unsigned *h_hold = nullptr; unsigned hold_seq = 0;   // pinned: the tuner's holding kernel waits for hold_seq (qc_hold_kernel)
+    unsigned fork_seq = 0;                   // last value promised to the fork word: the speculative build of pass k + 1 waits for fork_seq = k's number
+    long long wait_limit = 0;                // device-side waits give up after this many ticks of the 100 MHz clock (qc_wait_limit)
+    std::atomic<bool> waits_in_flight{false}; // device-side waits were issued and the host has not seen the handle's stream drained since (qc_gate)
+    // speculative build (scf_iterate): the NEXT pass's Fock build, issued behind this pass's Roothaan step before the host has seen the pass end
+    struct QcSpec {
+        bool pending = false;                // issued and not yet consumed / discarded
+        const void *owner = nullptr;         // the qc_scf_state it belongs to
+        const double *Da = nullptr, *Db = nullptr;   // densities it digests
+        double *Ga = nullptr, *Gb = nullptr; // where its closing kernel leaves G
+        bool f_done = false;                 // ... and F = H + G (the next pass's DIIS slots)
+        unsigned seq = 0;                    // its number (fork word value it waited for; cancel word value that empties it)
+    } spec;
     int issue_threads = -1;                  // helper threads that issue a build's launches: -1 = by the size of the build (qc_fock.hip)
     bool prep_enqueued = false;              // qc_fock_prepare_device put work on the handle's stream (see scf_iterate)
     bool join_by_events = false;             // dispatches are serialised here (qc_join_probe): the side streams are joined through events
@@ -182,6 +204,7 @@ struct qc_system {
     std::vector<int> cand_n;
     int cand_cur = 0;
     bool cand_frozen = false, cand_skip = false;
+    unsigned assign_gen = 0;                 // counts the changes of the stream assignment: a build's time is a sample of the assignment it ran under
     // second opinion (qc_fock_feedback): the tuner measures builds back to back; inside SCF passes the same assignment is 7-22 % slower,
     // and by how much differs from one tuner run to the next.  When the passes' builds are > 10 % slower than the tuner's figure, the
     // tuner runs ONCE more and the assignment with the better in-pass mean stays.
@@ -237,6 +260,9 @@ struct QcFockArgs {
     const double *fxs;    // non-null: G0 / G1 accumulate 64-bit fixed-point integers (hi plane), scale 2^S at fxs[0], 2^-S at fxs[1] (device)
     size_t fx_lo;         // doubles from the hi plane to the lo plane
     double *schwarz_out;  // non-null: Schwarz pass over the (P|P) quartets, sqrt(max |(ab|cd)|) per pair (device), no digestion
+    // device-side fork (speculative build of the next SCF pass): side streams start with a one-lane kernel that waits for the fork word to
+    // reach fork_seq; the class kernels return at once when the cancel word equals it
+    unsigned fork_seq = 0;   // 0: no device fork
 };
 int qc_launch_eri_full(qc_system *S, double *d_out);
 int qc_schwarz_device(qc_system *S);     // fills pairQ / imax from the (P|P) quartets, then screens the work lists
@@ -244,12 +270,19 @@ int qc_schwarz_device(qc_system *S);     // fills pairQ / imax from the (P|P) qu
 void qc_fx_scale(hipStream_t st, int n, const double *Da, const double *Db /*nullable*/, double imax, double *out);
 int qc_one_electron_device(qc_system *S, int which /* 0 S, 1 T, 2 V */, double *d_out);
 int qc_launch_fock_classes(qc_system *S, const QcFockArgs &a, float *class_ms /*nullable*/, float *unit_ms = nullptr /*nullable, 14*/, bool nofork = false);
-void qc_fock_feedback(qc_system *S, float build_ms);      // hipEvent time of a build inside an SCF pass (no-op once the choice is made)
+// hipEvent time of a build inside an SCF pass that ran under stream assignment `gen` (no-op once the choice is made)
+void qc_fock_feedback(qc_system *S, float build_ms, unsigned gen);
+bool qc_fock_can_speculate(const qc_system *S);            // the next build may be issued with a device-side fork (tuned, device join, fixed point)
+void qc_spec_release(hipStream_t st, unsigned *words, unsigned seq, const double *scal, int n, int nspin, double eps, unsigned *h_cancel,
+                     unsigned *h_seq, unsigned seqval);
+int qc_join_check(qc_system *S);                           // after a host wait: QC_ERR_HIP if a device-side wait of the handle gave up
+void qc_gate_quiet(qc_system *S);                          // the host has seen the handle's stream drained: none of its waits is in flight
 // (scale_done: the fixed-point unit of these densities is already in d_fxs - written by the kernel that produced them)
 int qc_fock_prepare_device(qc_system *S, const double *dDa, const double *dDb, bool uhf, const void *owner, bool scale_done = false);
 // (dH with dFa / dFb: the Fock matrices H + G are written by the closing kernel as well; *f_done tells whether both were)
 int qc_fock_build_device(qc_system *S, const double *dDa, const double *dDb, double *dGa, double *dGb, bool uhf, int *twin_cache = nullptr,
-                         const double *dH = nullptr, double *dFa = nullptr, double *dFb = nullptr, bool *f_done = nullptr, const void *owner = nullptr);
+                         const double *dH = nullptr, double *dFa = nullptr, double *dFb = nullptr, bool *f_done = nullptr, const void *owner = nullptr,
+                         unsigned fork_seq = 0 /* non-zero: speculative build behind the kernel that releases this value of the fork word */);
 
 // dense linear algebra on the handle's stream (all row-major n x n, device pointers)
 void qc_gemm(hipStream_t st, int m, int n, int k, double alpha, const double *A, int lda, bool ta, const double *B,
@@ -348,6 +381,9 @@ struct QcSmallArgs {
     double *fxs_out; double imax;  // non-null (RHF): the fixed-point unit of the build that will digest Dn goes here (qc_fx_scale)
     int *ctl_all, *ctl_out;        // non-null: hand the 16 control words over to ctl_out and clear them
     unsigned *seq_out; unsigned seq; // non-null (pinned host memory): the pass's sequence number, stored after everything else the host reads
+    // non-null: a speculative build of the next pass is queued behind this kernel - release the fork word fork_words[1] = fork_seq at the
+    // end; before that, if the pass meets the reference's stopping rule at eps (> 0), cancel that build (fork_words[2], *h_cancel)
+    unsigned *fork_words; unsigned fork_seq; double eps; unsigned *h_cancel;
 };
 int qc_scf_small_launch(hipStream_t st, const QcSmallArgs &a);
 size_t qc_scf_small_lds_bytes(int n);

@@ -574,6 +574,20 @@ __global__ __launch_bounds__(QCS_T) void qc_scf_small_kernel(const QcSmallArgs a
         }
     }
     __threadfence_system();
+    if (a.fork_words) {
+        // A speculative build of the next pass is queued behind this kernel: its side streams wait for the fork word, its class kernels look
+        // at the cancel word (qc_fock.hip, "Device-side fork").  If this pass meets the stopping rule the host has announced (rhf.rs:94:
+        // rms < epsilon, rms = sqrt(sum_i dD_ii^2 / n) as the host forms it), that build is emptied - and the host told so, in pinned memory,
+        // before it can see the pass end.  When the eigensolve wants a repeat (!ok) the host discards the build; it is released all the same.
+        __syncthreads();
+        if (tid == 0) {
+            if (a.eps > 0.0 && (a.phases & 4) && ok && sqrt(scal[1] / n) < a.eps) {
+                __hip_atomic_store(a.fork_words + 2, a.fork_seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (a.h_cancel) __hip_atomic_store(a.h_cancel, a.fork_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
+            __hip_atomic_store(a.fork_words + 1, a.fork_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
     if (a.seq_out) {     // the host polls this word instead of the stream's event (which the packet processor signals some microseconds later)
         __syncthreads();
         if (tid == 0) __hip_atomic_store(a.seq_out, a.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);

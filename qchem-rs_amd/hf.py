@@ -41,7 +41,8 @@ EXPORTS = ["qc_system_create", "qc_system_destroy", "qc_nbasis", "qc_nelectrons"
            "qc_fock_rhf_device", "qc_fock_uhf_device", "qc_sym_eig", "qc_scf_rhf", "qc_scf_uhf", "qc_comm_unique_id",
            "qc_comm_init", "qc_set_shard", "qc_plan_shard", "qc_set_stream", "qc_device_ready", "qc_work_stats_get",
            "qc_fock_profile", "qc_plan_shard_quartets", "qc_scf_begin_rhf", "qc_scf_begin_uhf", "qc_scf_iterate",
-           "qc_scf_orbital_energies", "qc_scf_density", "qc_scf_spin_square", "qc_scf_timings", "qc_scf_end", "qc_fock_profile_tiers", "qc_unit_quartets", "qc_sym_eig_warm", "qc_set_fock_mode", "qc_scf_tensor_ms", "qc_set_accumulation", "qc_set_schwarz", "qc_scf_matrix", "qc_rccl_info", "qc_measure_peaks"]
+           "qc_scf_orbital_energies", "qc_scf_density", "qc_scf_spin_square", "qc_scf_timings", "qc_scf_end", "qc_fock_profile_tiers", "qc_unit_quartets", "qc_sym_eig_warm", "qc_set_fock_mode", "qc_scf_tensor_ms", "qc_set_accumulation", "qc_set_schwarz", "qc_scf_matrix", "qc_rccl_info", "qc_measure_peaks",
+           "qc_scf_set_stop_rule", "qc_scf_counters"]
 
 
 class QcError(RuntimeError):
@@ -57,7 +58,7 @@ class _Output(C.Structure):
     _fields_ = [("orbital_energies", C.POINTER(C.c_double)), ("orbital_energies_beta", C.POINTER(C.c_double)),
                 ("electronic_energy", C.c_double), ("nuclear_repulsion", C.c_double), ("iterations", C.c_size_t),
                 ("ms_setup", C.c_double), ("ms_fock_total", C.c_double), ("ms_linalg_total", C.c_double),
-                ("ms_total", C.c_double)]
+                ("ms_total", C.c_double), ("ms_tuner", C.c_double)]
 
 
 class WorkStats(C.Structure):
@@ -130,6 +131,8 @@ def lib():
         L.qc_scf_spin_square.argtypes = [vp, C.POINTER(C.c_double)]
         L.qc_scf_timings.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double)]
         L.qc_scf_end.argtypes = [vp]; L.qc_scf_end.restype = None
+        L.qc_scf_set_stop_rule.argtypes = [vp, C.c_double]
+        L.qc_scf_counters.argtypes = [vp, C.POINTER(C.c_double)]
         _lib = L
     return _lib
 
@@ -286,7 +289,9 @@ class ScfStepper:
     """One loop-body pass per call (`qc_scf_begin_* / qc_scf_iterate / qc_scf_end`): what a host that owns the
     convergence loop binds, and what bench.py times."""
 
-    def __init__(self, system: "System", uhf: bool = False, n_alpha: int = 0, n_beta: int = 0):
+    def __init__(self, system: "System", uhf: bool = False, n_alpha: int = 0, n_beta: int = 0, stop_rule: float = 0.0):
+        """stop_rule > 0: the caller's loop ends once the reference's test holds at that epsilon (rhf.rs:94 / uhf.rs:139); told to the
+        library so that the Fock build it queues behind a converging pass is emptied on the device (qc_scf_set_stop_rule)."""
         self.system = system
         self.uhf = uhf
         self._st = C.c_void_p()
@@ -294,6 +299,8 @@ class ScfStepper:
             _check(lib().qc_scf_begin_uhf(system.handle, n_alpha, n_beta, C.byref(self._st)), "qc_scf_begin_uhf")
         else:
             _check(lib().qc_scf_begin_rhf(system.handle, C.byref(self._st)), "qc_scf_begin_rhf")
+        if stop_rule > 0.0:
+            _check(lib().qc_scf_set_stop_rule(self._st, float(stop_rule)), "qc_scf_set_stop_rule")
         # (the per-pass call is a host's inner loop: the foreign function and its out-parameters are bound once)
         self._iterate = lib().qc_scf_iterate
         self._e, self._r = C.c_double(), C.c_double()
@@ -329,6 +336,14 @@ class ScfStepper:
         a, b, c = C.c_double(), C.c_double(), C.c_double()
         _check(lib().qc_scf_timings(self._st, C.byref(a), C.byref(b), C.byref(c)), "qc_scf_timings")
         return dict(setup=a.value, fock=b.value, linalg=c.value)
+
+    def counters(self):
+        """ms_setup, ms_fock (builds with a tuner run left out), ms_linalg, builds behind ms_fock, host ms of tuner runs, passes,
+        speculative builds consumed / discarded."""
+        v = (C.c_double * 8)()
+        _check(lib().qc_scf_counters(self._st, v), "qc_scf_counters")
+        k = ("setup", "fock", "linalg", "builds_timed", "tuner", "passes", "spec_hits", "spec_lost")
+        return dict(zip(k, [float(x) for x in v]))
 
     def close(self):
         if self._st:
@@ -413,7 +428,7 @@ def _run(fn, system, config, uhf):
     _check(rc, fn)
     if rc == QC_NOT_CONVERGED:
         return None                                       # rhf.rs:106-107
-    t = dict(setup=out.ms_setup, fock=out.ms_fock_total, linalg=out.ms_linalg_total, total=out.ms_total)
+    t = dict(setup=out.ms_setup, fock=out.ms_fock_total, linalg=out.ms_linalg_total, total=out.ms_total, tuner=out.ms_tuner)
     if uhf:
         return UnrestrictedHartreeFockOutput(wa.tolist(), wb.tolist(), out.electronic_energy, out.nuclear_repulsion,
                                              int(out.iterations), t)

@@ -452,7 +452,10 @@ def test_launch_structure_switches_do_not_change_a_bit(monkeypatch):
     s0 = q.System(m)
     G0 = s0.fock_rhf(D)
     e0 = q.restricted_hartree_fock(s0, q.HartreeFockConfig(100, 1e-10))
-    for env in ({"QC_EVENT_JOIN": "1"}, {"QC_ISSUE_THREADS": "3"}, {"QC_ISSUE_THREADS": "2", "QC_EVENT_WAIT": "1"}):
+    # (round 4: QC_SPEC - speculative build of the next pass behind the Roothaan step, device-side fork; QC_NO_LANES - launch units drawn
+    # among all seven side streams instead of the four dispatch lanes)
+    for env in ({"QC_EVENT_JOIN": "1"}, {"QC_ISSUE_THREADS": "3"}, {"QC_ISSUE_THREADS": "2", "QC_EVENT_WAIT": "1"}, {"QC_SPEC": "1"},
+                {"QC_SPEC": "1", "QC_EVENT_WAIT": "1"}, {"QC_NO_LANES": "1"}):
         for k, v in env.items():
             monkeypatch.setenv(k, v)
         s = q.System(m)
@@ -466,6 +469,120 @@ def test_launch_structure_switches_do_not_change_a_bit(monkeypatch):
         for k in env:
             monkeypatch.delenv(k)
     s0.close()
+
+
+@pytest.mark.parametrize("mol,basis,uhf,na,nb,EPS", [("water", "cc-pVTZ", False, 0, 0, 1e-9), ("water", "cc-pVDZ", True, 0, 0, 1e-9), ("oxygen", "cc-pVDZ", True, 9, 7, 1e-9),
+                                                     ("ethylene", "cc-pVDZ", False, 0, 0, 1e-9), ("benzene", "6-31G_st_st", False, 0, 0, 1e-6)])
+def test_speculative_builds_are_used_cancelled_and_never_show(mol, basis, uhf, na, nb, EPS, monkeypatch):
+    """scf_iterate issues the next pass's Fock build behind the pass it is asked for (device-side fork).  Every pass after
+    the first must find its build in flight; the trajectory is bit for bit the one of the host-driven boundary (QC_NO_SPEC); with the
+    stopping rule announced the build behind the converging pass is emptied on the device, and a host that goes on regardless - or one
+    that never announced a rule - still gets correct passes.  All launch paths: one-workgroup RHF (release inside the kernel), closed-shell
+    UHF on that path (release kernel that also ends the pass), open-shell and n > 64 (generic sequence, event wait)."""
+    import qchem_rs_amd as q
+    m = load_system(mol, basis)
+
+    def run(stop_rule, extra, s):
+        st = q.ScfStepper(s, uhf=uhf, n_alpha=na, n_beta=nb, stop_rule=stop_rule)
+        tr, k_conv = [], None
+        for k in range(60):
+            e, r = st.iterate()
+            tr.append((e, r))
+            if k_conv is None and (r / 2 if uhf else r) < EPS:
+                k_conv = k
+            if k_conv is not None and k >= k_conv + extra:
+                break
+        c = st.counters()
+        st.close()
+        return tr, k_conv, c
+
+    s_ref = q.System(m)                                            # (default: host-driven pass boundary)
+    ref, k_ref, c_ref = run(0.0, 2, s_ref)
+    assert k_ref is not None and c_ref["spec_hits"] == 0
+    monkeypatch.setenv("QC_SPEC", "1")
+    s = q.System(m)
+    warm, _, _ = run(0.0, 0, s)                                   # (first run on a handle: its first build tunes the streams)
+    assert warm == ref[:len(warm)]
+    a, k_a, c_a = run(0.0, 2, s)                                  # no rule announced: every later pass consumes a speculative build
+    assert a == ref and k_a == k_ref
+    # (a pass whose eigensolve had to be repeated discards the build queued behind it)
+    assert c_a["spec_hits"] + c_a["spec_lost"] == len(a) - 1 and c_a["spec_lost"] <= len(a) // 4, c_a
+    b, k_b, c_b = run(EPS, 2, s)                                  # rule announced, host goes on for two more passes anyway
+    assert b == ref and k_b == k_ref
+    # the build behind the converging pass and behind each later pass that still meets the rule was emptied and rebuilt on request
+    assert c_b["spec_lost"] >= 1 and c_b["spec_hits"] + c_b["spec_lost"] == len(b) - 1, c_b
+    out = (q.unrestricted_hartree_fock if uhf else q.restricted_hartree_fock)(s, q.HartreeFockConfig(100, EPS, na, nb))
+    assert out.iterations == k_ref and out.electronic_energy == ref[k_ref][0]
+    s.close(); s_ref.close()
+
+
+def test_a_wait_that_gives_up_fails_the_call_that_waited(monkeypatch):
+    """A device-side wait (join of the side streams, fork of a speculative build) that runs into its limit has folded an incomplete
+    matrix: the call whose host wait follows it returns QC_ERR_HIP (never a wrong G), and the handle goes on with event joins.  The
+    limit is forced to nothing here (QC_WAIT_LIMIT_MS): every wait that has to wait at all gives up."""
+    import qchem_rs_amd as q
+    m = load_system("water", "cc-pVTZ")
+    D = _rand_sym(58, 7)
+    s = q.System(m)
+    G0 = s.fock_rhf(D)                                            # tuned, device join
+    monkeypatch.setenv("QC_WAIT_LIMIT_MS", "0.00001")
+    s2 = q.System(m)                                              # (the limit is read once per process: a fresh library copy is not needed, a fresh handle is)
+    failed = 0
+    for _ in range(4):
+        try:
+            G = s2.fock_rhf(D)
+            assert np.array_equal(G, G0)                          # a call that succeeds is complete
+        except q.hf.QcError:
+            failed += 1
+    monkeypatch.delenv("QC_WAIT_LIMIT_MS")
+    assert failed >= 1                                            # the first concurrent build's join cannot be instant
+    assert np.array_equal(s2.fock_rhf(D), G0)                     # event joins from now on
+    s.close(); s2.close()
+
+
+def test_two_handles_from_two_threads(monkeypatch):
+    """`distinct handles may be used from distinct threads` (include/qchem_hip.h): two SCF runs on one device at the same time - both
+    with device-side waits and speculative builds - end bit-identical to the same runs alone (per-device issue gate, qc_fock.hip)."""
+    import threading
+    import qchem_rs_amd as q
+    mols = [load_system("water", "cc-pVTZ"), load_system("ethylene", "cc-pVDZ")]
+    cfg = q.HartreeFockConfig(100, 1e-10)
+    alone = []
+    hs = [q.System(m) for m in mols]
+    for h in hs:
+        alone.append(q.restricted_hartree_fock(h, cfg))
+    for spec in (False, True):
+        if spec:
+            monkeypatch.setenv("QC_SPEC", "1")
+        res = [[None] * 3, [None] * 3]
+
+        def work(i):
+            for r in range(3):
+                res[i][r] = q.restricted_hartree_fock(hs[i], cfg)
+
+        th = [threading.Thread(target=work, args=(i,)) for i in range(2)]
+        for t in th:
+            t.start()
+        for t in th:
+            t.join(timeout=300)
+        assert not any(t.is_alive() for t in th)
+        for i in range(2):
+            for r in range(3):
+                o = res[i][r]
+                assert o is not None and o.iterations == alone[i].iterations and o.electronic_energy == alone[i].electronic_energy, spec
+                assert o.orbital_energies == alone[i].orbital_energies, spec
+    # one thread stepping two states of two handles alternately (a speculative build of one is in flight while the other issues)
+    st = [q.ScfStepper(h, stop_rule=1e-10) for h in hs]
+    tr = [[], []]
+    for k in range(12):
+        for i in range(2):
+            tr[i].append(st[i].iterate())
+    for i in range(2):
+        st[i].close()
+        one = q.ScfStepper(hs[i]); ref = [one.iterate() for _ in range(12)]; one.close()
+        assert tr[i] == ref
+    for h in hs:
+        h.close()
 
 
 def test_scf_runs_are_bitwise_reproducible():
