@@ -147,9 +147,11 @@ int qc_scf_timings(qc_scf_state *st, double *ms_setup, double *ms_fock, double *
  * kernel that ends a pass evaluates it on the device and empties the build queued behind a converging pass instead of running it for
  * nothing.  A host that goes on regardless gets a regular build.  epsilon = 0 (default): no rule; qc_scf_rhf / qc_scf_uhf set theirs. */
 int qc_scf_set_stop_rule(qc_scf_state *st, double epsilon);
-/* out[0..7] = ms_setup, ms_fock (builds that contained a tuner run are left out), ms_linalg, builds counted in ms_fock, host ms of
- * the tuner runs, passes done, speculative builds consumed, speculative builds discarded */
-int qc_scf_counters(qc_scf_state *st, double out[8]);
+/* out[0 .. n) of: ms_setup, ms_fock (builds that contained a tuner run are left out), ms_linalg, builds counted in ms_fock, host ms of
+ * the first build's timing passes, passes done, speculative builds consumed, speculative builds discarded, passes whose eigensolve was
+ * repeated, trials of the online stream-assignment search so far (handle-wide), 1 once that search has ended */
+#define QC_SCF_NCOUNTERS 11
+int qc_scf_counters(qc_scf_state *st, double *out, int n);
 void qc_scf_end(qc_scf_state *st);
 
 /* ---- Fock mode of the SCF drivers on this handle.  0 (default): direct - quartets are evaluated and digested every pass.
@@ -190,6 +192,10 @@ int qc_set_shard(qc_system *sys, int rank, int nranks);
 int qc_plan_shard(qc_system *sys, int rank, int nranks, int64_t *nquartets, double *flops);
 /* The shard's quartets as shell indices (A,B,C,D), 4 ints each; abcd == NULL: returns the count only. */
 int qc_plan_shard_quartets(qc_system *sys, int rank, int nranks, int32_t *abcd, int64_t capacity);
+
+/* ---- test hook (host only): one entry of a bra-major ket list - packed (pair | first primitive << 18 | length << 25; lists of systems
+ * with fewer than 2^18 stored shell pairs) or a plain pair index - written and read back the way the library does. */
+int qc_debug_ket_entry(int ket, int first_primitive, int length, int packed, int32_t out[3]);
 
 /* ---- measurement hooks */
 int qc_set_stream(qc_system *sys, void *hip_stream);  /* run on the caller's stream (e.g. torch's current stream) */

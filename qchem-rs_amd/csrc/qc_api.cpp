@@ -608,7 +608,8 @@ struct qc_scf_state {
     // measured SLOWER on MI355X (H2O/cc-pVTZ 0.38-0.44 ms per iteration against 0.31) - DESIGN.md 3.1 says why.  QC_SPEC=1 (read per
     // SCF state) switches it on.
     bool spec_on = getenv("QC_SPEC") != nullptr && getenv("QC_NO_SPEC") == nullptr;
-    int64_t spec_hits = 0, spec_lost = 0, builds_timed = 0, passes = 0;
+    int64_t spec_hits = 0, spec_lost = 0, builds_timed = 0, passes = 0, redos = 0;
+    double warm_rms_env = getenv("QC_EIG_WARM_RMS") ? atof(getenv("QC_EIG_WARM_RMS")) : 0.0;   // (read per SCF state: tests reach the repeat branch with it)
     double ms_tuner = 0;
     bool cur_build_tuned = false, pend_build_tuned = false;   // the build of the current / the pending timing set contained a tuner run
     unsigned cur_build_gen = 0, pend_build_gen = 0;           // ... and ran under this stream assignment (qc_system::assign_gen)
@@ -970,6 +971,7 @@ static int scf_iterate(qc_scf_state *st, double *energy, double *rms_out, bool m
         redo = true;
     }
     if (redo) {
+        st->redos += 1;
         // the repeated eigensolves report through the same control words (Jacobi sweeps exhausted: ctl[9]): hand them over again,
         // whichever spin was repeated, and clear them for the next pass
         QC_HIP_CHECK(hipMemcpyAsync(ctl_out, W.ctl, 16 * sizeof(int), hipMemcpyDefault, sm));
@@ -996,8 +998,7 @@ static int scf_iterate(qc_scf_state *st, double *energy, double *rms_out, bool m
         // (the one-workgroup path of small matrices pays 150 us for a cold start and nothing extra for a refinement pass that turns out to
         // be needed: it refines from the previous vectors one decade earlier - H2O/cc-pVTZ: one cold pass less per run, no repeats;
         // benzene at 1e-2: two repeated eigensolves per run, slower than 1e-3)
-        static const double warm_env = getenv("QC_EIG_WARM_RMS") ? atof(getenv("QC_EIG_WARM_RMS")) : 0.0;
-        const double warm_rms = warm_env > 0.0 ? warm_env : (W.small_fused ? 1e-2 : 1e-3);
+        const double warm_rms = st->warm_rms_env > 0.0 ? st->warm_rms_env : (W.small_fused ? 1e-2 : 1e-3);
         W.mode[s] = rms_s >= 1.0 ? 2 : (rms_s >= warm_rms || redo) ? 1 : 0;
         std::swap(st->D[s].p, st->Dn[s].p);                              // D += 1.0 * dD
         std::swap(W.CpPrev[s].p, W.CpNew[s].p);
@@ -1123,16 +1124,28 @@ int qc_scf_timings(qc_scf_state *st, double *ms_setup, double *ms_fock, double *
     return QC_OK;
 }
 void qc_scf_end(qc_scf_state *st) { scf_state_delete(st); }
+// (test hook, host only: what the bra-major work lists store for one lane and what the device-record builder reads back from it)
+int qc_debug_ket_entry(int ket, int first_primitive, int length, int packed, int32_t out[3]) {
+    if (!out || ket < 0) return QC_ERR_INVALID;
+    if (packed && (ket >= (1 << QC_KET_BITS) || first_primitive < 0 || first_primitive > 127 || length < 0 || length > 127)) return QC_ERR_INVALID;
+    const int entry = packed ? (int)qc_pack_ket_entry(ket, first_primitive, length) : ket;
+    int k, f, l;
+    qc_unpack_ket_entry(entry, packed != 0, &k, &f, &l);
+    out[0] = k; out[1] = f; out[2] = l;
+    return QC_OK;
+}
 int qc_scf_set_stop_rule(qc_scf_state *st, double epsilon) {
     if (!st || !(epsilon >= 0.0)) return QC_ERR_INVALID;
     st->eps_hint = epsilon;
     return QC_OK;
 }
-int qc_scf_counters(qc_scf_state *st, double out[8]) {
-    if (!st || !out) return QC_ERR_INVALID;
+int qc_scf_counters(qc_scf_state *st, double *out, int n) {
+    if (!st || !out || n < 0) return QC_ERR_INVALID;
     scf_flush_timing(st);
-    out[0] = st->ms_setup; out[1] = st->ms_fock; out[2] = st->ms_linalg; out[3] = (double)st->builds_timed;
-    out[4] = st->ms_tuner; out[5] = (double)st->passes; out[6] = (double)st->spec_hits; out[7] = (double)st->spec_lost;
+    const double v[QC_SCF_NCOUNTERS] = {st->ms_setup, st->ms_fock, st->ms_linalg, (double)st->builds_timed, st->ms_tuner, (double)st->passes,
+                                        (double)st->spec_hits, (double)st->spec_lost, (double)st->redos,
+                                        (double)st->S->on.trials, st->S->on.frozen ? 1.0 : 0.0};
+    for (int i = 0; i < n && i < QC_SCF_NCOUNTERS; ++i) out[i] = v[i];
     return QC_OK;
 }
 

@@ -56,7 +56,7 @@ int qc_device_ready(void) {
 }
 
 // Device records of a bra-major work list (QcBundleDev / QcKetUnit, qc_internal.h) from the host lists of qc_make_bundles
-static void qc_bm_device_lists(const qc_system *S, int lcd, const std::vector<QcBundle> &bundles, const std::vector<int> &ketlist,
+static void qc_bm_device_lists(const qc_system *S, int lcd, const std::vector<QcBundle> &bundles, const std::vector<int> &ketlist, bool packed,
                                std::vector<QcBundleDev> &db, std::vector<QcKetUnit> &du) {
     db.resize(bundles.size()); du.resize(ketlist.size());
     for (size_t i = 0; i < bundles.size(); ++i) {
@@ -65,8 +65,8 @@ static void qc_bm_device_lists(const qc_system *S, int lcd, const std::vector<Qc
         db[i] = QcBundleDev{b.bra, b.ij_lo, b.ij_hi, b.first, b.nket, b.maxK, p.doff, p.offa, p.offb, p.na | (p.nb << 8) | ((p.shA_eq_shB ? 1 : 0) << 16), b.pad0, 0};
     }
     for (size_t i = 0; i < ketlist.size(); ++i) {
-        const unsigned e = (unsigned)ketlist[i];
-        const int ket = (int)(e & 0x3ffffu), kl0 = (int)((e >> 18) & 0x7fu), klen = (int)(e >> 25);
+        int ket, kl0, klen;
+        qc_unpack_ket_entry(ketlist[i], packed, &ket, &kl0, &klen);
         const QcPairDesc &p = S->pairs[ket];
         const int stride = lcd == 0 ? qc_pair_stride(0, 1) : (lcd == 1 ? 8 : 16);
         const int K = klen ? klen : p.K;
@@ -91,7 +91,7 @@ static int upload_slots(qc_system *S) {
         }
         if (!c.bundles.empty()) {
             std::vector<QcBundleDev> db; std::vector<QcKetUnit> du;
-            qc_bm_device_lists(S, c.LCD, c.bundles, c.ketlist, db, du);
+            qc_bm_device_lists(S, c.LCD, c.bundles, c.ketlist, c.ket_packed, db, du);
             QC_HIP_CHECK(hipMalloc(&c.d_bundles, db.size() * sizeof(QcBundleDev)));
             QC_HIP_CHECK(hipMemcpy(c.d_bundles, db.data(), db.size() * sizeof(QcBundleDev), hipMemcpyHostToDevice));
             QC_HIP_CHECK(hipMalloc(&c.d_ketlist, du.size() * sizeof(QcKetUnit)));
@@ -104,8 +104,7 @@ static int upload_slots(qc_system *S) {
 int qc_device_reshard(qc_system *S) {
     S->prepared = false; S->gt_clean = false;                    // a build prepared for the old work lists must not skip the fork of the next one
     S->unit_ms.clear(); S->unit_stream.clear();
-    S->cand_stream.clear(); S->cand_weight.clear(); S->cand_ms.clear(); S->cand_n.clear(); S->cand_frozen = false; S->cand_skip = false; S->cand_cur = 0;
-    S->second_stage = 0; S->tune_count = 0; S->inpass_sum = 0.0; S->inpass_n = 0; S->builds_seen = 0;
+    S->cand_skip = false; S->tune_count = 0; S->on = qc_system::QcOnline{};
     S->assign_gen += 1;
     if (S->spec.pending) { if (S->stream) (void)hipStreamSynchronize(S->stream); S->spec.pending = false; }     // (it digests the old lists)
     qc_build_shards(S);
@@ -180,6 +179,10 @@ static int qc_lane_probe(qc_system *S);
 __global__ void qc_join_mark_kernel(unsigned *cnt);
 static void qc_gate_forget(qc_system *S);
 static void qc_issue_pool_drop(qc_system *S);
+void qc_online_reset(qc_system *S, bool frozen);
+void qc_assign_cache_lookup(qc_system *S);
+static void qc_assign_cache_store(const qc_system *S);
+constexpr int QC_SEARCH_FIRST_BUILD = 24, QC_SEARCH_CHUNK = 6, QC_SEARCH_REJECTS = 10, QC_SEARCH_TRIALS = 64;
 
 int qc_device_init(qc_system *S) {
     if (S->device_ready) return QC_OK;
@@ -236,7 +239,6 @@ int qc_device_init(qc_system *S) {
     QC_HIP_CHECK(hipMemset(S->d_join, 0, 4 * sizeof(unsigned)));
     QC_HIP_CHECK(hipHostMalloc(&S->h_join_timeout, 4 * sizeof(int), hipHostMallocDefault));
     *S->h_join_timeout = 0; S->join_target = 0;
-    S->h_hold = reinterpret_cast<unsigned *>(S->h_join_timeout + 1); *S->h_hold = 0; S->hold_seq = 0;
     {
         bool concurrent = true;
         int prc = qc_join_probe(S, &concurrent);
@@ -456,26 +458,23 @@ __global__ void qc_join_mark_kernel(unsigned *cnt) {
 // other's wave slots from the first cycle and the chain that ends the build loses its head start - measured, see launch_concurrent)
 __global__ void qc_join_wait_kernel(unsigned *cnt, unsigned target, int *timeout_flag, long long limit, int delay) {
     if (threadIdx.x != 0) return;
-    const long long t0 = wall_clock64();
+    // (poll gently: one load per ~1.7 us, the clock only every 16th time round - a fork waiter spins through a whole Roothaan step next to
+    // the one workgroup that runs it, and whatever it does to the memory system of its CU that workgroup pays)
+    long long t0 = 0;
+    unsigned it = 0;
     while ((int)(__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - target) < 0) {
-        __builtin_amdgcn_s_sleep(8);
-        if (wall_clock64() - t0 > limit) { __hip_atomic_store(timeout_flag, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM); break; }
+        __builtin_amdgcn_s_sleep(64);
+        if ((++it & 15u) == 0) {
+            const long long t = wall_clock64();
+            if (t0 == 0) t0 = t;
+            else if (t - t0 > limit) { __hip_atomic_store(timeout_flag, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM); break; }
+        }
     }
     if (delay > 0) {
         const long long t1 = wall_clock64();
-        while (wall_clock64() - t1 < delay) __builtin_amdgcn_s_sleep(4);
+        while (wall_clock64() - t1 < delay) __builtin_amdgcn_s_sleep(8);
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-}
-// (tuner: a kernel on the handle's stream that holds everything behind it until the host has finished issuing - the tuner's builds then
-// start the way a speculative build inside an SCF pass starts: every launch already in its queue when the fork word is released)
-__global__ void qc_hold_kernel(const unsigned *h_word, unsigned target, long long limit) {
-    if (threadIdx.x != 0) return;
-    const long long t0 = wall_clock64();
-    while ((int)(__hip_atomic_load(h_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) - target) < 0) {
-        __builtin_amdgcn_s_sleep(16);
-        if (wall_clock64() - t0 > limit) break;
-    }
 }
 // The word that ends an SCF pass on the device, for the launch sequences that have no kernel of their own to do it in (the one-workgroup
 // Roothaan kernel of small closed-shell runs does the same at its end, qc_scf_small.hip): decide whether the host - which has promised to
@@ -833,6 +832,11 @@ int qc_launch_fock_classes(qc_system *S, const QcFockArgs &fa, float *class_ms, 
         // (with the dispatch lanes known, slot 0 is the slot on the pipe of the handle's own stream: its chain is the one that runs there -
         // any other choice would put two chains on one pipe; the longest-first rule gives slot 0 the heaviest launch anyway)
         const int kmain = devfork ? -1 : (S->lane0_is_main ? (q[0].empty() ? -1 : 0) : ks[0]);
+        // (a speculative build keeps the pipe of the handle's own stream free of its waiting kernels: a queue whose head packet waits
+        // behind a running kernel slows the other queue of its pipe - the Roothaan step on the handle's stream ran 1.2-1.7x longer with
+        // a waiter next door - so the chain of slot 0 goes to the second stream of lane 1's pipe)
+        static const bool spec_keep_lane0 = getenv("QC_SPEC_LANE0") != nullptr;      // (A/B switch)
+        auto side_slot = [&](int k) { return (devfork && S->lane0_is_main && !spec_keep_lane0 && k == 0 && S->nlanes + 0 < QC_NSTREAMS) ? S->nlanes : k; };
         const bool event_join = S->join_by_events;                   // (QC_EVENT_JOIN, or dispatches are serialised here: qc_device_init)
         if (devfork && event_join) return QC_ERR_INVALID;            // (the caller asks qc_fock_can_speculate first)
         // an earlier ASYNCHRONOUS build's wait gave up (qc_fock_*_device return before their build has run; every call that waits on the
@@ -848,7 +852,7 @@ int qc_launch_fock_classes(qc_system *S, const QcFockArgs &fa, float *class_ms, 
                     const int k = set[i];
                     if (pos >= q[k].size()) continue;
                     const int u = q[k][pos];
-                    hipStream_t st = k == kmain ? S->stream : S->side[S->slot_side[k]];
+                    hipStream_t st = k == kmain ? S->stream : S->side[S->slot_side[side_slot(k)]];
                     if (pos == 0 && k != kmain && fork) QC_HIP_CHECK(hipStreamWaitEvent(st, S->ev_fork, 0));
                     if (pos == 0 && k != kmain && devfork) {
                         // (side chains in the order of their load, QC_FORK_STAGGER_US apart - default 6 us, the host's own issue rate)
@@ -863,7 +867,7 @@ int qc_launch_fock_classes(qc_system *S, const QcFockArgs &fa, float *class_ms, 
                 }
             if (!event_join) {
                 for (int i = 0; i < nset; ++i)
-                    if (set[i] != kmain && !q[set[i]].empty()) hipLaunchKernelGGL(qc_join_mark_kernel, dim3(1), dim3(64), 0, S->side[S->slot_side[set[i]]], S->d_join);
+                    if (set[i] != kmain && !q[set[i]].empty()) hipLaunchKernelGGL(qc_join_mark_kernel, dim3(1), dim3(64), 0, S->side[S->slot_side[side_slot(set[i])]], S->d_join);
                 if (hipGetLastError() != hipSuccess) return QC_ERR_HIP;
             }
             return QC_OK;
@@ -910,7 +914,7 @@ int qc_launch_fock_classes(qc_system *S, const QcFockArgs &fa, float *class_ms, 
         if (event_join) {
             for (int k = 0; k < QC_NSTREAMS; ++k) {
                 if (q[k].empty() || k == kmain) continue;
-                QC_HIP_CHECK(hipEventRecord(S->ev_join[k], S->side[S->slot_side[k]]));
+                QC_HIP_CHECK(hipEventRecord(S->ev_join[k], S->side[S->slot_side[side_slot(k)]]));
                 QC_HIP_CHECK(hipStreamWaitEvent(S->stream, S->ev_join[k], 0));
             }
         } else if (nside) {
@@ -930,259 +934,168 @@ int qc_launch_fock_classes(qc_system *S, const QcFockArgs &fa, float *class_ms, 
         return QC_OK;
     };
     if (S->unit_ms.size() != units.size()) {
-        // First build of a shard: tune the stream assignment (all of this is density-independent and its results are
-        // discarded).  Kernels that overlap slow each other down by class-dependent factors, so after an initial guess
-        // from the launches timed alone, QC_TUNE_ROUNDS concurrent builds are measured with events around every launch;
-        // each proposes the next assignment (longest-first on the durations seen *inside* the build, over 4 to 7 streams - fewer
-        // concurrent kernels disturb each other less), the fastest is kept.
+        // First build of a shard.  No tuner run (round 4): the launches are timed alone once (two serial passes: the first pays the code
+        // upload), placed longest-first on the dispatch lanes, and the assignment is refined ONLINE from the build times the SCF passes
+        // report anyway (qc_fock_feedback) - a neighbouring assignment is tried for a few passes and kept when it is faster.  The offline
+        // tuner of rounds 1-3 (25 + up to 256 extra builds and a local search, 55 ms for H2O/cc-pVTZ) cost ten times the 15-pass SCF it
+        // served and won 6 % of its builds; a process that has seen the same work lists before starts from what it learned (qc_assign_cache).
         S->unit_ms.assign(units.size(), 0.f);
-        // (a tuner run that fails half-way leaves nothing behind: the next build tunes again)
         struct Untuned { qc_system *S; bool keep = false; ~Untuned() { if (!keep) { S->unit_ms.clear(); S->unit_stream.clear(); } } } untuned{S};
         const size_t gbytes = (fa.fxs ? 2 : 1) * (size_t)a.nrep * a.rep_stride * sizeof(double);   // (hi and lo planes are contiguous)
         int rc = qc_launch_fock_classes(S, fa, nullptr, S->unit_ms.data());     // warm-up: first launches pay code upload
         if (rc == QC_OK) rc = qc_launch_fock_classes(S, fa, nullptr, S->unit_ms.data());   // serial, timed
         if (rc != QC_OK) return rc;
-        // (experiment switch: no tuning - longest-first on the durations alone over QC_TUNE_FIXED streams, the handle's stream 15 us ahead)
-        static const int fixed_w = getenv("QC_TUNE_FIXED") ? atoi(getenv("QC_TUNE_FIXED")) : 0;
-        if (fixed_w >= 1 && fixed_w <= QC_NSTREAMS) {
-            lpt(S->unit_ms, fixed_w, 0.015f);
-            S->cand_stream.clear(); S->cand_weight.clear(); S->cand_ms.clear(); S->cand_n.clear(); S->cand_frozen = true;
-            S->tuned_best_ms = 0.f; S->tune_count += 1; S->second_stage = 2; S->assign_gen += 1;
-            if (fa.G0) QC_HIP_CHECK(hipMemsetAsync(fa.G0, 0, gbytes, S->stream));
-            nofork = false;
-            untuned.keep = true;
-            return launch_concurrent(nullptr, false, 0);
-        }
-        lpt(S->unit_ms, QC_NSTREAMS);
-        EventList evl;
-        if (evl.create(2 + 2 * units.size()) != QC_OK) return QC_ERR_HIP;
-        std::vector<hipEvent_t> &ev = evl.ev;
-        std::vector<std::vector<int>> cand;
-        std::vector<std::vector<float>> weight;
-        std::vector<float> total;
-        static const bool dbg = getenv("QC_TUNE_DEBUG") != nullptr;
-        // One build as the steady state runs it, timed.  Inside SCF passes that is the speculative form (scf_iterate): every launch of the
-        // build is in its queue when the fork word is released, the side chains start a few microseconds apart on the device.  The tuner's
-        // builds take the same form - a holding kernel on the handle's stream keeps the release back until the host has issued everything -
-        // because which assignment wins depends on how the launches start (measured: assignments tuned with host-issued, event-forked
-        // builds ran 15 % slower in the speculative form than in their own).  QC_NO_SPEC / event joins / f64 atomics: the host-issued form.
-        const bool spec_form = !S->join_by_events && fa.fxs != nullptr && getenv("QC_SPEC") != nullptr && getenv("QC_NO_SPEC") == nullptr && getenv("QC_TUNE_EVENT_FORM") == nullptr;
-        auto steady_build = [&](float &t) -> int {
-            if (fa.G0) QC_HIP_CHECK(hipMemsetAsync(fa.G0, 0, gbytes, S->stream));
-            unsigned q = 0;
-            if (spec_form) {
-                S->hold_seq += 1;
-                hipLaunchKernelGGL(qc_hold_kernel, dim3(1), dim3(64), 0, S->stream, S->h_hold, S->hold_seq, 5000000LL);     // (gives up after 50 ms)
-                q = ++S->fork_seq;
-                qc_spec_release(S->stream, S->d_join, q, nullptr, S->nbasis, 0, 0.0, nullptr, nullptr, 0);
-            }
-            int r = launch_concurrent(ev.data(), false, q);
-            if (spec_form) __atomic_store_n(S->h_hold, S->hold_seq, __ATOMIC_RELEASE);
-            if (r != QC_OK) return r;
-            QC_HIP_CHECK(hipEventSynchronize(ev[1]));
-            if ((r = qc_join_check(S)) != QC_OK) return r;
-            QC_HIP_CHECK(hipEventElapsedTime(&t, ev[0], ev[1]));
-            return QC_OK;
-        };
-        for (int round = 0; round < QC_TUNE_ROUNDS; ++round) {
-            for (int rep = 0; rep < 2; ++rep) {             // the second run of a candidate is the one that counts
+        static const int fixed_w = getenv("QC_TUNE_FIXED") ? atoi(getenv("QC_TUNE_FIXED")) : 0;      // (experiment switch: lanes used, no online search)
+        lpt(S->unit_ms, fixed_w >= 1 && fixed_w <= QC_NSTREAMS ? fixed_w : QC_NSTREAMS, 0.015f);
+        S->tune_count += 1; S->assign_gen += 1;
+        const bool no_search = fixed_w >= 1 || getenv("QC_TUNE_OFF") != nullptr;
+        qc_online_reset(S, no_search);
+        // Kernels that overlap stretch each other by class-dependent factors (the bra-major launches 1.8x next to the one-wave-per-SIMD
+        // launches, those hardly at all), which the durations alone do not show: three concurrent builds with events around every
+        // launch, each proposing the longest-first assignment of the durations seen INSIDE it.  These proposals are the first trials of
+        // the online search; they cost three builds here and nothing later.
+        if (!no_search) {
+            const std::vector<int> first = S->unit_stream;
+            EventList evl;
+            if (evl.create(2 + 2 * units.size()) != QC_OK) return QC_ERR_HIP;
+            std::vector<hipEvent_t> &ev = evl.ev;
+            for (int round = 0; round < 3; ++round) {
                 if (fa.G0) QC_HIP_CHECK(hipMemsetAsync(fa.G0, 0, gbytes, S->stream));
                 if ((rc = launch_concurrent(ev.data(), true, 0)) != QC_OK) return rc;
-                QC_HIP_CHECK(hipEventSynchronize(ev[1])); if ((rc = qc_join_check(S)) != QC_OK) return rc;
+                QC_HIP_CHECK(hipEventSynchronize(ev[1]));
+                if ((rc = qc_join_check(S)) != QC_OK) return rc;
+                std::vector<float> dur(units.size(), 0.f);
+                for (size_t u = 0; u < units.size(); ++u)
+                    if (!units[u].empty()) { QC_HIP_CHECK(hipEventSynchronize(ev[3 + 2 * u])); QC_HIP_CHECK(hipEventElapsedTime(&dur[u], ev[2 + 2 * u], ev[3 + 2 * u])); }
+                lpt(dur, QC_NSTREAMS, round == 1 ? 0.015f : 0.f);
+                if (std::find(S->on.cands.begin(), S->on.cands.end(), S->unit_stream) == S->on.cands.end() && S->unit_stream != first) S->on.cands.push_back(S->unit_stream);
             }
-            float tot = 0.f;
-            QC_HIP_CHECK(hipEventElapsedTime(&tot, ev[0], ev[1]));
-            std::vector<float> dur(units.size(), 0.f);
-            // (the device-side join tells the handle's stream, not the runtime, that the side streams are through: their events are
-            // waited for by name before they are read)
-            for (size_t u = 0; u < units.size(); ++u)
-                if (!units[u].empty()) { QC_HIP_CHECK(hipEventSynchronize(ev[3 + 2 * u])); QC_HIP_CHECK(hipEventElapsedTime(&dur[u], ev[2 + 2 * u], ev[3 + 2 * u])); }
-            // (a candidate keeps the durations measured in ITS build: they order the launches - longest chain first - when it is replayed)
-            cand.push_back(S->unit_stream); weight.push_back(dur); total.push_back(tot);
-            if (dbg) {
-                fprintf(stderr, "[tune] cand %d total %.3f ms:", round, tot);
-                for (size_t u = 0; u < units.size(); ++u) if (!units[u].empty()) fprintf(stderr, " u%zu@s%d %.0f/%.0f", u, S->unit_stream[u], dur[u] * 1e3, S->unit_ms[u] * 1e3);
-                fprintf(stderr, "\n");
-            }
-            static const int widths[QC_TUNE_ROUNDS] = {QC_NSTREAMS, QC_NSTREAMS, 5, 4, 6, QC_NSTREAMS};   // of the *next* candidate
-            lpt(dur, widths[round]);
+            S->unit_stream = first; S->unit_weight = S->unit_ms; S->on.best = first;
         }
-        // (round 3) The totals above were measured with two events around every launch, and those change the picture (a build of 13 launches
-        // gains 26 event packets): the ranking that the local search and the finals start from is taken again from builds as the steady state
-        // runs them - together with three more candidates, longest-first on the durations ALONE over 4, 5 and 6 streams: a kernel trace of
-        // H2O/cc-pVTZ passes showed in-build durations equal to the durations alone at five concurrent launches (the chip's wave slots
-        // are full at that point; a sixth or seventh launch only stretches the others), and the chosen assignment ending 187 us after its
-        // start on a four-launch chain where longest-first over five streams packs the same durations into 156.
-        static const bool tune_v1 = getenv("QC_TUNE_V1") != nullptr;            // (A/B switch: the ranking of round 2)
-        if (!tune_v1) {
-            for (int wdt : {4, 5, 6}) {
-                if (wdt > QC_NSTREAMS) continue;
-                for (float hs : {0.f, 0.015f}) {
-                    lpt(S->unit_ms, wdt, hs);
-                    cand.push_back(S->unit_stream); weight.push_back(S->unit_ms); total.push_back(0.f);
-                }
+        qc_assign_cache_lookup(S);
+        if (fa.G0) QC_HIP_CHECK(hipMemsetAsync(fa.G0, 0, gbytes, S->stream));
+        nofork = false;                                  // the side streams must see that memset (and the timing passes) finished
+        untuned.keep = true;
+    }
+    // an instalment of the assignment search (see above): not in a speculative build, not in the builds of a profiling call
+    S->on.builds += 1;
+    if (!S->on.frozen && fa.fork_seq == 0 && fa.G0 && S->on.builds >= QC_SEARCH_FIRST_BUILD && S->on.spent + 2 * QC_SEARCH_CHUNK <= S->on.builds) {
+        const size_t gbytes = (fa.fxs ? 2 : 1) * (size_t)a.nrep * a.rep_stride * sizeof(double);
+        EventList evl;
+        if (evl.create(2) != QC_OK) return QC_ERR_HIP;
+        qc_system::QcOnline &o = S->on;
+        static const bool dbg = getenv("QC_TUNE_DEBUG") != nullptr;
+        int rc = QC_OK;
+        auto measure = [&](const std::vector<int> &assign, float &t) -> int {
+            S->unit_stream = assign;
+            t = 1e30f;
+            for (int rep = 0; rep < 2; ++rep) {
+                QC_HIP_CHECK(hipMemsetAsync(fa.G0, 0, gbytes, S->stream));
+                int r = launch_concurrent(evl.ev.data(), false, 0);
+                if (r != QC_OK) return r;
+                QC_HIP_CHECK(hipEventSynchronize(evl.ev[1]));
+                if ((r = qc_join_check(S)) != QC_OK) return r;
+                float x = 0.f;
+                QC_HIP_CHECK(hipEventElapsedTime(&x, evl.ev[0], evl.ev[1]));
+                t = std::min(t, x);
+                o.spent += 1;
             }
-            for (size_t i = 0; i < cand.size(); ++i) {
-                S->unit_stream = cand[i]; S->unit_weight = weight[i];
-                float tmin = 1e30f;
-                for (int rep = 0; rep < 3; ++rep) {
-                    float t = 0.f;
-                    if ((rc = steady_build(t)) != QC_OK) return rc;
-                    if (rep > 0) tmin = std::min(tmin, t);
-                }
-                total[i] = tmin;
-                if (dbg) fprintf(stderr, "[tune] cand %zu as the steady state runs it: %.3f ms\n", i, tmin);
-            }
-        }
-        // local search around the fastest candidate: move one launch to another stream or swap two launches, keep what makes the build
-        // faster (steady-state form of the build, best of two; which kernels disturb each other is not something the longest-first rule
-        // sees).  A fixed pseudo-random sequence; at most QC_TUNE_LOCAL steps of two builds each, and no more than ~0.1 s of them, once
-        // per geometry.
-        {
-            size_t b = 0;
-            for (size_t i = 1; i < total.size(); ++i) if (total[i] < total[b]) b = i;
-            std::vector<int> cur = cand[b];
-            const std::vector<float> w = weight[b];
-            auto measure = [&](const std::vector<int> &assign, float &t) -> int {
-                S->unit_stream = assign; S->unit_weight = w;
-                t = 1e30f;
-                for (int rep = 0; rep < 2; ++rep) {
-                    float x = 0.f;
-                    int r = steady_build(x);
-                    if (r != QC_OK) return r;
-                    t = std::min(t, x);
-                }
-                return QC_OK;
-            };
+            return QC_OK;
+        };
+        auto propose = [&]() -> bool {
+            if (!o.cands.empty()) { o.trial = o.cands.back(); o.cands.pop_back(); return true; }      // (the proposals of the first build)
             std::vector<int> act;
             for (size_t u = 0; u < units.size(); ++u) if (!units[u].empty()) act.push_back((int)u);
-            float tcur = 0.f;
-            if ((rc = measure(cur, tcur)) != QC_OK) return rc;
-            unsigned rng = 2463534242u + 40503u * (unsigned)S->tune_count;      // (a second tuner run takes another path)
-            auto next = [&]() { rng ^= rng << 13; rng ^= rng >> 17; rng ^= rng << 5; return rng >> 4; };
-            float spent = 0.f;
-            for (int step = 0; step < QC_TUNE_LOCAL && act.size() > 1 && (step < 8 || spent < 100.f); ++step) {
-                std::vector<int> trial = cur;
+            const int nl = std::min(QC_NSTREAMS, S->nlanes);
+            if (act.size() < 2 || nl < 2) return false;
+            auto next = [&]() { o.rng ^= o.rng << 13; o.rng ^= o.rng >> 17; o.rng ^= o.rng << 5; return o.rng >> 4; };
+            for (int tries = 0; tries < 32; ++tries) {
+                std::vector<int> t = o.best;
                 const int u = act[next() % act.size()];
-                if (next() & 1) {
-                    const int k = (int)(next() % std::min(QC_NSTREAMS, S->nlanes));
-                    if (k == trial[u]) continue;
-                    trial[u] = k;
-                } else {
-                    const int v = act[next() % act.size()];
-                    if (trial[v] == trial[u]) continue;
-                    std::swap(trial[u], trial[v]);
-                }
-                float t = 0.f;
-                if ((rc = measure(trial, t)) != QC_OK) return rc;
-                spent += 2.f * t;
-                if (dbg) fprintf(stderr, "[tune] local step %d: %.3f ms (current %.3f)\n", step, t, tcur);
-                if (t < 0.985f * tcur) { cur = trial; tcur = t; }
+                if (next() & 1) { const int k = (int)(next() % nl); if (k == t[u]) continue; t[u] = k; }
+                else { const int v = act[next() % act.size()]; if (t[v] == t[u]) continue; std::swap(t[u], t[v]); }
+                o.trial = t;
+                return true;
             }
-            cand.push_back(cur); weight.push_back(w); total.push_back(tcur);
+            return false;
+        };
+        if (o.best.empty()) o.best = S->unit_stream;
+        float tb = 0.f;
+        if (o.base_ms <= 0.0) { if ((rc = measure(o.best, tb)) != QC_OK) return rc; o.base_ms = tb; }
+        for (int k = 0; k < QC_SEARCH_CHUNK && !o.frozen; ++k) {
+            if (!propose()) { o.frozen = true; break; }
+            const bool seeded = !o.cands.empty();
+            float t = 0.f;
+            if ((rc = measure(o.trial, t)) != QC_OK) return rc;
+            o.trials += 1;
+            if (dbg) fprintf(stderr, "[tune] trial %d (build %ld of the handle): %.4f ms against %.4f ms - %s\n", o.trials, (long)o.builds, t, o.base_ms, t < 0.985 * o.base_ms ? "kept" : "dropped");
+            if (t < 0.985 * o.base_ms) { o.best = o.trial; o.base_ms = t; o.rejects = 0; }
+            else if (!seeded) o.rejects += 1;
+            if (o.rejects >= QC_SEARCH_REJECTS || o.trials >= QC_SEARCH_TRIALS) o.frozen = true;
         }
-        // final: the three fastest candidates again, now as the steady state runs them (no events around the launches),
-        // three builds each, best of the three
-        std::vector<size_t> rank(total.size());
-        for (size_t i = 0; i < rank.size(); ++i) rank[i] = i;
-        std::sort(rank.begin(), rank.end(), [&](size_t x, size_t y) { return total[x] < total[y]; });
-        size_t best = rank[0];
-        float best_t = 1e30f;
-        S->cand_stream.clear(); S->cand_weight.clear(); S->cand_ms.clear(); S->cand_n.clear();
-        std::vector<float> fin_t;
-        std::vector<size_t> fin_c;
-        for (size_t r = 0; r < std::min<size_t>(3, rank.size()); ++r) {
-            S->unit_stream = cand[rank[r]]; S->unit_weight = weight[rank[r]];
-            float tmin = 1e30f;
-            for (int rep = 0; rep < 3; ++rep) {
-                float t = 0.f;
-                if ((rc = steady_build(t)) != QC_OK) return rc;
-                tmin = std::min(tmin, t);
-            }
-            if (dbg) fprintf(stderr, "[tune] final cand %zu: %.3f ms\n", rank[r], tmin);
-            if (tmin < best_t) { best_t = tmin; best = rank[r]; }
-            fin_t.push_back(tmin); fin_c.push_back(rank[r]);
-        }
-        // the finalists stay available: inside SCF runs the passes themselves decide between them (qc_fock_feedback) - those within
-        // 10 % of the best, that is: sampling a clearly slower one costs more passes than it can win
-        for (size_t r = 0; r < fin_c.size(); ++r) {
-            if (fin_t[r] > 1.10f * best_t) continue;
-            S->cand_stream.push_back(cand[fin_c[r]]); S->cand_weight.push_back(weight[fin_c[r]]); S->cand_ms.push_back(0.0); S->cand_n.push_back(0);
-            if (fin_c[r] == best) S->cand_cur = (int)S->cand_stream.size() - 1;
-        }
-        S->unit_stream = cand[best]; S->unit_weight = weight[best];
-        S->tuned_best_ms = best_t; S->tune_count += 1; S->inpass_sum = 0.0; S->inpass_n = 0;
-        S->assign_gen += 1;
-        S->cand_skip = true;                             // (the first build under the new assignment is not a sample)
-        if (fa.G0) QC_HIP_CHECK(hipMemsetAsync(fa.G0, 0, gbytes, S->stream));
-        nofork = false;                                  // the side streams must see that memset (and the tuner's builds) finished
-        untuned.keep = true;
+        S->unit_stream = o.best;
+        S->assign_gen += 1; S->tune_count += 1;             // (this build carries extra builds: not a timing sample)
+        if (o.frozen) { qc_assign_cache_store(S); if (dbg) fprintf(stderr, "[tune] search ends after %d trials (%ld extra builds): %.4f ms\n", o.trials, (long)o.spent, o.base_ms); }
+        QC_HIP_CHECK(hipMemsetAsync(fa.G0, 0, gbytes, S->stream));
+        nofork = false;
     }
     return launch_concurrent(nullptr, false, fa.fork_seq);
 }
 
-// Online choice between the tuner's finalists.  The tuning builds run back to back; inside an SCF pass a build follows ~20 small
-// linear-algebra kernels and a host turn-around, and which finalist is fastest THERE differed from run to run by up to 20 % of the
-// build (0.31-0.38 ms on H2O/cc-pVTZ).  The SCF pass reports the hipEvent time of each of its builds: every finalist gets
-// QC_ONLINE_SAMPLES of them in turn (the first after a switch is not counted), then the best mean stays.  Stream assignment does not
-// change results (integer accumulation), only time.
-constexpr int QC_ONLINE_SAMPLES = 3;
-constexpr int QC_INPASS_SAMPLES = 4;
-// A build may be issued speculatively (device-side fork, scf_iterate) when nothing of it needs the host: the stream assignment is tuned
-// (a tuner run waits for its builds), the side streams are joined on the device, and the accumulation is the fixed-point one whose
-// closing fold leaves the planes clean (the f64 mode starts with a memset the side streams would have to wait for).
+// ---- Refinement of the stream assignment, paid for by use.  A neighbouring assignment (one launch moved to another lane, two launches
+// of different lanes swapped; first of all the proposals of the first build) is measured by two extra builds, back to back, and kept when
+// the better of them beats the current best by 1.5 % - the local search of rounds 2-3.  What changed in round 4 is WHEN it runs: never in
+// a handle's first builds (the offline tuner of rounds 1-3 spent 55 ms - ten times the 15-pass SCF of H2O/cc-pVTZ it served - to win 6 %
+// of its builds), but in small instalments once the handle has shown that it lives long: from its 24th build on, a build may spend on
+// trials as many extra builds as the handle has done useful ones so far, minus what was spent already.  A handle that does one SCF pays
+// nothing; one that runs hundreds of builds (geometry loops, benchmarks) converges to the searched assignment at a bounded overhead
+// and then stops (QC_SEARCH_REJECTS rejections in a row, or QC_SEARCH_TRIALS trials); the result goes to a process-wide cache keyed by
+// the shape of the work lists.  The stream assignment does not change results (integer accumulation), only time.
+void qc_online_reset(qc_system *S, bool frozen) {
+    S->on = qc_system::QcOnline{};
+    S->on.frozen = frozen;
+    S->on.best = S->unit_stream;
+    S->on.rng = 2463534242u;
+}
+static uint64_t qc_assign_key(const qc_system *S) {
+    uint64_t h = 1469598103934665603ull;
+    auto mix = [&](uint64_t v) { h ^= v; h *= 1099511628211ull; };
+    mix((uint64_t)S->nlanes); mix((uint64_t)S->nbasis); mix((uint64_t)S->nranks); mix((uint64_t)S->rank); mix((uint64_t)S->accum_fx);
+    for (const auto &c : S->classes) { mix(((uint64_t)c.LAB << 40) | ((uint64_t)c.LCD << 32) | (uint64_t)(c.bm ? 1 : 0)); mix((uint64_t)c.slots.size()); mix((uint64_t)c.bundles.size()); mix((uint64_t)c.prim_quartets); }
+    return h;
+}
+struct QcAssignCache { std::mutex mu; std::vector<std::pair<uint64_t, std::pair<std::vector<int>, bool>>> e; };
+static QcAssignCache &qc_assign_cache() { static QcAssignCache c; return c; }
+void qc_assign_cache_lookup(qc_system *S) {
+    if (getenv("QC_NO_ASSIGN_CACHE")) return;
+    const uint64_t key = qc_assign_key(S);
+    QcAssignCache &C = qc_assign_cache();
+    std::lock_guard<std::mutex> lk(C.mu);
+    for (const auto &kv : C.e)
+        if (kv.first == key && kv.second.first.size() == S->unit_stream.size()) {
+            S->unit_stream = kv.second.first; S->on.best = S->unit_stream; S->on.frozen = S->on.frozen || kv.second.second; S->assign_gen += 1;
+            return;
+        }
+}
+static void qc_assign_cache_store(const qc_system *S) {
+    if (getenv("QC_NO_ASSIGN_CACHE")) return;
+    const uint64_t key = qc_assign_key(S);
+    QcAssignCache &C = qc_assign_cache();
+    std::lock_guard<std::mutex> lk(C.mu);
+    for (auto &kv : C.e) if (kv.first == key) { kv.second = {S->on.best, S->on.frozen}; return; }
+    if (C.e.size() < 64) C.e.push_back({key, {S->on.best, S->on.frozen}});
+}
+// A build may be issued speculatively (device-side fork, scf_iterate) when nothing of it needs the host: the launches have been timed
+// (that first build waits for its serial passes), the side streams are joined on the device, and the accumulation is the fixed-point one
+// whose closing fold leaves the planes clean (the f64 mode starts with a memset the side streams would have to wait for).
 bool qc_fock_can_speculate(const qc_system *S) {
     return S->device_ready && !S->join_by_events && S->accum_fx && S->launch_plan && !S->unit_ms.empty() &&
            S->unit_ms.size() == S->launch_plan->units.size();
 }
-// (`gen`: the stream assignment the build ran under.  With the pass end seen through the sequence word - and with speculative builds -
-// a build's time arrives one or two builds after it was issued; a sample of an assignment that has been replaced since is dropped,
-// and so is the first one of a new assignment.)
+// (the SCF passes report their build times: kept as the handle's running mean - the search itself measures its own builds)
 void qc_fock_feedback(qc_system *S, float build_ms, unsigned gen) {
-    int nc = (int)S->cand_stream.size();
-    if (S->unit_stream.empty()) return;
     if (gen != S->assign_gen) return;
-    S->builds_seen += 1;
-    // (the second tuner run keeps its own best: no sampling of finalists, the whole procedure ends within a dozen builds)
-    if (S->second_stage == 1 && nc >= 2 && !S->cand_frozen) { S->cand_frozen = true; nc = 0; }
-    static const bool no_second = getenv("QC_TUNE_ONCE") != nullptr;           // (A/B switch)
-    if ((nc < 2 || S->cand_frozen) && S->second_stage < 2 && !no_second) {
-        // second opinion: in-pass mean of the current assignment against the tuner's figure
-        if (S->cand_skip) { S->cand_skip = false; return; }      // (first build under this assignment)
-        S->inpass_sum += build_ms; S->inpass_n += 1;
-        if (S->inpass_n < QC_INPASS_SAMPLES) return;
-        const double mean = S->inpass_sum / S->inpass_n;
-        static const bool dbg = getenv("QC_TUNE_DEBUG") != nullptr;
-        if (S->second_stage == 0) {
-            if (mean <= 1.10 * S->tuned_best_ms || S->builds_seen > 8) { S->second_stage = 2; return; }       // (good enough, or too late in the run)
-            if (dbg) fprintf(stderr, "[tune] in-pass builds %.3f ms vs %.3f ms tuned: one more tuner run\n", mean, S->tuned_best_ms);
-            S->first_mean = mean; S->first_stream = S->unit_stream; S->first_weight = S->unit_weight;
-            S->second_stage = 1;
-            S->assign_gen += 1;                            // (builds already issued under the first choice are no samples of the second)
-            S->unit_ms.clear();                            // the next build tunes again (its time is not a sample: the caller leaves builds with a tuner run out)
-            S->cand_stream.clear(); S->cand_weight.clear(); S->cand_ms.clear(); S->cand_n.clear(); S->cand_frozen = false; S->cand_cur = 0;
-        } else {
-            if (dbg) fprintf(stderr, "[tune] in-pass builds: first choice %.3f ms, second %.3f ms\n", S->first_mean, mean);
-            if (S->first_mean < mean) { S->unit_stream = S->first_stream; S->unit_weight = S->first_weight; S->cand_stream.clear(); S->cand_frozen = true; S->assign_gen += 1; }
-            S->second_stage = 2;
-        }
-        return;
-    }
-    if (nc < 2 || S->cand_frozen) return;
-    const int c = S->cand_cur;
-    if (S->cand_skip) S->cand_skip = false;            // first build after a switch: not counted
-    else { S->cand_ms[c] += build_ms; S->cand_n[c] += 1; }
-    if (S->cand_n[c] < QC_ONLINE_SAMPLES) return;
-    int next = -1;
-    for (int k = 0; k < nc; ++k) if (S->cand_n[k] < QC_ONLINE_SAMPLES) { next = k; break; }
-    if (next < 0) {                                     // every finalist sampled: keep the best
-        next = 0;
-        for (int k = 1; k < nc; ++k) if (S->cand_ms[k] / S->cand_n[k] < S->cand_ms[next] / S->cand_n[next]) next = k;
-        S->cand_frozen = true;
-        static const bool dbg = getenv("QC_TUNE_DEBUG") != nullptr;
-        if (dbg) { fprintf(stderr, "[tune] online:"); for (int k = 0; k < nc; ++k) fprintf(stderr, " cand %d %.3f ms", k, S->cand_ms[k] / S->cand_n[k]); fprintf(stderr, " -> %d\n", next); }
-    }
-    if (next != c) { S->cand_cur = next; S->unit_stream = S->cand_stream[next]; S->unit_weight = S->cand_weight[next]; S->cand_skip = true; S->assign_gen += 1; }
+    S->on.seen_sum += build_ms; S->on.seen_n += 1;
 }
 
 // temporary device buffer of the two set-up passes below: released on every return path
@@ -1223,10 +1136,10 @@ int qc_schwarz_device(qc_system *S) {
             continue;
         }
         if (c.bm) {
-            qc_make_bundles(S, diag, 0, bundles, ketlist);
+            const bool packed = qc_make_bundles(S, diag, 0, bundles, ketlist);
             QcTmpDev<QcBundleDev> db; QcTmpDev<QcKetUnit> dk;
             std::vector<QcBundleDev> hb; std::vector<QcKetUnit> hu;
-            qc_bm_device_lists(S, c.LCD, bundles, ketlist, hb, hu);
+            qc_bm_device_lists(S, c.LCD, bundles, ketlist, packed, hb, hu);
             QC_HIP_CHECK(db.alloc(hb.size()));
             QC_HIP_CHECK(dk.alloc(hu.size()));
             QC_HIP_CHECK(hipMemcpyAsync(db.p, hb.data(), hb.size() * sizeof(QcBundleDev), hipMemcpyHostToDevice, S->stream));
@@ -1275,11 +1188,11 @@ int qc_launch_eri_full(qc_system *S, double *d_out) {
             continue;
         }
         if (c.bm) {
-            qc_make_bundles(S, c.tasks, 0, bundles, ketlist);
+            const bool packed = qc_make_bundles(S, c.tasks, 0, bundles, ketlist);
             if (bundles.empty()) continue;
             QcTmpDev<QcBundleDev> db; QcTmpDev<QcKetUnit> dk;
             std::vector<QcBundleDev> hb; std::vector<QcKetUnit> hu;
-            qc_bm_device_lists(S, c.LCD, bundles, ketlist, hb, hu);
+            qc_bm_device_lists(S, c.LCD, bundles, ketlist, packed, hb, hu);
             QC_HIP_CHECK(db.alloc(hb.size()));
             QC_HIP_CHECK(dk.alloc(hu.size()));
             QC_HIP_CHECK(hipMemcpyAsync(db.p, hb.data(), hb.size() * sizeof(QcBundleDev), hipMemcpyHostToDevice, S->stream));

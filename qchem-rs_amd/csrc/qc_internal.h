@@ -31,8 +31,6 @@ constexpr int QC_NREP = 32;             // replicas of the Fock accumulation buf
 constexpr int QC_FX_MAXBITS = 52;       // fixed-point accumulation: finest unit 2^-52 Eh; the scale of a build follows its density (qc_fx_scale)
 constexpr double QC_SCHWARZ_TAU = 1e-12; // quartets with sqrt((ab|ab) (cd|cd)) below this are not evaluated (default)
 constexpr int QC_LDS_MAX = 160 * 1024;  // LDS of a gfx950 CU, the cap the kernels with dynamic LDS are allowed
-constexpr int QC_TUNE_ROUNDS = 6;        // concurrent builds measured before the stream assignment is frozen
-constexpr int QC_TUNE_LOCAL = 128;        // local-search steps (move / swap of launches between streams) around the best of them
 #ifndef QC_NSTREAMS_N
 #define QC_NSTREAMS_N 7
 #endif
@@ -119,6 +117,7 @@ struct QcClass {
     int bm_rows = 0;              // most bra functions (na + nb) of a bundle: rows of the kernels' exchange buffer
     std::vector<QcBundle> bundles;
     std::vector<int> ketlist;
+    bool ket_packed = false;      // ketlist entries are packed (pair, first primitive, length) chunks, not plain pair indices (qc_make_bundles)
     QcBundleDev *d_bundles = nullptr;
     QcKetUnit *d_ketlist = nullptr;
     // work model of `shard`
@@ -175,7 +174,6 @@ struct qc_system {
                                              // [2] number of the speculative build that was cancelled on the device (its class kernels return at once)
     int *h_join_timeout = nullptr;           // pinned: set by a device-side wait that gave up (the launches it waited for never finished)
     unsigned join_target = 0;
-    unsigned *h_hold = nullptr; unsigned hold_seq = 0;   // pinned: the tuner's holding kernel waits for hold_seq (qc_hold_kernel)
     unsigned fork_seq = 0;                   // last value promised to the fork word: the speculative build of pass k + 1 waits for fork_seq = k's number
     long long wait_limit = 0;                // device-side waits give up after this many ticks of the 100 MHz clock (qc_wait_limit)
     std::atomic<bool> waits_in_flight{false}; // device-side waits were issued and the host has not seen the handle's stream drained since (qc_gate)
@@ -197,23 +195,20 @@ struct qc_system {
     std::vector<float> unit_ms;              // measured serial time of each launch unit (autotuned once per shard)
     std::vector<int> unit_stream;            // side stream of each launch unit (longest-processing-time assignment)
     std::vector<float> unit_weight;          // durations that order the launches (measured inside concurrent builds)
-    // the tuner's finalists and their build times as seen by SCF passes (qc_fock_feedback)
-    std::vector<std::vector<int>> cand_stream;
-    std::vector<std::vector<float>> cand_weight;
-    std::vector<double> cand_ms;
-    std::vector<int> cand_n;
-    int cand_cur = 0;
-    bool cand_frozen = false, cand_skip = false;
+    // refinement of the stream assignment in instalments paid for by use (qc_fock.hip, "Refinement of the stream assignment")
+    struct QcOnline {
+        bool frozen = false;
+        std::vector<int> best, trial;
+        std::vector<std::vector<int>> cands;   // proposals of the first build (longest-first on in-build durations): tried before random neighbours
+        double base_ms = 0.0;                  // build time of `best` as the search measured it
+        int trials = 0, rejects = 0;
+        long builds = 0, spent = 0;            // builds asked of this handle / extra builds the search has run
+        unsigned rng = 2463534242u;
+        double seen_sum = 0.0; long seen_n = 0;   // build times reported by SCF passes under the current assignment
+    } on;
+    bool cand_skip = false;                  // the next build is the first under a new assignment: not a sample
     unsigned assign_gen = 0;                 // counts the changes of the stream assignment: a build's time is a sample of the assignment it ran under
-    // second opinion (qc_fock_feedback): the tuner measures builds back to back; inside SCF passes the same assignment is 7-22 % slower,
-    // and by how much differs from one tuner run to the next.  When the passes' builds are > 10 % slower than the tuner's figure, the
-    // tuner runs ONCE more and the assignment with the better in-pass mean stays.
-    float tuned_best_ms = 0.f;               // the tuner's own figure for its choice
-    int tune_count = 0;                      // tuner runs on this shard layout
-    int second_stage = 0;                    // 0 sampling the first choice, 1 sampling the second, 2 decided
-    double inpass_sum = 0.0; int inpass_n = 0, builds_seen = 0;
-    double first_mean = 0.0;
-    std::vector<int> first_stream; std::vector<float> first_weight;
+    int tune_count = 0;                      // first builds (launches timed alone) on this shard layout
     // accumulators zeroed, fixed-point scale (and the UHF density sum) already enqueued for a build from exactly these densities, and the host
     // has waited for the handle's stream since (qc_fock_prepare_device): the build then starts its side streams without a fork
     bool prepared = false;
@@ -337,7 +332,17 @@ inline int qc_shard_owner(size_t i, int nranks, size_t ci) {
 void qc_make_slots(const qc_system *S, const std::vector<QcTask> &tasks, int itmax, bool split_cols, std::vector<QcSlot> &out);
 // group tasks by bra into bundles of <= 64 kets (sorted by primitive count); itmax > 0 also cuts the bra primitive range
 // (unit > 0: lanes take chunks of at most `unit` primitives of a ket pair, packed into the ketlist entry; 0: whole pairs)
-void qc_make_bundles(const qc_system *S, const std::vector<QcTask> &tasks, int itmax, std::vector<QcBundle> &bundles, std::vector<int> &ketlist, int unit = 0);
+// Returns whether the ketlist entries are PACKED (pair | first primitive << 18 | length << 25, qc_pack_ket_entry) - only possible with
+// unit > 0, fewer than 2^18 stored pairs and at most 127 primitives per ket pair - or plain pair indices.  Whoever decodes a list
+// (qc_unpack_ket_entry) needs that flag: a plain index above 2^18 would otherwise be cut and its upper bits read as a chunk.
+bool qc_make_bundles(const qc_system *S, const std::vector<QcTask> &tasks, int itmax, std::vector<QcBundle> &bundles, std::vector<int> &ketlist, int unit = 0);
+constexpr int QC_KET_BITS = 18;
+inline unsigned qc_pack_ket_entry(int ket, int kl0, int len) { return (unsigned)ket | ((unsigned)kl0 << QC_KET_BITS) | ((unsigned)len << (QC_KET_BITS + 7)); }
+inline void qc_unpack_ket_entry(int entry, bool packed, int *ket, int *kl0, int *len) {
+    const unsigned e = (unsigned)entry;
+    if (!packed) { *ket = entry; *kl0 = 0; *len = 0; return; }          // (len 0: the whole pair)
+    *ket = (int)(e & ((1u << QC_KET_BITS) - 1)); *kl0 = (int)((e >> QC_KET_BITS) & 0x7fu); *len = (int)(e >> (QC_KET_BITS + 7));
+}
 inline int qc_unit_of(int LAB, int LCD, bool bm) { return bm ? 2 * (QC_LPAIR + 1) + 2 * LCD + (LAB >= 3 ? 1 : 0) : 2 * LAB + (LCD >= 4 ? 1 : 0); }
 // the launch a class belongs to inside a build: with `merge_t1` (bases with f functions) the wide-ket buckets of the bra classes 0 and 1 ride
 // in the launch of bra class 2, those of class 4 in the launch of class 3, those of class 6 in the launch of class 5 (qc_fock_tier1_low_kernel); the per-class launches of the profiling / set-up passes use qc_unit_of

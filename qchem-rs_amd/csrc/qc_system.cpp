@@ -414,9 +414,9 @@ void qc_make_slots(const qc_system *S, const std::vector<QcTask> &tasks, int itm
 // With whole pairs a wave runs as long as its most contracted ket (64 primitive pairs for a pair of contracted s shells) while the
 // lanes of single-primitive kets idle, and a molecule with few shell pairs cannot fill 64 lanes per bra at all (H2O/cc-pVTZ: 55 ss
 // pairs); chunks of equal length fill the lanes and bound the trip count.
-void qc_make_bundles(const qc_system *S, const std::vector<QcTask> &tasks, int itmax, std::vector<QcBundle> &bundles, std::vector<int> &ketlist, int unit) {
+bool qc_make_bundles(const qc_system *S, const std::vector<QcTask> &tasks, int itmax, std::vector<QcBundle> &bundles, std::vector<int> &ketlist, int unit) {
     bundles.clear(); ketlist.clear();
-    if (unit > 0 && S->pairs.size() < (1u << 18)) {
+    if (unit > 0 && S->pairs.size() < (1u << QC_KET_BITS)) {
         struct U { int bra, ket, kl0, len; };
         std::vector<U> us;
         for (const auto &t : tasks) {
@@ -435,7 +435,7 @@ void qc_make_bundles(const qc_system *S, const std::vector<QcTask> &tasks, int i
                 while (j < us.size() && us[j].bra == us[i].bra && j - i < 64) ++j;
                 const int Kab = S->pairs[us[i].bra].K, maxK = us[i].len;
                 const int first = (int)ketlist.size();
-                for (size_t k = i; k < j; ++k) ketlist.push_back((int)((unsigned)us[k].ket | ((unsigned)us[k].kl0 << 18) | ((unsigned)us[k].len << 25)));
+                for (size_t k = i; k < j; ++k) ketlist.push_back((int)qc_pack_ket_entry(us[k].ket, us[k].kl0, us[k].len));
                 // bra primitive pairs per bundle: about max(itmax, 32) primitive quartets per lane, so that the digestion of a partial block
                 // (two to three primitive quartets' worth of instructions) stays a small share
                 static const int pq_env = getenv("QC_BM_PQ") ? atoi(getenv("QC_BM_PQ")) : 32;           // (A/B switch)
@@ -450,7 +450,7 @@ void qc_make_bundles(const qc_system *S, const std::vector<QcTask> &tasks, int i
             std::stable_sort(bundles.begin(), bundles.end(), [](const QcBundle &x, const QcBundle &y) {
                 return (int64_t)(x.ij_hi - x.ij_lo) * x.maxK > (int64_t)(y.ij_hi - y.ij_lo) * y.maxK;
             });
-            return;
+            return true;
         }
     }
     std::vector<QcTask> t(tasks);
@@ -474,6 +474,7 @@ void qc_make_bundles(const qc_system *S, const std::vector<QcTask> &tasks, int i
     std::stable_sort(bundles.begin(), bundles.end(), [](const QcBundle &x, const QcBundle &y) {
         return (int64_t)(x.ij_hi - x.ij_lo) * x.maxK > (int64_t)(y.ij_hi - y.ij_lo) * y.maxK;
     });
+    return false;          // entries are plain pair indices
 }
 
 // Static shard: inside every launch class the cost-sorted quartet list is dealt to the ranks in boustrophedon order
@@ -519,7 +520,7 @@ void qc_build_shards(qc_system *S) {
         if (c.bm) {
             c.bm_rows = 0;
             for (const auto &t : c.shard) c.bm_rows = std::max(c.bm_rows, S->pairs[t.bra].na + S->pairs[t.bra].nb);
-            qc_make_bundles(S, c.shard, itmax, c.bundles, c.ketlist);
+            c.ket_packed = qc_make_bundles(S, c.shard, itmax, c.bundles, c.ketlist);
             // ket-primitive chunks instead of whole ket pairs where they save instructions of the slowest lanes (model below)
             static const int unit_env = getenv("QC_BM_UNIT") ? atoi(getenv("QC_BM_UNIT")) : 8;       // (A/B switch: 0 = whole ket pairs)
             if (unit_env > 0) {
@@ -533,12 +534,12 @@ void qc_build_shards(qc_system *S) {
                 auto cost = [](const std::vector<QcBundle> &bs) { int64_t t = 0; for (const auto &b : bs) t += (int64_t)(b.ij_hi - b.ij_lo) * b.maxK + 6; return t; };
                 std::vector<QcBundle> ub; std::vector<int> uk;
                 static const int unit_pp_env = getenv("QC_BM_PP_UNIT") ? atoi(getenv("QC_BM_PP_UNIT")) : 8;     // (the same for the p.p-ket class)
-                qc_make_bundles(S, c.shard, itmax, ub, uk, c.LCD == 2 ? unit_pp_env : unit_env);
+                const bool upacked = qc_make_bundles(S, c.shard, itmax, ub, uk, c.LCD == 2 ? unit_pp_env : unit_env);
                 static const int gain_env = getenv("QC_BM_GAIN") ? atoi(getenv("QC_BM_GAIN")) : 0;       // (A/B switch: percent of the old cost)
                 const bool high_bra = c.LAB >= 3;
                 const int gain = gain_env > 0 ? gain_env : (c.bundles.size() < 4096 ? 120 : 80);
                 const bool allowed = !high_bra || c.bundles.size() < 512;
-                if (!ub.empty() && allowed && cost(ub) * 100 < cost(c.bundles) * gain) { c.bundles.swap(ub); c.ketlist.swap(uk); }
+                if (!ub.empty() && allowed && cost(ub) * 100 < cost(c.bundles) * gain) { c.bundles.swap(ub); c.ketlist.swap(uk); c.ket_packed = upacked; }
             }
             if (c.LCD == 2) {   // p.p kets: every bundle three times, once per Cartesian axis of the ket's first function (QcBundle::pad0)
                 std::vector<QcBundle> b3;
@@ -598,8 +599,12 @@ void qc_build_shards(qc_system *S) {
             c.prim_quartets += (int64_t)b.K * k.K;          // evaluated (after the primitive-pair cut-off)
             // SURVEY.md 8(d) work model, verbatim
             c.bytes_alg += 8.0 * (5.0 * (Kab + Kcd) + 3.0 * (na * nb + nc * nd + na * nc + na * nd + nb * nc + nb * nd));
-            c.flops_alg += Kab * Kcd * (40.0 * (L + 1) + 3.0 * qc_rwork((int)L) + 2.0 * hab * hcd) + 2.0 * ca * cb * hab * hcd +
-                           2.0 * ca * cb * cc * cd * hcd + 12.0 * na * nb * nc * nd;
+            // (the two Hermite -> Cartesian terms depend on which pair is transformed first; the model takes the cheaper order, so that the
+            // figure is a function of the quartet and not of the orientation a launch class happens to store it in)
+            const double tr_ab_first = 2.0 * ca * cb * hab * hcd + 2.0 * ca * cb * cc * cd * hcd;
+            const double tr_cd_first = 2.0 * cc * cd * hcd * hab + 2.0 * cc * cd * ca * cb * hab;
+            c.flops_alg += Kab * Kcd * (40.0 * (L + 1) + 3.0 * qc_rwork((int)L) + 2.0 * hab * hcd) + std::min(tr_ab_first, tr_cd_first) +
+                           12.0 * na * nb * nc * nd;
             // LDS doubles one lane group needs for this quartet (layout in qc_fock_kernel.h)
             const int ncd = k.na * k.nb, nab = b.na * b.nb;
             // (the bra block is read straight from memory)

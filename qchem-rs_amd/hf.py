@@ -42,7 +42,7 @@ EXPORTS = ["qc_system_create", "qc_system_destroy", "qc_nbasis", "qc_nelectrons"
            "qc_comm_init", "qc_set_shard", "qc_plan_shard", "qc_set_stream", "qc_device_ready", "qc_work_stats_get",
            "qc_fock_profile", "qc_plan_shard_quartets", "qc_scf_begin_rhf", "qc_scf_begin_uhf", "qc_scf_iterate",
            "qc_scf_orbital_energies", "qc_scf_density", "qc_scf_spin_square", "qc_scf_timings", "qc_scf_end", "qc_fock_profile_tiers", "qc_unit_quartets", "qc_sym_eig_warm", "qc_set_fock_mode", "qc_scf_tensor_ms", "qc_set_accumulation", "qc_set_schwarz", "qc_scf_matrix", "qc_rccl_info", "qc_measure_peaks",
-           "qc_scf_set_stop_rule", "qc_scf_counters"]
+           "qc_scf_set_stop_rule", "qc_scf_counters", "qc_debug_ket_entry"]
 
 
 class QcError(RuntimeError):
@@ -132,7 +132,7 @@ def lib():
         L.qc_scf_timings.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double)]
         L.qc_scf_end.argtypes = [vp]; L.qc_scf_end.restype = None
         L.qc_scf_set_stop_rule.argtypes = [vp, C.c_double]
-        L.qc_scf_counters.argtypes = [vp, C.POINTER(C.c_double)]
+        L.qc_scf_counters.argtypes = [vp, C.POINTER(C.c_double), C.c_int]
         _lib = L
     return _lib
 
@@ -339,10 +339,10 @@ class ScfStepper:
 
     def counters(self):
         """ms_setup, ms_fock (builds with a tuner run left out), ms_linalg, builds behind ms_fock, host ms of tuner runs, passes,
-        speculative builds consumed / discarded."""
-        v = (C.c_double * 8)()
-        _check(lib().qc_scf_counters(self._st, v), "qc_scf_counters")
-        k = ("setup", "fock", "linalg", "builds_timed", "tuner", "passes", "spec_hits", "spec_lost")
+        speculative builds consumed / discarded, passes whose eigensolve was repeated."""
+        v = (C.c_double * 11)()
+        _check(lib().qc_scf_counters(self._st, v, 11), "qc_scf_counters")
+        k = ("setup", "fock", "linalg", "builds_timed", "tuner", "passes", "spec_hits", "spec_lost", "redos", "assign_trials", "assign_frozen")
         return dict(zip(k, [float(x) for x in v]))
 
     def close(self):

@@ -252,6 +252,33 @@ def test_rccl_path_single_rank_communicator():
     assert "rccl" in q.rccl_info().lower()
 
 
+def test_repeat_branch_with_a_communicator(monkeypatch):
+    """The repeat branch of a pass (scf_iterate: a refinement that asks for rotations -> the eigensolve again, new density, the scalars
+    published a second time - the one place where a multi-rank pass issues a second collective) with a 1-rank communicator.  Reached on
+    purpose: QC_EIG_WARM_RMS = 0.5 lets the perturbative refinement start while the density still moves by 0.1 per element.  The
+    trajectory may differ from the default path in its last bits (other eigensolver per pass), the fixed point may not."""
+    import qchem_rs_amd as q
+    m = load_system("ethylene", "cc-pVDZ")                 # n = 48: one-workgroup path without a communicator, generic path with one
+    s0 = q.System(m)
+    e0 = q.restricted_hartree_fock(s0, q.HartreeFockConfig(100, 1e-10))
+    monkeypatch.setenv("QC_EIG_WARM_RMS", "0.5")
+    for comm in (False, True):
+        s = q.System(m)
+        if comm:
+            s.comm_init(q.comm_unique_id(), 0, 1)
+        st = q.ScfStepper(s)
+        e = r = None
+        for k in range(60):
+            e, r = st.iterate()
+            if r < 1e-10:
+                break
+        c = st.counters()
+        st.close(); s.close()
+        assert r < 1e-10 and c["redos"] >= 1, (comm, c)
+        assert abs(e - e0.electronic_energy) < 1e-9, (comm, e, e0.electronic_energy)
+    s0.close()
+
+
 def test_step_api_matches_driver():
     """qc_scf_begin/iterate/end (the entry points a host-owned convergence loop binds) == qc_scf_rhf."""
     q, s, o = _sys("water", "cc-pVDZ")
@@ -672,6 +699,37 @@ def test_benzene_ccpvdz_energy_matches_oracle():
     assert abs(e + s.nuclear_repulsion() - ref["total_energy"]) < 5 * TOL_E          # plausibility bound on the reported values
     out = q.restricted_hartree_fock(s, q.HartreeFockConfig(100, 1e-8))              # the driver returns what the stepper saw
     assert out is not None and out.iterations == k and out.electronic_energy == e
+
+
+def test_benzene_ccpvdz_reaches_the_noise_floor():
+    """BASELINE config 5 at epsilon = 1e-10: the loop of rhf.rs:66-104 - never-reset DIIS over six samples - has a noise floor
+    on this molecule; the pass at which rms first dips below 1e-10 is random (24, 30, 87, > 95 in five variants of the product; the oracle
+    stalls at 3e-9).  What IS robust, and pinned here: the floor is reached by pass 21 (rms < 1e-9), the walk stays orders of magnitude
+    below the convergence region's entry (< 1e-5 through pass 60; excursions depend on the last bits of G - 3e-8 with round 3's work
+    lists, 1.5e-6 with round 4's, whose cost-sorted order differs - a bound of 1e-7 is NOT robust), and the energy no longer moves: the
+    reported one (stale G: first order in the residual - 1.2e-7 Eh off in the two passes of an excursion) to 1e-6 Eh, the variational one
+    of the pass's density, evaluated by a second handle's Fock build, to 1e-10."""
+    import qchem_rs_amd as q
+    m = load_system("benzene", "cc-pVDZ")
+    s, s2 = q.System(m), q.System(m)
+    st = q.ScfStepper(s)
+    H = None
+    tr, evar = [], {}
+    for k in range(61):
+        e, r = st.iterate()
+        tr.append((e, r))
+        if k in (21, 30, 40, 50, 60):
+            if H is None:
+                H = st.matrix("H")
+            D = st.density(0)
+            evar[k] = 0.5 * float(np.sum(D * (2 * H + s2.fock_rhf(D))))
+    st.close(); s.close(); s2.close()
+    first = next(k for k, (_, r) in enumerate(tr) if r < 1e-9)
+    assert first <= 21, first
+    assert max(r for _, r in tr[21:]) < 1e-5
+    assert max(abs(e - tr[21][0]) for e, _ in tr[21:]) < 1e-6
+    ev = list(evar.values())
+    assert max(ev) - min(ev) < 1e-10, evar
 
 
 @pytest.mark.parametrize("mol,basis", [("water", "cc-pVDZ"), ("ethylene", "6-31G_st_st"), ("oxygen", "cc-pVDZ")])

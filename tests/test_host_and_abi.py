@@ -110,3 +110,21 @@ def test_reciprocal_index_division_is_exact_on_the_kernels_range():
         inv0 = np.float32(1.0) / np.float32(d)
         for inv in (inv0, np.nextafter(inv0, np.float32(0)), np.nextafter(inv0, np.float32(2))):
             assert np.array_equal((xf * inv).astype(np.int64), x // d), d
+
+
+def test_ket_list_entries_survive_more_than_2_18_shell_pairs():
+    """the device-record builder decoded EVERY ket-list entry as (pair | first primitive << 18 | length << 25), also the plain
+    pair indices of lists that were never packed (systems with 2^18 or more stored shell pairs, or ket pairs of more than 127 primitives)
+    - a plain index above 2^18 lost its upper bits to a chunk that does not exist.  The decode now follows the list's packing flag."""
+    import ctypes as C
+    import numpy as np
+    import qchem_rs_amd as q
+    L = q.lib()
+    out = (C.c_int32 * 3)()
+    for ket in (0, 5, (1 << 18) - 1, 1 << 18, (1 << 18) + 12345, (1 << 25) + 7, (1 << 30) + 3):
+        assert L.qc_debug_ket_entry(ket, 0, 0, 0, out) == 0
+        assert list(out) == [ket, 0, 0], (ket, list(out))           # plain entries: whole pair, whatever the index
+    for ket, f, n in ((0, 0, 1), (77, 3, 8), ((1 << 18) - 1, 120, 7), (1234, 127, 127)):
+        assert L.qc_debug_ket_entry(ket, f, n, 1, out) == 0
+        assert list(out) == [ket, f, n]
+    assert L.qc_debug_ket_entry(1 << 18, 0, 1, 1, out) == -1        # does not fit a packed entry: the list builder never packs then

@@ -27,7 +27,10 @@ dist.init_process_group("gloo")
 box = [q.comm_unique_id() if rank == 0 else None]
 dist.broadcast_object_list(box, src=0)
 out = {{}}
-for mol, basis, uhf in (("water", "cc-pVDZ", False), ("water", "STO-3G", True), ("benzene", "STO-3G", False)):
+# (QC_EIG_WARM_RMS in the environment of the second invocation: the perturbative refinement starts while the density still moves, asks for
+# rotations, and the pass takes its repeat branch - the one place where a pass issues a second collective, scf_iterate)
+redo = os.environ.get("QC_EIG_WARM_RMS") is not None
+for mol, basis, uhf in ((("ethylene", "cc-pVDZ", False),) if redo else (("water", "cc-pVDZ", False), ("water", "STO-3G", True), ("benzene", "STO-3G", False))):
     m = load_system(mol, basis)
     ref = q.System(m)                                    # this rank alone: the whole quartet list
     run = q.unrestricted_hartree_fock if uhf else q.restricted_hartree_fock
@@ -35,6 +38,12 @@ for mol, basis, uhf in (("water", "cc-pVDZ", False), ("water", "STO-3G", True), 
     s = q.System(m)
     s.comm_init(box[0], rank, world)
     r2 = run(s, q.HartreeFockConfig(100, 1e-9))
+    if redo:
+        st = q.ScfStepper(s)
+        for k in range(12):
+            st.iterate()
+        c = st.counters(); st.close()
+        assert c["redos"] >= 1, c
     out["%s/%s/%s" % (mol, basis, "uhf" if uhf else "rhf")] = dict(
         same_energy=abs(r1.electronic_energy - r2.electronic_energy) < 1e-10, same_iterations=r1.iterations == r2.iterations,
         same_orbitals=max(abs(x - y) for x, y in zip(r1.orbital_energies, r2.orbital_energies)) < 1e-9,
@@ -62,15 +71,20 @@ def test_two_ranks_agree_bitwise_and_reproduce_the_single_gpu_scf(tmp_path):
     script.write_text(WORKER.format(root=ROOT))
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-    p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
-                        "--master-port", str(port), str(script)], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env, timeout=900)
-    assert p.returncode == 0, p.stderr[-3000:]
-    seen = {}
-    for ln in p.stdout.splitlines():
-        if ln.startswith("RANK"):
-            seen[int(ln[4])] = json.loads(ln.split(" ", 1)[1])
-    assert sorted(seen) == [0, 1]
-    for rank, res in seen.items():
-        for key, r in res.items():
-            assert r["same_energy"] and r["same_iterations"] and r["same_orbitals"], (rank, key, r)
-    assert seen[0] == seen[1]                                # every rank holds the same state, bit for bit (hex digits compared)
+    for redo in (False, True):
+        if redo:
+            env["QC_EIG_WARM_RMS"] = "0.5"                   # the repeat branch of scf_iterate (second collective of a pass) on two ranks
+        p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+                            "--master-port", str(port), str(script)], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env, timeout=900)
+        assert p.returncode == 0, p.stderr[-3000:]
+        seen = {}
+        for ln in p.stdout.splitlines():
+            if ln.startswith("RANK"):
+                seen[int(ln[4])] = json.loads(ln.split(" ", 1)[1])
+        assert sorted(seen) == [0, 1]
+        for rank, res in seen.items():
+            for key, r in res.items():
+                # (with the repeat branch forced, single-GPU and two-rank runs take other eigensolvers per pass: same fixed point, the
+                # pass count may differ by one)
+                assert r["same_energy"] and r["same_orbitals"] and (redo or r["same_iterations"]), (rank, key, r)
+        assert seen[0] == seen[1]                            # every rank holds the same state, bit for bit (hex digits compared)
