@@ -131,7 +131,8 @@ constexpr int QC_SYNC_WORDS = 12;          // 4 doubles + 16 ints of pass scalar
 
 struct ScfWork {
     int n;
-    DevBuf H, S, X, t1, t2, t3, t4, Fp, Cp, C, w, ework, Fd, scal, small, CpPrev[2], CpNew[2], Fps[2], X0, tri;
+    // (work buffers of a Roothaan step come in two sets: the two spins of a UHF pass run at the same time on two streams, set b = spin)
+    DevBuf H, S, X, t1[2], t2[2], t3[2], t4[2], Fp[2], Cp, C, w, ework[2], Fd[2], scal, small[2], CpPrev[2], CpNew[2], Fps[2], X0[2], tri[2];
     bool have_prev[2] = {false, false};
     // Open-shell runs (n_alpha != n_beta) use the rotation-based eigensolvers only.  Their SCF solutions of interest include
     // saddles of the UHF functional that are kept by spatial symmetry alone (O2 triplet, BASELINE config 4): Jacobi rotations
@@ -152,13 +153,17 @@ struct ScfWork {
         if (h_scal) (void)hipHostFree(h_scal);
         if (d_sync) (void)hipFree(d_sync);
     }
-    int init(int n_) {
+    int init(int n_, int nsets) {
         n = n_;
         const size_t nn = (size_t)n * n;
-        DevBuf *all[] = {&H, &S, &X, &t1, &t2, &t3, &t4, &Fp, &Cp, &C, &ework, &Fd, &CpPrev[0], &CpPrev[1], &CpNew[0], &CpNew[1], &Fps[0], &Fps[1], &X0};
+        DevBuf *all[] = {&H, &S, &X, &Cp, &C, &CpPrev[0], &CpPrev[1], &CpNew[0], &CpNew[1], &Fps[0], &Fps[1]};
         for (auto b : all) if (b->alloc(nn) != QC_OK) return QC_ERR_HIP;
-        if (tri.alloc(qc_eig_tridiag_work_doubles(n)) != QC_OK) return QC_ERR_HIP;
-        if (w.alloc(n) != QC_OK || scal.alloc(16) != QC_OK || small.alloc(qc_eig_small_doubles(n)) != QC_OK) return QC_ERR_HIP;
+        for (int b = 0; b < nsets; ++b) {
+            DevBuf *set[] = {&t1[b], &t2[b], &t3[b], &t4[b], &Fp[b], &ework[b], &Fd[b], &X0[b]};
+            for (auto x : set) if (x->alloc(nn) != QC_OK) return QC_ERR_HIP;
+            if (tri[b].alloc(qc_eig_tridiag_work_doubles(n)) != QC_OK || small[b].alloc(qc_eig_small_doubles(n)) != QC_OK) return QC_ERR_HIP;
+        }
+        if (w.alloc(n) != QC_OK || scal.alloc(16) != QC_OK) return QC_ERR_HIP;
         if (hipMalloc(&ctl, 16 * sizeof(int)) != hipSuccess || hipMemset(ctl, 0, 16 * sizeof(int)) != hipSuccess) return QC_ERR_HIP;
         if (hipHostMalloc(&h_scal, (2 * QC_SYNC_WORDS + 1) * sizeof(double)) != hipSuccess) return QC_ERR_HIP;
         std::memset(h_scal, 0, (2 * QC_SYNC_WORDS + 1) * sizeof(double));     // (the last word: sequence number of the pass, see scf_iterate)
@@ -170,8 +175,8 @@ struct ScfWork {
 // sorted_eigs on device (utils.rs:20-36): Fp -> (Cp, w)
 int device_sorted_eigs(qc_system *S, ScfWork &W, double *dA, double *dV, double *dw) {
     // (set-up eigensolves: synchronous; ctl[12..15] scratch, ctl[9]: Jacobi sweeps ran out)
-    if (W.rotations_only) return qc_eig_device(S->stream, W.n, dA, dV, dw, W.ework.p, 40, 1e-9, W.ctl + 9);
-    return qc_eig_cold_sync(S->stream, W.n, dA, W.X0.p, W.tri.p, dV, dw, W.ework.p, W.t1.p, W.t2.p, W.t3.p, W.t4.p, W.small.p, W.ctl + 12, W.ctl + 9);
+    if (W.rotations_only) return qc_eig_device(S->stream, W.n, dA, dV, dw, W.ework[0].p, 40, 1e-9, W.ctl + 9);
+    return qc_eig_cold_sync(S->stream, W.n, dA, W.X0[0].p, W.tri[0].p, dV, dw, W.ework[0].p, W.t1[0].p, W.t2[0].p, W.t3[0].p, W.t4[0].p, W.small[0].p, W.ctl + 12, W.ctl + 9);
 }
 
 // start-up shared by both drivers: H = T + V, X = S^-1/2 (rhf.rs:124-131), Hückel matrix (rhf.rs:141-143)
@@ -181,10 +186,10 @@ int scf_setup(qc_system *S, ScfWork &W, std::vector<double> &h_eht) {
     // S, T, V on the device (molint::overlap / kinetic / nuclear, rhf.rs:41-43); H = T + V (rhf.rs:48)
     hipStream_t st = S->stream;
     int rc1 = qc_one_electron_device(S, 0, W.S.p);
-    if (rc1 == QC_OK) rc1 = qc_one_electron_device(S, 1, W.t1.p);
-    if (rc1 == QC_OK) rc1 = qc_one_electron_device(S, 2, W.t2.p);
+    if (rc1 == QC_OK) rc1 = qc_one_electron_device(S, 1, W.t1[0].p);
+    if (rc1 == QC_OK) rc1 = qc_one_electron_device(S, 2, W.t2[0].p);
     if (rc1 != QC_OK) return rc1;
-    qc_axpby(st, n, 1.0, W.t1.p, 1.0, W.t2.p, W.H.p);
+    qc_axpby(st, n, 1.0, W.t1[0].p, 1.0, W.t2[0].p, W.H.p);
     std::vector<double> s(nn), h(nn);
     QC_HIP_CHECK(hipMemcpyAsync(s.data(), W.S.p, nn * sizeof(double), hipMemcpyDeviceToHost, st));
     QC_HIP_CHECK(hipMemcpyAsync(h.data(), W.H.p, nn * sizeof(double), hipMemcpyDeviceToHost, st));
@@ -196,10 +201,10 @@ int scf_setup(qc_system *S, ScfWork &W, std::vector<double> &h_eht) {
     // X = U (diag((U^T S U)_ii^-1/2) U^T): note the diagonal of the product, not the returned eigenvalues
     int rc = device_sorted_eigs(S, W, W.S.p, W.Cp.p, W.w.p);          // U (column order is immaterial for X)
     if (rc != QC_OK) return rc;
-    qc_gemm(st, n, n, n, 1.0, W.S.p, n, false, W.Cp.p, n, false, 0.0, W.t1.p, n);      // S U
-    qc_gemm(st, n, n, n, 1.0, W.Cp.p, n, true, W.t1.p, n, false, 0.0, W.t2.p, n);      // U^T (S U)
-    qc_scale_cols_invsqrt(st, n, W.Cp.p, W.t2.p, W.t1.p);                               // U diag^-1/2
-    qc_gemm(st, n, n, n, 1.0, W.t1.p, n, false, W.Cp.p, n, true, 0.0, W.X.p, n);       // (.) U^T
+    qc_gemm(st, n, n, n, 1.0, W.S.p, n, false, W.Cp.p, n, false, 0.0, W.t1[0].p, n);      // S U
+    qc_gemm(st, n, n, n, 1.0, W.Cp.p, n, true, W.t1[0].p, n, false, 0.0, W.t2[0].p, n);      // U^T (S U)
+    qc_scale_cols_invsqrt(st, n, W.Cp.p, W.t2[0].p, W.t1[0].p);                               // U diag^-1/2
+    qc_gemm(st, n, n, n, 1.0, W.t1[0].p, n, false, W.Cp.p, n, true, 0.0, W.X.p, n);       // (.) U^T
     return QC_OK;
 }
 
@@ -207,10 +212,10 @@ int scf_setup(qc_system *S, ScfWork &W, std::vector<double> &h_eht) {
 int huckel_density(qc_system *S, ScfWork &W, const std::vector<double> &h_eht, int nocc, double factor, double *dD) {
     const int n = S->nbasis;
     hipStream_t st = S->stream;
-    QC_HIP_CHECK(hipMemcpyAsync(W.Fd.p, h_eht.data(), h_eht.size() * sizeof(double), hipMemcpyHostToDevice, st));
-    qc_gemm(st, n, n, n, 1.0, W.Fd.p, n, false, W.X.p, n, false, 0.0, W.t1.p, n);
-    qc_gemm(st, n, n, n, 1.0, W.X.p, n, true, W.t1.p, n, false, 0.0, W.Fp.p, n);
-    int rc = device_sorted_eigs(S, W, W.Fp.p, W.Cp.p, W.w.p);
+    QC_HIP_CHECK(hipMemcpyAsync(W.Fd[0].p, h_eht.data(), h_eht.size() * sizeof(double), hipMemcpyHostToDevice, st));
+    qc_gemm(st, n, n, n, 1.0, W.Fd[0].p, n, false, W.X.p, n, false, 0.0, W.t1[0].p, n);
+    qc_gemm(st, n, n, n, 1.0, W.X.p, n, true, W.t1[0].p, n, false, 0.0, W.Fp[0].p, n);
+    int rc = device_sorted_eigs(S, W, W.Fp[0].p, W.Cp.p, W.w.p);
     if (rc != QC_OK) return rc;
     qc_gemm(st, n, n, n, 1.0, W.X.p, n, false, W.Cp.p, n, false, 0.0, W.C.p, n);
     if (nocc > 0) qc_gemm(st, n, n, nocc, factor, W.C.p, n, false, W.C.p, n, true, 0.0, dD, n);
@@ -221,35 +226,36 @@ int huckel_density(qc_system *S, ScfWork &W, const std::vector<double> &h_eht, i
 // One spin's Roothaan step, enqueued without any host synchronisation: F = H + G; e = FDS - SDF; DIIS; F' = X^T F X;
 // eigenvectors; C = X C'   (rhf.rs:70-76).  The eigensolve is warm-started from this spin's previous vectors once they
 // exist (qc_eig_refine_async: outcome in ctl[4 spin]); new vectors go to CpNew[spin], C to dC.
+// (`st`, `b`: the stream the step is enqueued on and its set of work buffers - the two spins of a UHF pass are independent until their
+// scalars meet and run side by side, scf_iterate)
 int roothaan_enqueue(qc_system *S, ScfWork &W, DeviceDiis &diis, const double *dG, const double *dD, double *dw_out, double *dC, int spin,
-                     double *dE, double *dF, bool have_F) {
+                     double *dE, double *dF, bool have_F, hipStream_t st, int b) {
     const int n = S->nbasis;
-    hipStream_t st = S->stream;
     if (!have_F) qc_axpby(st, n, 1.0, W.H.p, 1.0, dG, dF);                               // F (else written by the build's closing kernel)
-    qc_gemm(st, n, n, n, 1.0, dF, n, false, dD, n, false, 0.0, W.t2.p, n);               // F D
-    qc_gemm(st, n, n, n, 1.0, W.t2.p, n, false, W.S.p, n, false, 0.0, W.Fp.p, n);        // F D S
-    qc_sub_transpose(st, n, W.Fp.p, dE);                                                 // e = FDS - (FDS)^T = FDS - SDF
-    int rc = diis.extrapolate(st, W.Fd.p, W.ctl + 8);
+    qc_gemm(st, n, n, n, 1.0, dF, n, false, dD, n, false, 0.0, W.t2[b].p, n);               // F D
+    qc_gemm(st, n, n, n, 1.0, W.t2[b].p, n, false, W.S.p, n, false, 0.0, W.Fp[b].p, n);        // F D S
+    qc_sub_transpose(st, n, W.Fp[b].p, dE);                                                 // e = FDS - (FDS)^T = FDS - SDF
+    int rc = diis.extrapolate(st, W.Fd[b].p, W.ctl + 8);
     if (rc != QC_OK) return rc;
-    qc_gemm(st, n, n, n, 1.0, W.Fd.p, n, false, W.X.p, n, false, 0.0, W.t1.p, n);        // F X
-    qc_gemm(st, n, n, n, 1.0, W.X.p, n, true, W.t1.p, n, false, 0.0, W.Fps[spin].p, n);  // X^T (F X)
+    qc_gemm(st, n, n, n, 1.0, W.Fd[b].p, n, false, W.X.p, n, false, 0.0, W.t1[b].p, n);        // F X
+    qc_gemm(st, n, n, n, 1.0, W.X.p, n, true, W.t1[b].p, n, false, 0.0, W.Fps[spin].p, n);  // X^T (F X)
     // Eigensolve.  Near convergence (mode 0): GEMM refinement from this spin's previous vectors.  Otherwise - first pass, or the
     // density still moves by more than 1e-3 per element - the tridiagonal path (start vectors from qc_eig_tridiag.hip + the same
     // refinement); matrices below QC_TRI_MIN_N go to the single-workgroup Jacobi kernels.  Outcome in ctl[4 spin].
     W.cold[spin] = false;
     static const bool force_jacobi = getenv("QC_EIG_JACOBI") != nullptr;      // A/B switch: no tridiagonal path
     if (W.have_prev[spin] && W.mode[spin] == 0)
-        rc = qc_eig_refine_async(st, n, W.Fps[spin].p, W.CpPrev[spin].p, W.CpNew[spin].p, dw_out, W.ework.p, W.t1.p, W.t2.p, W.t3.p, W.t4.p,
-                                 W.small.p, W.ctl + 4 * spin, W.npass[spin]);
+        rc = qc_eig_refine_async(st, n, W.Fps[spin].p, W.CpPrev[spin].p, W.CpNew[spin].p, dw_out, W.ework[b].p, W.t1[b].p, W.t2[b].p, W.t3[b].p, W.t4[b].p,
+                                 W.small[b].p, W.ctl + 4 * spin, W.npass[spin]);
     else if (qc_tri_ok(n) && !force_jacobi && !W.rotations_only) {
         W.cold[spin] = true;
         // (three refinement passes are enqueued: two finish most starts - the third is then five empty launches - but near-degenerate
         // clusters of a nearly converged benzene need it, and running out of passes costs a Jacobi eigensolve)
-        rc = qc_eig_cold_async(st, n, W.Fps[spin].p, W.X0.p, W.tri.p, W.CpNew[spin].p, dw_out, W.ework.p, W.t1.p, W.t2.p, W.t3.p, W.t4.p, W.small.p,
+        rc = qc_eig_cold_async(st, n, W.Fps[spin].p, W.X0[b].p, W.tri[b].p, W.CpNew[spin].p, dw_out, W.ework[b].p, W.t1[b].p, W.t2[b].p, W.t3[b].p, W.t4[b].p, W.small[b].p,
                                W.ctl + 4 * spin, 3);
     } else if (W.have_prev[spin])
-        rc = qc_eig_device_warm(st, n, W.Fps[spin].p, W.CpPrev[spin].p, W.CpNew[spin].p, dw_out, W.ework.p, W.t1.p, W.t2.p, 40, 1e-9, W.ctl + 9);
-    else rc = qc_eig_device(st, n, W.Fps[spin].p, W.CpNew[spin].p, dw_out, W.ework.p, 40, 1e-9, W.ctl + 9);   // sorted_eigs (rhf.rs:75), cold
+        rc = qc_eig_device_warm(st, n, W.Fps[spin].p, W.CpPrev[spin].p, W.CpNew[spin].p, dw_out, W.ework[b].p, W.t1[b].p, W.t2[b].p, 40, 1e-9, W.ctl + 9);
+    else rc = qc_eig_device(st, n, W.Fps[spin].p, W.CpNew[spin].p, dw_out, W.ework[b].p, 40, 1e-9, W.ctl + 9);   // sorted_eigs (rhf.rs:75), cold
     if (rc != QC_OK) return rc;
     qc_gemm(st, n, n, n, 1.0, W.X.p, n, false, W.CpNew[spin].p, n, false, 0.0, dC, n);   // C = X C'
     return QC_OK;
@@ -269,6 +275,7 @@ int roothaan_small(qc_system *S, ScfWork &W, DeviceDiis &diis, const double *dG,
     a.D = dD; a.S = W.S.p; a.X = W.X.p; a.H = W.H.p; a.G = dG;
     a.E_out = dE;
     a.m = (int)diis.slots.size(); a.minlen = diis.minlen; a.maxlen = diis.maxlen;
+    a.dots_generic = W.rotations_only ? 1 : 0;
     for (int j = 0; j < a.m; ++j) { a.slot[j] = diis.slots[j]; a.errs[j] = diis.pool[2 * diis.slots[j]]; a.focks[j] = diis.pool[2 * diis.slots[j] + 1]; }
     a.Bmat = diis.d_B; a.c_out = diis.d_c; a.diis_flag = W.ctl + 8;
     a.Fp = W.Fps[spin].p;
@@ -289,12 +296,12 @@ int roothaan_small(qc_system *S, ScfWork &W, DeviceDiis &diis, const double *dG,
     if ((rc = qc_scf_small_launch(st, pre)) != QC_OK) return rc;
     if (qc_tri_ok(n) && !force_jacobi && !W.rotations_only) {
         W.cold[spin] = true;
-        if ((rc = qc_eig_tridiag_start(st, n, W.Fps[spin].p, W.X0.p, W.tri.p)) != QC_OK) return rc;
-        a.phases = 6; a.V0 = W.X0.p; a.npass = 3;
+        if ((rc = qc_eig_tridiag_start(st, n, W.Fps[spin].p, W.X0[0].p, W.tri[0].p)) != QC_OK) return rc;
+        a.phases = 6; a.V0 = W.X0[0].p; a.npass = 3;
         return qc_scf_small_launch(st, a);
     }
-    if (W.have_prev[spin]) rc = qc_eig_device_warm(st, n, W.Fps[spin].p, W.CpPrev[spin].p, W.CpNew[spin].p, dw_out, W.ework.p, W.t1.p, W.t2.p, 40, 1e-9, W.ctl + 9);
-    else rc = qc_eig_device(st, n, W.Fps[spin].p, W.CpNew[spin].p, dw_out, W.ework.p, 40, 1e-9, W.ctl + 9);
+    if (W.have_prev[spin]) rc = qc_eig_device_warm(st, n, W.Fps[spin].p, W.CpPrev[spin].p, W.CpNew[spin].p, dw_out, W.ework[0].p, W.t1[0].p, W.t2[0].p, 40, 1e-9, W.ctl + 9);
+    else rc = qc_eig_device(st, n, W.Fps[spin].p, W.CpNew[spin].p, dw_out, W.ework[0].p, 40, 1e-9, W.ctl + 9);
     if (rc != QC_OK) return rc;
     a.phases = 4; a.Cp_in = W.CpNew[spin].p;
     return qc_scf_small_launch(st, a);
@@ -306,12 +313,12 @@ int roothaan_redo_eig(qc_system *S, ScfWork &W, double *dw_out, double *dC, int 
     hipStream_t st = S->stream;
     int rc;
     if (W.cold[spin] && W.have_prev[spin])    // the tridiagonal start was not good enough: rotations in the basis of the previous vectors
-        rc = qc_eig_device_warm(st, n, W.Fps[spin].p, W.CpPrev[spin].p, W.CpNew[spin].p, dw_out, W.ework.p, W.t1.p, W.t2.p, 40, 1e-9, W.ctl + 9);
-    else if (W.cold[spin]) rc = qc_eig_device(st, n, W.Fps[spin].p, W.CpNew[spin].p, dw_out, W.ework.p, 40, 1e-9, W.ctl + 9);
+        rc = qc_eig_device_warm(st, n, W.Fps[spin].p, W.CpPrev[spin].p, W.CpNew[spin].p, dw_out, W.ework[0].p, W.t1[0].p, W.t2[0].p, 40, 1e-9, W.ctl + 9);
+    else if (W.cold[spin]) rc = qc_eig_device(st, n, W.Fps[spin].p, W.CpNew[spin].p, dw_out, W.ework[0].p, 40, 1e-9, W.ctl + 9);
     else if (W.rotations_only)
-        rc = qc_eig_device_refine(st, n, W.Fps[spin].p, W.CpPrev[spin].p, W.CpNew[spin].p, dw_out, W.ework.p, W.t1.p, W.t2.p, W.t3.p, W.t4.p, W.small.p, W.ctl + 9);
+        rc = qc_eig_device_refine(st, n, W.Fps[spin].p, W.CpPrev[spin].p, W.CpNew[spin].p, dw_out, W.ework[0].p, W.t1[0].p, W.t2[0].p, W.t3[0].p, W.t4[0].p, W.small[0].p, W.ctl + 9);
     else     // the refinement from the previous vectors was not perturbative after all: the tridiagonal path (its own fallback: the Jacobi kernels)
-        rc = qc_eig_cold_sync(st, n, W.Fps[spin].p, W.X0.p, W.tri.p, W.CpNew[spin].p, dw_out, W.ework.p, W.t1.p, W.t2.p, W.t3.p, W.t4.p, W.small.p, W.ctl + 12, W.ctl + 9);
+        rc = qc_eig_cold_sync(st, n, W.Fps[spin].p, W.X0[0].p, W.tri[0].p, W.CpNew[spin].p, dw_out, W.ework[0].p, W.t1[0].p, W.t2[0].p, W.t3[0].p, W.t4[0].p, W.small[0].p, W.ctl + 12, W.ctl + 9);
     if (rc != QC_OK) return rc;
     qc_gemm(st, n, n, n, 1.0, W.X.p, n, false, W.CpNew[spin].p, n, false, 0.0, dC, n);
     return QC_OK;
@@ -399,6 +406,7 @@ int qc_one_electron_gpu(qc_system *S, int which, double *out) {
 int qc_set_stream(qc_system *S, void *hip_stream) {
     if (!S) return QC_ERR_INVALID;
     if (S->own_stream && S->stream) { (void)hipStreamDestroy(S->stream); S->own_stream = false; }
+    S->lanes_probed = false;                                     // (which side stream shares the pipe of the caller's stream was not measured)
     S->prepared = false; S->gt_clean = false;                    // (the preliminaries of a prepared build were enqueued on the old stream)
     S->stream = (hipStream_t)hip_stream;
     if (!S->stream && S->device_ready) { QC_HIP_CHECK(hipStreamCreateWithFlags(&S->stream, hipStreamNonBlocking)); S->own_stream = true; }
@@ -609,6 +617,7 @@ struct qc_scf_state {
     // SCF state) switches it on.
     bool spec_on = getenv("QC_SPEC") != nullptr && getenv("QC_NO_SPEC") == nullptr;
     int64_t spec_hits = 0, spec_lost = 0, builds_timed = 0, passes = 0, redos = 0;
+    bool spin_parallel = getenv("QC_NO_SPIN_PARALLEL") == nullptr;      // (A/B switch, read per SCF state)
     double warm_rms_env = getenv("QC_EIG_WARM_RMS") ? atof(getenv("QC_EIG_WARM_RMS")) : 0.0;   // (read per SCF state: tests reach the repeat branch with it)
     double ms_tuner = 0;
     bool cur_build_tuned = false, pend_build_tuned = false;   // the build of the current / the pending timing set contained a tuner run
@@ -646,8 +655,12 @@ static void scf_state_delete(qc_scf_state *st) {
 static int scf_begin(qc_system *S, bool uhf, int n_alpha, int n_beta, qc_scf_state **out) {
     if (!S || !out) return QC_ERR_INVALID;
     const double t0 = now_ms();
+    static const bool sdbg = getenv("QC_SETUP_DEBUG") != nullptr;
+    double tt = t0;
+    auto lap = [&](const char *what) { if (sdbg) { const double t = now_ms(); fprintf(stderr, "[setup] %-28s %.3f ms\n", what, t - tt); tt = t; } };
     int rc = qc_device_init(S);
     if (rc != QC_OK) return rc;
+    lap("qc_device_init (total)");
     const int n = S->nbasis;
     const size_t nn = (size_t)n * n;
     qc_scf_state *st = new (std::nothrow) qc_scf_state();
@@ -663,16 +676,22 @@ static int scf_begin(qc_system *S, bool uhf, int n_alpha, int n_beta, qc_scf_sta
     st->W.rotations_only = uhf && st->nocc[0] != st->nocc[1];
     // (not for open-shell runs: their saddle-point trajectories depend on every last bit - DESIGN.md 1 - and keep the arithmetic they were
     // validated with; QC_NO_SMALL_FUSED: A/B switch, the generic launch sequence)
-    st->W.small_fused = n <= QC_SMALL_MAXN && !st->W.rotations_only && getenv("QC_NO_SMALL_FUSED") == nullptr;
-    if ((rc = st->W.init(n)) != QC_OK) return rc;
+    // (round 4: open-shell runs take it too when QC_OPEN_SHELL_FUSED is set - with the DIIS dot products in the generic sequence's summation
+    // order, QcSmallArgs::dots_generic; default decided by the bit-for-bit comparison of the O2-triplet trace)
+    static const bool open_fused = getenv("QC_OPEN_SHELL_FUSED") != nullptr;
+    st->W.small_fused = n <= QC_SMALL_MAXN && (!st->W.rotations_only || open_fused) && getenv("QC_NO_SMALL_FUSED") == nullptr;
+    if ((rc = st->W.init(n, uhf ? 2 : 1)) != QC_OK) return rc;
     for (int s = 0; s < nspin; ++s) if (st->D[s].alloc(nn) != QC_OK || st->Dn[s].alloc(nn) != QC_OK) return QC_ERR_HIP;
     if (st->Gb[0].alloc(nspin * nn) != QC_OK || st->Gb[1].alloc(nspin * nn) != QC_OK || st->Cs.alloc(nspin * nn) != QC_OK || st->ws.alloc(nspin * n) != QC_OK) return QC_ERR_HIP;
     QC_HIP_CHECK(hipHostMalloc(&st->h_cancel, sizeof(unsigned), hipHostMallocDefault));
     *st->h_cancel = 0;
     std::vector<double> h_eht;
+    lap("state buffers");
     if ((rc = scf_setup(S, st->W, h_eht)) != QC_OK) return rc;           // rhf.rs:41-49
+    lap("S, T, V, X = S^-1/2");
     for (int s = 0; s < nspin; ++s)                                       // rhf.rs:50 / uhf.rs:60-63
         if ((rc = huckel_density(S, st->W, h_eht, st->nocc[s], uhf ? 1.0 : 2.0, st->D[s].p)) != QC_OK) return rc;
+    lap("Hueckel guess");
     if (S->fock_mode == 1) {
         // the reference's conventional SCF: ERI tensor once (rhf.rs:45), antisymmetrised copy (rhf.rs:58-62), dense
         // contraction per pass.  8 n^4 bytes per tensor; two of them live during the build.
@@ -803,10 +822,10 @@ static int scf_iterate(qc_scf_state *st, double *energy, double *rms_out, bool m
         QC_HIP_CHECK(hipEventRecord(ev0, sm));
         if (st->uhf) {   // uhf.rs:216-226: G_s = <I, D_s + D_s'> - <I^x, D_s>
             qc_axpby(sm, n, 1.0, st->D[0].p, 1.0, st->D[1].p, st->Dtot.p);
-            qc_axpby(sm, n, -1.0, st->D[0].p, 0.0, nullptr, W.t1.p);
-            qc_tensor_gemv(sm, n, st->T4.p, st->Dtot.p, st->TK.p, W.t1.p, Gcur);
-            qc_axpby(sm, n, -1.0, st->D[1].p, 0.0, nullptr, W.t1.p);
-            qc_tensor_gemv(sm, n, st->T4.p, st->Dtot.p, st->TK.p, W.t1.p, Gcur + nn);
+            qc_axpby(sm, n, -1.0, st->D[0].p, 0.0, nullptr, W.t1[0].p);
+            qc_tensor_gemv(sm, n, st->T4.p, st->Dtot.p, st->TK.p, W.t1[0].p, Gcur);
+            qc_axpby(sm, n, -1.0, st->D[1].p, 0.0, nullptr, W.t1[0].p);
+            qc_tensor_gemv(sm, n, st->T4.p, st->Dtot.p, st->TK.p, W.t1[0].p, Gcur + nn);
         } else {
             qc_tensor_gemv(sm, n, st->T4.p, st->D[0].p, nullptr, nullptr, Gcur);   // rhf.rs:152-167
         }
@@ -823,9 +842,24 @@ static int scf_iterate(qc_scf_state *st, double *energy, double *rms_out, bool m
     }
     scf_flush_timing(st);                                                 // (the previous pass's times, now that this pass's build is out)
     if (!spec_hit) QC_HIP_CHECK(hipEventRecord(ev1, sm));
-    if (!W.small_fused)
-        for (int s = 0; s < nspin; ++s)                                   // (the control words were cleared by the previous pass)
-            if ((rc = roothaan_enqueue(S, W, *st->diis[s], Gcur + s * nn, st->D[s].p, st->ws.p + s * n, st->Cs.p + s * nn, s, dE[s], dF[s], have_F)) != QC_OK) return rc;
+    // UHF: the two spins' steps are independent (uhf.rs:84-135 runs them one after the other) - the beta step goes to a side stream on
+    // another dispatch pipe, behind an event of the build's closing kernel, and meets the handle's stream again before the scalars
+    // (device-side join).  Same kernels, same arithmetic, per spin: results are bit for bit those of the serial order (QC_NO_SPIN_PARALLEL).
+    const bool spin_par = st->uhf && !W.small_fused && st->spin_parallel && S->nlanes >= 2 && !S->join_by_events;
+    if (!W.small_fused) {
+        hipStream_t side = spin_par ? qc_spin_fork(S) : nullptr;
+        if (spin_par && !side) return QC_ERR_HIP;
+        for (int s = 0; s < nspin; ++s) {                                 // (the control words were cleared by the previous pass)
+            const bool on_side = spin_par && s == 1;
+            if ((rc = roothaan_enqueue(S, W, *st->diis[s], Gcur + s * nn, st->D[s].p, st->ws.p + s * n, st->Cs.p + s * nn, s, dE[s], dF[s], have_F,
+                                       on_side ? side : sm, on_side ? 1 : 0)) != QC_OK) return rc;
+            if (on_side) {    // the beta density on the side stream as well; then the streams meet
+                if (st->nocc[s] > 0) qc_gemm(side, n, n, st->nocc[s], 1.0, st->Cs.p + s * nn, n, false, st->Cs.p + s * nn, n, true, 0.0, st->Dn[s].p, n);
+                else QC_HIP_CHECK(hipMemsetAsync(st->Dn[s].p, 0, nn * sizeof(double), side));
+            }
+        }
+        if (spin_par && (rc = qc_spin_join(S)) != QC_OK) return rc;
+    }
     int *h_ctl = reinterpret_cast<int *>(W.h_scal + 4);
     // Multi-rank runs take every decision (convergence, DIIS failure, eigensolve mode, repeat) from the SAME numbers on every
     // rank: the pass scalars go to device memory, are all-reduced as bit patterns (max) together with their complements - so a
@@ -835,8 +869,10 @@ static int scf_iterate(qc_scf_state *st, double *energy, double *rms_out, bool m
     const bool multi = S->comm != nullptr;
     double *scal_out = multi ? reinterpret_cast<double *>(W.d_sync) : W.h_scal;
     int *ctl_out = multi ? reinterpret_cast<int *>(W.d_sync + 4) : h_ctl;
+    bool dens_done[2] = {false, spin_par};                               // (the beta density of a spin-parallel pass was formed on the side stream)
     auto density_and_scalars = [&](int s, bool hand_over) -> int {
-        if (st->nocc[s] > 0) qc_gemm(sm, n, n, st->nocc[s], st->uhf ? 1.0 : 2.0, st->Cs.p + s * nn, n, false, st->Cs.p + s * nn, n, true, 0.0, st->Dn[s].p, n);
+        if (dens_done[s]) dens_done[s] = false;                          // (once: a repeat of the eigensolve forms it again, here)
+        else if (st->nocc[s] > 0) qc_gemm(sm, n, n, st->nocc[s], st->uhf ? 1.0 : 2.0, st->Cs.p + s * nn, n, false, st->Cs.p + s * nn, n, true, 0.0, st->Dn[s].p, n);
         else QC_HIP_CHECK(hipMemsetAsync(st->Dn[s].p, 0, nn * sizeof(double), sm));
         // energy and rms straight into pinned host memory; the last spin's kernel also hands over and clears the control words
         qc_energy_rms(sm, n, st->Dn[s].p, st->D[s].p, W.H.p, Gcur + s * nn, scal_out + 2 * s, hand_over ? W.ctl : nullptr, ctl_out);
@@ -1081,13 +1117,13 @@ int qc_scf_spin_square(qc_scf_state *st, double *s2) {
     ScfWork &W = st->W;
     const int n = S->nbasis;
     hipStream_t sm = S->stream;
-    qc_gemm(sm, n, n, n, 1.0, st->D[0].p, n, false, W.S.p, n, false, 0.0, W.t1.p, n);      // D_alpha S
-    qc_gemm(sm, n, n, n, 1.0, st->D[1].p, n, false, W.S.p, n, false, 0.0, W.t2.p, n);      // D_beta S
+    qc_gemm(sm, n, n, n, 1.0, st->D[0].p, n, false, W.S.p, n, false, 0.0, W.t1[0].p, n);      // D_alpha S
+    qc_gemm(sm, n, n, n, 1.0, st->D[1].p, n, false, W.S.p, n, false, 0.0, W.t2[0].p, n);      // D_beta S
     // tr(A B) = sum_ij A_ij B_ji: one dot product of A with B^T - reuse the DIIS dot kernel on (A, B^T)
-    qc_sub_transpose(sm, n, W.t2.p, W.t3.p);                                                // t3 = B - B^T
-    qc_axpby(sm, n, 1.0, W.t2.p, -1.0, W.t3.p, W.t4.p);                                    // t4 = B^T
-    const double *ys[1] = {W.t4.p};
-    qc_dots(sm, n, W.t1.p, ys, 1, W.scal.p);
+    qc_sub_transpose(sm, n, W.t2[0].p, W.t3[0].p);                                                // t3 = B - B^T
+    qc_axpby(sm, n, 1.0, W.t2[0].p, -1.0, W.t3[0].p, W.t4[0].p);                                    // t4 = B^T
+    const double *ys[1] = {W.t4[0].p};
+    qc_dots(sm, n, W.t1[0].p, ys, 1, W.scal.p);
     double tr = 0.0;
     QC_HIP_CHECK(hipMemcpyAsync(&tr, W.scal.p, sizeof(double), hipMemcpyDeviceToHost, sm));
     QC_HIP_CHECK(hipStreamSynchronize(sm));

@@ -176,6 +176,8 @@ static std::vector<int> qc_build_rplan() {
 
 static int qc_join_probe(qc_system *S, bool *concurrent);
 static int qc_lane_probe(qc_system *S);
+static bool qc_stream_pool_take(qc_system *S);
+static bool qc_stream_pool_give(qc_system *S);
 __global__ void qc_join_mark_kernel(unsigned *cnt);
 static void qc_gate_forget(qc_system *S);
 static void qc_issue_pool_drop(qc_system *S);
@@ -187,6 +189,10 @@ constexpr int QC_SEARCH_FIRST_BUILD = 24, QC_SEARCH_CHUNK = 6, QC_SEARCH_REJECTS
 int qc_device_init(qc_system *S) {
     if (S->device_ready) return QC_OK;
     if (qc_device_ready() != QC_OK) return QC_ERR_NO_DEVICE;
+    static const bool sdbg = getenv("QC_SETUP_DEBUG") != nullptr;
+    auto tnow = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    double tt = tnow();
+    auto lap = [&](const char *what) { if (sdbg) { const double t = tnow(); fprintf(stderr, "[setup] %-28s %.3f ms\n", what, t - tt); tt = t; } };
     QC_HIP_CHECK(hipGetDevice(&S->device));
     hipDeviceProp_t prop;
     QC_HIP_CHECK(hipGetDeviceProperties(&prop, S->device));
@@ -194,12 +200,19 @@ int qc_device_init(qc_system *S) {
         fprintf(stderr, "qchem_hip: device %d is %s, this library is built for gfx950 only\n", S->device, prop.gcnArchName);
         return QC_ERR_NO_DEVICE;
     }
-    if (!S->stream) { QC_HIP_CHECK(hipStreamCreateWithFlags(&S->stream, hipStreamNonBlocking)); S->own_stream = true; }
-    for (int i = 0; i < QC_NSTREAMS; ++i) {
-        QC_HIP_CHECK(hipStreamCreateWithFlags(&S->side[i], hipStreamNonBlocking));
-        QC_HIP_CHECK(hipEventCreateWithFlags(&S->ev_join[i], hipEventDisableTiming));
+    // (creating a stream costs ~2 ms - eight of them 17 ms, three times a whole 15-pass SCF of H2O/cc-pVTZ: a handle that goes away
+    // leaves its streams, events and measured dispatch lanes in a process-wide pool for the next one)
+    bool lanes_known = false;
+    if (!S->stream && qc_stream_pool_take(S)) lanes_known = true;
+    else {
+        if (!S->stream) { QC_HIP_CHECK(hipStreamCreateWithFlags(&S->stream, hipStreamNonBlocking)); S->own_stream = true; }
+        for (int i = 0; i < QC_NSTREAMS; ++i) {
+            QC_HIP_CHECK(hipStreamCreateWithFlags(&S->side[i], hipStreamNonBlocking));
+            QC_HIP_CHECK(hipEventCreateWithFlags(&S->ev_join[i], hipEventDisableTiming));
+        }
+        QC_HIP_CHECK(hipEventCreateWithFlags(&S->ev_fork, hipEventDisableTiming));
     }
-    QC_HIP_CHECK(hipEventCreateWithFlags(&S->ev_fork, hipEventDisableTiming));
+    lap("streams and events");
     const size_t nn = (size_t)S->nbasis * S->nbasis;
     QC_HIP_CHECK(hipMalloc(&S->d_pairdata, S->pairdata.size() * sizeof(double)));
     QC_HIP_CHECK(hipMemcpy(S->d_pairdata, S->pairdata.data(), S->pairdata.size() * sizeof(double), hipMemcpyHostToDevice));
@@ -209,6 +222,7 @@ int qc_device_init(qc_system *S) {
     QC_HIP_CHECK(hipMemcpy(S->d_pspack, S->pspack.data(), S->pspack.size() * sizeof(double), hipMemcpyHostToDevice));
     QC_HIP_CHECK(hipMalloc(&S->d_pairs, S->pairs.size() * sizeof(QcPairDesc)));
     QC_HIP_CHECK(hipMemcpy(S->d_pairs, S->pairs.data(), S->pairs.size() * sizeof(QcPairDesc), hipMemcpyHostToDevice));
+    lap("pair data upload");
     // rows: F_{L+j}(x_k) / j!, j = 0..7, per total order L; then exp(-x_k)
     std::vector<double> tab((size_t)(QC_LTOT + 1) * QC_BOYS_NGRID * 8 + QC_BOYS_NGRID), row(QC_BOYS_NORD);
     for (int k = 0; k < QC_BOYS_NGRID; ++k) {
@@ -219,6 +233,7 @@ int qc_device_init(qc_system *S) {
         }
         tab[(size_t)(QC_LTOT + 1) * QC_BOYS_NGRID * 8 + k] = std::exp(-k * QC_BOYS_DX);
     }
+    lap("Boys tables on the host");
     QC_HIP_CHECK(hipMalloc(&S->d_boys, tab.size() * sizeof(double)));
     QC_HIP_CHECK(hipMemcpy(S->d_boys, tab.data(), tab.size() * sizeof(double), hipMemcpyHostToDevice));
     {
@@ -235,10 +250,12 @@ int qc_device_init(qc_system *S) {
     QC_HIP_CHECK(hipMalloc(&S->d_Gred, (size_t)2 * 2 * nn * sizeof(double)));
     QC_HIP_CHECK(hipMalloc(&S->d_Dj, nn * sizeof(double)));
     QC_HIP_CHECK(hipMalloc(&S->d_flag, 4 * sizeof(int)));
-    QC_HIP_CHECK(hipMalloc(&S->d_join, 4 * sizeof(unsigned)));
-    QC_HIP_CHECK(hipMemset(S->d_join, 0, 4 * sizeof(unsigned)));
+    QC_HIP_CHECK(hipMalloc(&S->d_join, 8 * sizeof(unsigned)));
+    QC_HIP_CHECK(hipMemset(S->d_join, 0, 8 * sizeof(unsigned)));
+    S->spin_target = 0;
     QC_HIP_CHECK(hipHostMalloc(&S->h_join_timeout, 4 * sizeof(int), hipHostMallocDefault));
     *S->h_join_timeout = 0; S->join_target = 0;
+    lap("tables, buffers");
     {
         bool concurrent = true;
         int prc = qc_join_probe(S, &concurrent);
@@ -246,14 +263,18 @@ int qc_device_init(qc_system *S) {
         S->join_by_events = !concurrent || getenv("QC_EVENT_JOIN") != nullptr;      // (A/B switch, read per handle: the event join of rounds 1-2)
         S->issue_threads = getenv("QC_ISSUE_THREADS") ? atoi(getenv("QC_ISSUE_THREADS")) : -1;    // (0: never; n: always n helpers; read per handle)
         if (!concurrent && getenv("QC_SCF_DEBUG")) fprintf(stderr, "qchem_hip: kernels of different streams do not run concurrently here (profiler counters?): event join\n");
-        if (concurrent) { prc = qc_lane_probe(S); if (prc != QC_OK) return prc; }
+        if (concurrent && !lanes_known) { prc = qc_lane_probe(S); if (prc != QC_OK) return prc; S->lanes_probed = getenv("QC_NO_LANES") == nullptr; }
     }
+    lap("join + lane probes");
     QC_HIP_CHECK(hipMalloc(&S->d_fxs, 2 * sizeof(double)));
     // Schwarz factors of the pairs (once per geometry), then the screened work lists
     int rc = qc_schwarz_device(S);
     if (rc != QC_OK) return rc;
+    lap("Schwarz pass");
     qc_build_shards(S);
+    lap("work lists");
     if ((rc = upload_slots(S)) != QC_OK) return rc;
+    lap("upload");
     S->device_ready = true;
     return QC_OK;
 }
@@ -275,15 +296,16 @@ void qc_device_free(qc_system *S) {
     if (S->h_join_timeout) { (void)hipHostFree(S->h_join_timeout); S->h_join_timeout = nullptr; }
     for (void *p : ptrs) if (p) (void)hipFree(p);
     S->d_shells = nullptr; S->d_pairdata = S->d_pairdataT = S->d_pspack = nullptr; S->d_pairs = nullptr; S->d_rplan = nullptr; S->d_gidx = nullptr; S->d_boys = S->d_D = S->d_G = S->d_Gtmp = S->d_Gred = S->d_Dj = nullptr;
-    for (int i = 0; i < QC_NSTREAMS; ++i) {
-        if (S->side[i]) (void)hipStreamDestroy(S->side[i]);
-        if (S->ev_join[i]) (void)hipEventDestroy(S->ev_join[i]);
-        S->side[i] = nullptr; S->ev_join[i] = nullptr;
+    if (!qc_stream_pool_give(S)) {
+        for (int i = 0; i < QC_NSTREAMS; ++i) {
+            if (S->side[i]) (void)hipStreamDestroy(S->side[i]);
+            if (S->ev_join[i]) (void)hipEventDestroy(S->ev_join[i]);
+        }
+        if (S->ev_fork) (void)hipEventDestroy(S->ev_fork);
+        if (S->own_stream && S->stream) (void)hipStreamDestroy(S->stream);
     }
-    if (S->ev_fork) (void)hipEventDestroy(S->ev_fork);
+    for (int i = 0; i < QC_NSTREAMS; ++i) { S->side[i] = nullptr; S->ev_join[i] = nullptr; }
     S->ev_fork = nullptr;
-
-    if (S->own_stream && S->stream) (void)hipStreamDestroy(S->stream);
     S->stream = nullptr; S->own_stream = false; S->device_ready = false;
 }
 
@@ -358,6 +380,45 @@ struct QcIssuePool {
 
 static void qc_issue_pool_drop(qc_system *S) { delete S->issue_pool; S->issue_pool = nullptr; }
 
+// ---- Pool of stream sets (the handle's own stream, the side streams, their events, the dispatch lanes measured on them)
+struct QcStreamSet {
+    int device; hipStream_t main, side[QC_NSTREAMS]; hipEvent_t ev_fork, ev_join[QC_NSTREAMS];
+    int slot_side[QC_NSTREAMS], nlanes; bool lane0_is_main;
+};
+struct QcStreamPool { std::mutex mu; std::vector<QcStreamSet> sets; };
+static QcStreamPool &qc_stream_pool() { static QcStreamPool *p = new QcStreamPool(); return *p; }     // (never destroyed: the runtime may be gone by then)
+static bool qc_stream_pool_take(qc_system *S) {
+    if (getenv("QC_NO_STREAM_POOL") || getenv("QC_NO_LANES")) return false;
+    QcStreamPool &P = qc_stream_pool();
+    std::lock_guard<std::mutex> lk(P.mu);
+    for (size_t i = 0; i < P.sets.size(); ++i) {
+        if (P.sets[i].device != S->device) continue;
+        const QcStreamSet t = P.sets[i];
+        P.sets.erase(P.sets.begin() + i);
+        S->stream = t.main; S->own_stream = true; S->ev_fork = t.ev_fork;
+        for (int k = 0; k < QC_NSTREAMS; ++k) { S->side[k] = t.side[k]; S->ev_join[k] = t.ev_join[k]; S->slot_side[k] = t.slot_side[k]; }
+        S->nlanes = t.nlanes; S->lane0_is_main = t.lane0_is_main; S->lanes_probed = true;
+        return true;
+    }
+    return false;
+}
+// (only complete sets whose lanes were measured with the handle's OWN stream; everything on them has been waited for)
+static bool qc_stream_pool_give(qc_system *S) {
+    if (getenv("QC_NO_STREAM_POOL") || !S->own_stream || !S->stream || !S->lanes_probed || !S->ev_fork) return false;
+    for (int k = 0; k < QC_NSTREAMS; ++k) if (!S->side[k] || !S->ev_join[k]) return false;
+    if (hipStreamSynchronize(S->stream) != hipSuccess) return false;
+    for (int k = 0; k < QC_NSTREAMS; ++k) if (hipStreamSynchronize(S->side[k]) != hipSuccess) return false;
+    QcStreamPool &P = qc_stream_pool();
+    std::lock_guard<std::mutex> lk(P.mu);
+    if (P.sets.size() >= 8) return false;
+    QcStreamSet t{};
+    t.device = S->device; t.main = S->stream; t.ev_fork = S->ev_fork;
+    for (int k = 0; k < QC_NSTREAMS; ++k) { t.side[k] = S->side[k]; t.ev_join[k] = S->ev_join[k]; t.slot_side[k] = S->slot_side[k]; }
+    t.nlanes = S->nlanes; t.lane0_is_main = S->lane0_is_main;
+    P.sets.push_back(t);
+    return true;
+}
+
 // ---- Dispatch lanes.  Measured on MI355X (tools/probes/pipe_probe.hip): with GPU_MAX_HW_QUEUES=8, eight HIP streams land on eight hardware
 // queues that sit in PAIRS on four dispatch pipes, and a pipe works on one dispatch packet until every workgroup of that grid has been
 // launched - a one-workgroup kernel on stream j completes in 12 us while a grid of 8192 workgroups dispatches on an unrelated stream, and
@@ -386,13 +447,14 @@ static int qc_lane_probe(qc_system *S) {
     for (int k = 0; k < QC_NSTREAMS; ++k) mark(S->side[k]);
     QC_HIP_CHECK(hipDeviceSynchronize());
     double d_alone = 1e30;
-    for (int rep = 0; rep < 2; ++rep) {
+    {
         const auto t0 = clk::now();
         busy(S->stream);
         QC_HIP_CHECK(hipStreamSynchronize(S->stream));
-        d_alone = std::min(d_alone, us(t0, clk::now()));
+        d_alone = us(t0, clk::now());
     }
     // coupled(x, y): a marker on y waits for the grid on x
+    // (one measurement; a positive is measured again - a hiccup of the host must not merge two lanes)
     auto coupled = [&](hipStream_t x, hipStream_t y, bool *out) -> int {
         double lat = 1e30;
         for (int rep = 0; rep < 2; ++rep) {
@@ -402,6 +464,7 @@ static int qc_lane_probe(qc_system *S) {
             QC_HIP_CHECK(hipStreamSynchronize(y));
             lat = std::min(lat, us(t1, clk::now()));
             QC_HIP_CHECK(hipStreamSynchronize(x));
+            if (lat <= 0.5 * d_alone) break;
         }
         *out = lat > 0.5 * d_alone;
         return QC_OK;
@@ -560,6 +623,23 @@ static void qc_gate_forget(qc_system *S) {          // the handle goes away
     S->waits_in_flight = false;
 }
 
+hipStream_t qc_spin_fork(qc_system *S) {
+    QcGateHold gate(S);
+    hipStream_t side = S->side[S->slot_side[S->lane0_is_main ? 1 : 0]];
+    if (hipEventRecord(S->ev_fork, S->stream) != hipSuccess || hipStreamWaitEvent(side, S->ev_fork, 0) != hipSuccess) return nullptr;
+    return side;
+}
+int qc_spin_join(qc_system *S) {
+    QcGateHold gate(S);
+    hipStream_t side = S->side[S->slot_side[S->lane0_is_main ? 1 : 0]];
+    S->spin_target += 1;
+    S->wait_limit = qc_wait_limit(S);
+    hipLaunchKernelGGL(qc_join_mark_kernel, dim3(1), dim3(64), 0, side, S->d_join + 4);
+    hipLaunchKernelGGL(qc_join_wait_kernel, dim3(1), dim3(64), 0, S->stream, S->d_join + 4, S->spin_target, S->h_join_timeout, S->wait_limit, 0);
+    gate.waits = true;
+    return hipGetLastError() == hipSuccess ? QC_OK : QC_ERR_HIP;
+}
+
 // After a host wait that follows a device-joined build: did one of its waits give up?  Then the matrix it folded was not complete: the
 // call fails (last_error says why), the accumulator planes are no longer known to be clean, the counter and the host's target meet
 // again, and this handle joins through events from now on.
@@ -569,8 +649,8 @@ int qc_join_check(qc_system *S) {
                     "this handle joins its streams through events from now on";
     fprintf(stderr, "qchem_hip: %s\n", S->last_error.c_str());
     (void)hipDeviceSynchronize();
-    unsigned c[3] = {0, 0, 0};
-    if (hipMemcpy(c, S->d_join, sizeof(c), hipMemcpyDeviceToHost) == hipSuccess) { S->join_target = c[0]; S->fork_seq = std::max(S->fork_seq, c[1]); }
+    unsigned c[5] = {0, 0, 0, 0, 0};
+    if (hipMemcpy(c, S->d_join, sizeof(c), hipMemcpyDeviceToHost) == hipSuccess) { S->join_target = c[0]; S->fork_seq = std::max(S->fork_seq, c[1]); S->spin_target = c[4]; }
     __atomic_store_n(S->h_join_timeout, 0, __ATOMIC_RELEASE);
     S->join_by_events = true;
     S->gt_clean = false; S->prepared = false; S->spec.pending = false;

@@ -155,7 +155,9 @@ struct qc_system {
     int slot_side[QC_NSTREAMS] = {0, 1, 2, 3, 4, 5, 6};
     int nlanes = QC_NSTREAMS;
     bool lane0_is_main = false;
+    bool lanes_probed = false;               // slot_side / nlanes were measured on this handle's own stream set (qc_lane_probe)
     hipEvent_t ev_fork = nullptr, ev_join[QC_NSTREAMS] = {};
+    unsigned spin_target = 0;                // join counter of the spin-parallel Roothaan steps (d_join[4])
     double *d_pairdata = nullptr, *d_pairdataT = nullptr, *d_pspack = nullptr;
     void *d_shells = nullptr;                // shells / primitives / transforms / nuclei for the one-electron kernels (one blob)
     size_t shell_blob_off[5] = {};
@@ -270,6 +272,10 @@ void qc_fock_feedback(qc_system *S, float build_ms, unsigned gen);
 bool qc_fock_can_speculate(const qc_system *S);            // the next build may be issued with a device-side fork (tuned, device join, fixed point)
 void qc_spec_release(hipStream_t st, unsigned *words, unsigned seq, const double *scal, int n, int nspin, double eps, unsigned *h_cancel,
                      unsigned *h_seq, unsigned seqval);
+// the beta step of a UHF pass on a side stream (another dispatch pipe than the handle's): fork = that stream, made to wait for what the
+// handle's stream holds so far; join = the handle's stream waits for it (marker + waiting kernel, under the per-device gate)
+hipStream_t qc_spin_fork(qc_system *S);
+int qc_spin_join(qc_system *S);
 int qc_join_check(qc_system *S);                           // after a host wait: QC_ERR_HIP if a device-side wait of the handle gave up
 void qc_gate_quiet(qc_system *S);                          // the host has seen the handle's stream drained: none of its waits is in flight
 // (scale_done: the fixed-point unit of these densities is already in d_fxs - written by the kernel that produced them)
@@ -368,6 +374,7 @@ struct QcSmallArgs {
     const double *D, *S, *X, *H, *G;
     double *E_out;                 // the pass's DIIS error slot
     int m, minlen, maxlen;         // DIIS window length (newest first), Diis::new(minlen, maxlen)
+    int dots_generic;              // the DIIS dot products in the summation order of qc_dots_kernel (open-shell runs: bit-identical trajectories)
     int slot[12];
     const double *errs[12], *focks[12];
     double *Bmat, *c_out;          // B (slot-indexed, maxlen x maxlen) and the coefficients, in HBM

@@ -25,7 +25,7 @@ namespace {
 
 constexpr int QCS_T = 256, QCS_W = QCS_T / 64, QCS_E = 16;           // threads, waves, matrix elements per thread (rows rr + 4 q)
 constexpr int QCS_LD = 66, QCS_BUF = 64 * QCS_LD;                    // leading dimension and doubles of a matrix buffer
-constexpr int QCS_SMALL_DOUBLES = 64 /*lam*/ + QCS_W * 12 /*red*/ + 12 /*dots*/ + 12 /*c*/ + 144 /*B*/ + 8 /*scalars*/;
+constexpr int QCS_SMALL_DOUBLES = 64 /*lam*/ + QCS_W * 12 /*red*/ + 12 /*dots*/ + 12 /*c*/ + 144 /*B*/ + 8 /*scalars*/ + 12 * 16 /*wave sums of the generic-order dots*/;
 constexpr int QCS_SMALL_INTS = 64 /*partner*/ + 64 /*rank*/ + 16 /*flags*/;
 
 __device__ __forceinline__ double qcs_readlane(double v, int lane) {
@@ -172,8 +172,8 @@ __global__ __launch_bounds__(QCS_T) void qc_scf_small_kernel(const QcSmallArgs a
     const int n = a.n;
     double *B0 = lds, *B1 = lds + BUF, *B2 = lds + 2 * BUF, *B3 = lds + 3 * BUF;
     double *sm = lds + 4 * BUF;
-    double *lam = sm, *red = lam + 64, *dots = red + QCS_W * 12, *cvec = dots + 12, *Bl = cvec + 12, *scal = Bl + 144;
-    int *partner = reinterpret_cast<int *>(scal + 8), *rank_s = partner + 64, *flg = rank_s + 64;
+    double *lam = sm, *red = lam + 64, *dots = red + QCS_W * 12, *cvec = dots + 12, *Bl = cvec + 12, *scal = Bl + 144, *gsh = scal + 8;
+    int *partner = reinterpret_cast<int *>(gsh + 12 * 16), *rank_s = partner + 64, *flg = rank_s + 64;
     const int tid = threadIdx.x, rr = tid >> 6, cc = tid & 63;           // this thread's elements: rows rr + 4 q, column cc
     const bool cok = cc < n;
     bool ok = true;                                                      // (uniform) the eigenvectors for `post` exist
@@ -252,6 +252,40 @@ __global__ __launch_bounds__(QCS_T) void qc_scf_small_kernel(const QcSmallArgs a
                 }
             }
             qcs_block_sums<12>(part, a.m, red, dots);
+            if (a.dots_generic) {
+                // Open-shell runs: the dot products in the summation order of the generic launch sequence (qc_dots_kernel, qc_linalg.hip: 1024
+                // threads, thread t sums the elements t + 1024 u in ascending u, lanes by the shuffle tree, the sixteen wave sums in
+                // order).  The trajectories of such runs - crawls along saddles of the UHF functional, DESIGN.md 1 - depend on the last bit
+                // of these numbers, and the one that is pinned against the oracle is the generic sequence's.  The error matrix goes to a flat
+                // copy in B3 (free between the two products around here), the 1024 virtual threads are served in four rounds.
+                const int nn = n * n;
+                QCS_EACH(q, i) if (QCS_IN(i)) B3[i * n + cc] = e[q];
+                __syncthreads();
+                const int wave = qcs_wave(), lane = tid & 63;
+                for (int j = 0; j < a.m; ++j) {
+                    const double *__restrict__ yj = a.errs[j];
+                    for (int r = 0; r < 4; ++r) {
+                        const int t = r * QCS_T + tid;
+                        double av[4], bv[4];
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) { const int x = min(t + u * 1024, nn - 1); av[u] = B3[x]; bv[u] = j == 0 ? B3[x] : yj[x]; }
+                        double sgen = 0.0;
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) if (t + u * 1024 < nn) sgen = fma(av[u], bv[u], sgen);
+#pragma unroll
+                        for (int o = 32; o > 0; o >>= 1) sgen += __shfl_down(sgen, o, 64);
+                        if (lane == 0) gsh[j * 16 + r * QCS_W + wave] = sgen;
+                    }
+                }
+                __syncthreads();
+                if (tid < a.m) {
+                    double tsum = 0.0;
+                    for (int k = 0; k < 16; ++k) tsum += gsh[tid * 16 + k];
+                    dots[tid] = tsum;
+                }
+                for (int x = tid; x < BUF; x += QCS_T) B3[x] = 0.0;      // (the block's padding is zero for the rest of the kernel)
+                __syncthreads();
+            }
         }
         QCS_STAMP();
         // ---- DIIS coefficients by wave 0; the other three waves fetch X meanwhile.  The first three Fock matrices of the combination are

@@ -612,6 +612,29 @@ def test_two_handles_from_two_threads(monkeypatch):
         h.close()
 
 
+@pytest.mark.parametrize("mol,basis,na,nb", [("oxygen", "cc-pVDZ", 9, 7), ("water", "cc-pVDZ", 0, 0), ("benzene", "6-31G_st_st", 0, 0)])
+def test_spin_parallel_roothaan_steps_do_not_change_a_bit(mol, basis, na, nb, monkeypatch):
+    """UHF passes on the generic launch sequence run the alpha and the beta Roothaan step side by side on two streams (scf_iterate).  Same
+    kernels and arithmetic per spin: every pass - energy, rms, and at the end the orbital energies - is bit for bit the serial order's
+    (QC_NO_SPIN_PARALLEL), also for the O2 triplet, whose trajectory forgives nothing."""
+    import qchem_rs_amd as q
+    m = load_system(mol, basis)
+
+    def run():
+        s = q.System(m)
+        st = q.ScfStepper(s, uhf=True, n_alpha=na, n_beta=nb)
+        tr = [st.iterate() for _ in range(30)]
+        w = (st.orbital_energies(0), st.orbital_energies(1))
+        st.close(); s.close()
+        return tr, w
+
+    par, wp = run()
+    monkeypatch.setenv("QC_NO_SPIN_PARALLEL", "1")
+    ser, ws = run()
+    assert par == ser
+    assert np.array_equal(wp[0], ws[0]) and np.array_equal(wp[1], ws[1])
+
+
 def test_scf_runs_are_bitwise_reproducible():
     q, s, o = _sys("water", "cc-pVDZ")
     outs = [q.restricted_hartree_fock(s, q.HartreeFockConfig(100, 1e-10)) for _ in range(2)]
