@@ -26,6 +26,7 @@ pub struct QcHfOutput {
     pub ms_fock_total: f64,
     pub ms_linalg_total: f64,
     pub ms_total: f64,
+    pub ms_tuner: f64,
 }
 
 pub const QC_OK: c_int = 0;
@@ -56,6 +57,8 @@ extern "C" {
     pub fn qc_scf_orbital_energies(st: *mut QcScfState, spin: c_int, out: *mut f64) -> c_int;
     pub fn qc_scf_density(st: *mut QcScfState, spin: c_int, out: *mut f64) -> c_int;
     pub fn qc_scf_spin_square(st: *mut QcScfState, s2: *mut f64) -> c_int;
+    pub fn qc_scf_set_stop_rule(st: *mut QcScfState, epsilon: f64) -> c_int;
+    pub fn qc_scf_counters(st: *mut QcScfState, out: *mut f64, n: c_int) -> c_int;
     pub fn qc_scf_end(st: *mut QcScfState);
     pub fn qc_set_fock_mode(sys: *mut QcSystem, mode: c_int) -> c_int;
     /// 1 (default): exact, order-independent accumulation of G; 0: f64 atomics.

@@ -1115,7 +1115,18 @@ int qc_launch_fock_classes(qc_system *S, const QcFockArgs &fa, float *class_ms, 
         }
         S->unit_stream = o.best;
         S->assign_gen += 1; S->tune_count += 1;             // (this build carries extra builds: not a timing sample)
-        if (o.frozen) { qc_assign_cache_store(S); if (dbg) fprintf(stderr, "[tune] search ends after %d trials (%ld extra builds): %.4f ms\n", o.trials, (long)o.spent, o.base_ms); }
+        if (o.frozen) {
+            qc_assign_cache_store(S);
+            if (dbg) {
+                fprintf(stderr, "[tune] search ends after %d trials (%ld extra builds): %.4f ms; lanes:", o.trials, (long)o.spent, o.base_ms);
+                for (int k = 0; k < QC_NSTREAMS; ++k) {
+                    bool any = false;
+                    for (size_t u = 0; u < units.size(); ++u) if (!units[u].empty() && o.best[u] == k) { fprintf(stderr, "%s u%zu(%.0f)", any ? "" : " [", u, S->unit_ms[u] * 1e3); any = true; }
+                    if (any) fprintf(stderr, " ]");
+                }
+                fprintf(stderr, "\n");
+            }
+        }
         QC_HIP_CHECK(hipMemsetAsync(fa.G0, 0, gbytes, S->stream));
         nofork = false;
     }

@@ -4,7 +4,7 @@
 # Then, in the SAME invocation: the summaries (tools/make_profile_summary.py -> profiles/<tag>_*) and the default `python bench.py` line,
 # which quotes its HBM traffic from the PMC summary just written - so the two cannot disagree.  Everything lands under
 # gpurun_out/prof_<tag>/ (profiles/ of the box copy is mirrored into gpurun_out/prof_<tag>/profiles/ for the way back).
-TAG=${1:-r03}
+TAG=${1:-r04}
 R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/prof_$TAG
 mkdir -p $O
