@@ -860,7 +860,7 @@ int qc_launch_fock_classes(qc_system *S, const QcFockArgs &fa, float *class_ms, 
     // (`head_start`, ms: stream 0 is given that much more work than the others.  The most loaded stream becomes the handle's own stream,
     // and a build that ends on the handle's stream goes straight on to the fold, while one that ends on a side stream first pays the
     // cross-queue signal - event packet, barrier packets, ~20 us on the H2O/cc-pVTZ trace.)
-    auto lpt = [&](const std::vector<float> &w, int nstreams, float head_start = 0.f) {
+    auto lpt = [&](const std::vector<float> &w, int nstreams, float head_start = 0.f, bool bm_on_second = false) {
         nstreams = std::min(nstreams, S->nlanes);              // (slots beyond the dispatch lanes share a pipe with an earlier one)
         std::vector<int> ord;
         for (size_t u = 0; u < units.size(); ++u) if (!units[u].empty()) ord.push_back((int)u);
@@ -868,7 +868,16 @@ int qc_launch_fock_classes(qc_system *S, const QcFockArgs &fa, float *class_ms, 
         std::vector<float> load(nstreams, 0.f);
         load[0] = -head_start;
         S->unit_stream.assign(units.size(), 0);
+        // (bm_on_second: the bra-major launches - persistent grids that are dispatched at once and do not hold their pipe - on the SECOND
+        // streams of the pipes, every one its own chain, next to the column launches on the lanes.  H2O/cc-pVTZ without any search:
+        // 0.341 against 0.350 ms per iteration, benzene 1.730 against 1.718; as a proposal of the search, with moves onto the second
+        // streams allowed, the search ended on assignments that were fast back to back and slow inside SCF passes (0.199 ms builds
+        // against 0.192) and found nothing for benzene.  QC_BM_PAIRED keeps the experiment.)
+        static const bool bm_env = getenv("QC_BM_PAIRED") != nullptr;
+        const bool bm_paired = bm_on_second || bm_env;
+        int nextb = S->nlanes;
         for (int u : ord) {
+            if (bm_paired && u >= 2 * (QC_LPAIR + 1) && S->nlanes == nstreams && nextb < QC_NSTREAMS) { S->unit_stream[u] = nextb++; continue; }
             const int k = (int)(std::min_element(load.begin(), load.end()) - load.begin());
             S->unit_stream[u] = k;
             load[k] += w[u];
@@ -1200,6 +1209,10 @@ template <class T> struct QcTmpDev {
 // class kernels in their `schwarz_out` mode - unsplit slots / one-ket bundles, serial launches, once per geometry.
 int qc_schwarz_device(qc_system *S) {
     const size_t np = S->pairs.size();
+    // (the classes' launches are serial on the handle's stream and independent of the host: their temporary lists stay alive in `keep`
+    // and ONE wait ends the pass - a wait per class made it 4 ms for H2O/cc-pVTZ, most of a cold handle's set-up)
+    struct Keep { std::vector<void *> p; ~Keep() { for (void *x : p) if (x) (void)hipFree(x); } } keep;
+    auto keep_alloc = [&](size_t bytes, void **out) -> hipError_t { hipError_t e = hipMalloc(out, bytes); if (e == hipSuccess) keep.p.push_back(*out); return e; };
     QcTmpDev<double> dq;
     QC_HIP_CHECK(dq.alloc(np));
     double *const d_q = dq.p;
@@ -1218,38 +1231,36 @@ int qc_schwarz_device(qc_system *S) {
             QcClass cc;
             cc.LAB = c.LAB; cc.LCD = c.LCD; cc.LGC = c.col_lgc; cc.slot_words = c.col_slot_words; cc.lds_bytes = c.col_lds_bytes;
             qc_make_slots(S, diag, 0, false, slots);
-            QcTmpDev<QcSlot> d;
-            QC_HIP_CHECK(d.alloc(slots.size()));
-            QC_HIP_CHECK(hipMemcpyAsync(d.p, slots.data(), slots.size() * sizeof(QcSlot), hipMemcpyHostToDevice, S->stream));
-            int rc = launch_segments(S, qc_unit_of(cc.LAB, cc.LCD, false), {Seg{&cc, d.p, (int)slots.size()}}, S->stream, a);
-            QC_HIP_CHECK(hipStreamSynchronize(S->stream));
-            if (rc != QC_OK) return rc;
+            QcSlot *dsl = nullptr;
+            QC_HIP_CHECK(keep_alloc(slots.size() * sizeof(QcSlot), (void **)&dsl));
+            QC_HIP_CHECK(hipMemcpy(dsl, slots.data(), slots.size() * sizeof(QcSlot), hipMemcpyHostToDevice));
+            int rc = launch_segments(S, qc_unit_of(cc.LAB, cc.LCD, false), {Seg{&cc, dsl, (int)slots.size()}}, S->stream, a);
+            if (rc != QC_OK) { (void)hipStreamSynchronize(S->stream); return rc; }
             continue;
         }
         if (c.bm) {
             const bool packed = qc_make_bundles(S, diag, 0, bundles, ketlist);
-            QcTmpDev<QcBundleDev> db; QcTmpDev<QcKetUnit> dk;
+            QcBundleDev *db = nullptr; QcKetUnit *dk = nullptr;
             std::vector<QcBundleDev> hb; std::vector<QcKetUnit> hu;
             qc_bm_device_lists(S, c.LCD, bundles, ketlist, packed, hb, hu);
-            QC_HIP_CHECK(db.alloc(hb.size()));
-            QC_HIP_CHECK(dk.alloc(hu.size()));
-            QC_HIP_CHECK(hipMemcpyAsync(db.p, hb.data(), hb.size() * sizeof(QcBundleDev), hipMemcpyHostToDevice, S->stream));
-            QC_HIP_CHECK(hipMemcpyAsync(dk.p, hu.data(), hu.size() * sizeof(QcKetUnit), hipMemcpyHostToDevice, S->stream));
+            QC_HIP_CHECK(keep_alloc(hb.size() * sizeof(QcBundleDev), (void **)&db));
+            QC_HIP_CHECK(keep_alloc(hu.size() * sizeof(QcKetUnit), (void **)&dk));
+            QC_HIP_CHECK(hipMemcpy(db, hb.data(), hb.size() * sizeof(QcBundleDev), hipMemcpyHostToDevice));
+            QC_HIP_CHECK(hipMemcpy(dk, hu.data(), hu.size() * sizeof(QcKetUnit), hipMemcpyHostToDevice));
             int mx = 0;
             for (const auto &t : diag) mx = std::max(mx, qc_bm_wave_words(c.LAB, S->pairs[t.bra].na * S->pairs[t.bra].nb, S->pairs[t.ket].na * S->pairs[t.ket].nb));
-            int rc = launch_segments(S, qc_unit_of(c.LAB, c.LCD, true), {Seg{&c, nullptr, (int)bundles.size(), db.p, dk.p, mx * 8}}, S->stream, a);
-            QC_HIP_CHECK(hipStreamSynchronize(S->stream));
-            if (rc != QC_OK) return rc;
+            int rc = launch_segments(S, qc_unit_of(c.LAB, c.LCD, true), {Seg{&c, nullptr, (int)bundles.size(), db, dk, mx * 8}}, S->stream, a);
+            if (rc != QC_OK) { (void)hipStreamSynchronize(S->stream); return rc; }
             continue;
         }
         qc_make_slots(S, diag, 0, false, slots);
-        QcTmpDev<QcSlot> d;
-        QC_HIP_CHECK(d.alloc(slots.size()));
-        QC_HIP_CHECK(hipMemcpyAsync(d.p, slots.data(), slots.size() * sizeof(QcSlot), hipMemcpyHostToDevice, S->stream));
-        int rc = launch_segments(S, qc_unit_of(c.LAB, c.LCD, false), {Seg{&c, d.p, (int)slots.size()}}, S->stream, a);
-        QC_HIP_CHECK(hipStreamSynchronize(S->stream));
-        if (rc != QC_OK) return rc;
+        QcSlot *dsl = nullptr;
+        QC_HIP_CHECK(keep_alloc(slots.size() * sizeof(QcSlot), (void **)&dsl));
+        QC_HIP_CHECK(hipMemcpy(dsl, slots.data(), slots.size() * sizeof(QcSlot), hipMemcpyHostToDevice));
+        int rc = launch_segments(S, qc_unit_of(c.LAB, c.LCD, false), {Seg{&c, dsl, (int)slots.size()}}, S->stream, a);
+        if (rc != QC_OK) { (void)hipStreamSynchronize(S->stream); return rc; }
     }
+    QC_HIP_CHECK(hipStreamSynchronize(S->stream));
     S->pairQ.assign(np, 0.0);
     QC_HIP_CHECK(hipMemcpy(S->pairQ.data(), d_q, np * sizeof(double), hipMemcpyDeviceToHost));
     S->imax = 0.0;

@@ -129,6 +129,9 @@ __device__ __forceinline__ void qc_step2_pp(double (&W)[3][qc_nherm(LAB)], const
 // primitive loop (`hd` carries them from pass to pass); the first ket record is loaded once per bundle (`hk0`, `ek0`); the rows of
 // step 3 come in pieces of QC_BM_PIECE scalars, each requested while the previous one is being used.
 constexpr int QC_BM_PIECE = 10;
+#ifndef QC_BM_AHEAD
+#define QC_BM_AHEAD 1
+#endif
 template <int LAB, int LCD, int NIJ, int CAX = 0>
 __device__ __forceinline__ void qc_bm_pass(const double *__restrict__ pd, const double *__restrict__ pdT, const double *__restrict__ Tb,
                                            const int bdoff, const int strideB, const int ij, const int ij_last, const int nab,
@@ -169,23 +172,24 @@ __device__ __forceinline__ void qc_bm_pass(const double *__restrict__ pd, const 
 #pragma unroll
         for (int k = 0; k < NV; ++k) est[k] = (k * 64 < ne) ? Eg[min(lane + k * 64, ne - 1)] : 0.0;
     }
-    // the next ket primitive's record is requested one iteration ahead.  ss kets: pair-data block [q, Q | E]; ps kets:
-    // packed record [q, Q | e0x, e0y, e0z, e1] (ketBase points into pspack, stride 8)
-    double4 hk = hk0;
-    double4 ekn4 = ek0, ekn4b = ek0b, ekn4c = ek0c;
-    double ekn = ek0.x;
-    for (int kl = 0; kl < maxK; ++kl) {
+    // The ket primitives' records are requested QC_BM_AHEAD iterations ahead (round 4).  ss kets: pair-data block [q, Q | E]; ps kets: packed
+    // record [q, Q | e0x, e0y, e0z, e1] (ketBase points into pspack, stride 8).  One iteration ahead - rounds 1-3 - left every iteration
+    // waiting for its record: per-wave phase timing (-DQC_BM_TIMING) shows 0.47-0.74 us per iteration for EVERY class, (ss|ss) with its
+    // 130 instructions per iteration as well as (pp|ps) with 217 - the latency of an L2 hit under load, not the arithmetic (0.15-0.3 us
+    // of issue).  The loop is unrolled by the depth so that the staged records rotate through fixed registers.
+    struct Rec { double4 h; double e; double4 e4, e4b, e4c; };
+    auto fetch = [&](const int kl) -> Rec {
+        Rec r{};
+        const double *__restrict__ kbn = ketBase + (size_t)min(kl, Kc1) * strideK;
+        r.h = *reinterpret_cast<const double4 *>(kbn);
+        if constexpr (LCD == 0) r.e = kbn[4];
+        else r.e4 = *reinterpret_cast<const double4 *>(kbn + 4);
+        if constexpr (LCD == 2) { r.e4b = *reinterpret_cast<const double4 *>(kbn + 8); r.e4c = *reinterpret_cast<const double4 *>(kbn + 12); }
+        return r;
+    };
+    auto step = [&](const int kl, const Rec &rc) {
         const bool valid = kl < K_cd;
-        const double4 ck = hk;
-        const double ek = ekn;
-        const double4 ek4 = ekn4, ek4b = ekn4b, ek4c = ekn4c;
-        {
-            const double *__restrict__ kbn = ketBase + (size_t)min(kl + 1, Kc1) * strideK;
-            hk = *reinterpret_cast<const double4 *>(kbn);
-            if constexpr (LCD == 0) ekn = kbn[4];
-            else ekn4 = *reinterpret_cast<const double4 *>(kbn + 4);
-            if constexpr (LCD == 2) { ekn4b = *reinterpret_cast<const double4 *>(kbn + 8); ekn4c = *reinterpret_cast<const double4 *>(kbn + 12); }
-        }
+        const double4 ck = rc.h;
         const double q = ck.x;
 #pragma unroll
         for (int u = 0; u < NIJ; ++u) {
@@ -197,23 +201,50 @@ __device__ __forceinline__ void qc_bm_pass(const double *__restrict__ pd, const 
             qc_rtab<L>(alpha, X, Y, Z, F, Rr);
             const double sc = valid ? pref : 0.0;
             if constexpr (LCD == 0) {
-                const double e = ek * sc;               // ss ket: a single Hermite function, W[h] += e R_h
+                const double e = rc.e * sc;               // ss ket: a single Hermite function, W[h] += e R_h
 #pragma unroll
                 for (int h = 0; h < qc_nherm(LAB); ++h) W[u][0][h] = fma(e, Rr[h], W[u][0][h]);
             } else if constexpr (LCD == 1) {
-                const double e0[3] = {ek4.x * sc, ek4.y * sc, ek4.z * sc};
-                qc_step2_ps<LAB>(W[u], e0, -(ek4.w * sc), Rr);
+                const double e0[3] = {rc.e4.x * sc, rc.e4.y * sc, rc.e4.z * sc};
+                qc_step2_ps<LAB>(W[u], e0, -(rc.e4.w * sc), Rr);
             } else {
-                // packed p.p record: ek4 = (A_x, A_y, A_z, kh), ek4b = (D_x, D_y, D_z, khh), ek4c = (hq A_x, hq A_y, hq A_z, -)
-                const double Ac = (CAX == 0 ? ek4.x : (CAX == 1 ? ek4.y : ek4.z)) * sc, hAc = (CAX == 0 ? ek4c.x : (CAX == 1 ? ek4c.y : ek4c.z)) * sc;
-                const double kh = ek4.w * sc;
-                const double c0[3] = {fma(Ac, ek4b.x, CAX == 0 ? kh : 0.0), fma(Ac, ek4b.y, CAX == 1 ? kh : 0.0), fma(Ac, ek4b.z, CAX == 2 ? kh : 0.0)};
-                const double cc[3] = {-(kh * ek4b.x), -(kh * ek4b.y), -(kh * ek4b.z)};
-                qc_step2_pp<LAB, CAX>(W[u], c0, cc, -hAc, ek4b.w * sc, Rr);
+                // packed p.p record: e4 = (A_x, A_y, A_z, kh), e4b = (D_x, D_y, D_z, khh), e4c = (hq A_x, hq A_y, hq A_z, -)
+                const double Ac = (CAX == 0 ? rc.e4.x : (CAX == 1 ? rc.e4.y : rc.e4.z)) * sc, hAc = (CAX == 0 ? rc.e4c.x : (CAX == 1 ? rc.e4c.y : rc.e4c.z)) * sc;
+                const double kh = rc.e4.w * sc;
+                const double c0[3] = {fma(Ac, rc.e4b.x, CAX == 0 ? kh : 0.0), fma(Ac, rc.e4b.y, CAX == 1 ? kh : 0.0), fma(Ac, rc.e4b.z, CAX == 2 ? kh : 0.0)};
+                const double cc[3] = {-(kh * rc.e4b.x), -(kh * rc.e4b.y), -(kh * rc.e4b.z)};
+                qc_step2_pp<LAB, CAX>(W[u], c0, cc, -hAc, rc.e4b.w * sc, Rr);
             }
+        }
+    };
+    Rec r0{};
+    r0.h = hk0; r0.e = ek0.x; r0.e4 = ek0; r0.e4b = ek0b; r0.e4c = ek0c;
+    // (p.p kets keep one record ahead: their 16-double records would push the kernel past 256 registers - one wave per SIMD)
+    constexpr int AHEAD = (LCD == 2) ? 1 : QC_BM_AHEAD;
+    if constexpr (AHEAD == 1) {
+        for (int kl = 0; kl < maxK; ++kl) {
+            const Rec cur = r0;
+            r0 = fetch(kl + 1);
+            step(kl, cur);
+        }
+    } else if constexpr (AHEAD == 2) {
+        Rec r1 = fetch(1);
+        for (int kl = 0; kl < maxK; kl += 2) {
+            { const Rec cur = r0; r0 = fetch(kl + 2); step(kl, cur); }
+            if (kl + 1 < maxK) { const Rec cur = r1; r1 = fetch(kl + 3); step(kl + 1, cur); }
+        }
+    } else {
+        Rec r1 = fetch(1), r2 = fetch(2);
+        for (int kl = 0; kl < maxK; kl += 3) {
+            { const Rec cur = r0; r0 = fetch(kl + 3); step(kl, cur); }
+            if (kl + 1 < maxK) { const Rec cur = r1; r1 = fetch(kl + 4); step(kl + 1, cur); }
+            if (kl + 2 < maxK) { const Rec cur = r2; r2 = fetch(kl + 5); step(kl + 2, cur); }
         }
     }
     QC_BT(1);
+#ifdef QC_BM_TIMING
+    tph[6] += maxK; tph[7] += 1;      // (iterations of the primitive loop, passes)
+#endif
     // step 3 with the wave-uniform bra blocks: I[ab][c] += sum_u sum_h E_ab,ij+u[ab][h] W[u][c][h]
     if constexpr (STAGE) {
         // High bras (HAB = 20 / 35, up to 36 function pairs): a row is 2-4 scalar pieces, and one piece ahead leaves the step bound by the
@@ -607,8 +638,8 @@ __device__ __forceinline__ void qc_bm_segment(const QcBmArgs &a, const int s, co
     }
 #ifdef QC_BM_TIMING
     if (lane == 0 && wave == 0 && wg < 2 && a.base.eri_out == nullptr && a.base.schwarz_out == nullptr)
-        printf("bm<%d,%d> seg wg %d: %d bundles (of %d)  setup %lld  k-loop %lld  step3 %lld  digestK %lld  digestJ %lld  flush %lld  [10 ns]\n", LAB, LCD, wg, nbun, nb,
-               tph[0], tph[1], tph[2], tph[3], tph[4], tph[5]);
+        printf("bm<%d,%d> seg wg %d: %d bundles (of %d)  setup %lld  k-loop %lld  step3 %lld  digestK %lld  digestJ %lld  flush %lld  [10 ns]  k-iterations %lld in %lld passes: %.0f ns per iteration\n", LAB, LCD, wg, nbun, nb,
+               tph[0], tph[1], tph[2], tph[3], tph[4], tph[5], tph[6], tph[7], tph[6] ? 10.0 * (double)tph[1] / (double)tph[6] : 0.0);
 #endif
 }
 
