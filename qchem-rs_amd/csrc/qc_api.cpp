@@ -1180,7 +1180,7 @@ int qc_scf_counters(qc_scf_state *st, double *out, int n) {
     scf_flush_timing(st);
     const double v[QC_SCF_NCOUNTERS] = {st->ms_setup, st->ms_fock, st->ms_linalg, (double)st->builds_timed, st->ms_tuner, (double)st->passes,
                                         (double)st->spec_hits, (double)st->spec_lost, (double)st->redos,
-                                        (double)st->S->on.trials, st->S->on.frozen ? 1.0 : 0.0};
+                                        (double)st->S->on.trials, st->S->on.settled ? 1.0 : 0.0};
     for (int i = 0; i < n && i < QC_SCF_NCOUNTERS; ++i) out[i] = v[i];
     return QC_OK;
 }

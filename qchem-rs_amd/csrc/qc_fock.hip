@@ -1109,8 +1109,14 @@ int qc_launch_fock_classes(qc_system *S, const QcFockArgs &fa, float *class_ms, 
             return false;
         };
         if (o.best.empty()) o.best = S->unit_stream;
+        auto note_top = [&](const std::vector<int> &a, float t) {
+            for (auto &e : o.top) if (e.second == a) { e.first = std::min(e.first, t); return; }
+            o.top.push_back({t, a});
+            std::sort(o.top.begin(), o.top.end(), [](const std::pair<float, std::vector<int>> &x, const std::pair<float, std::vector<int>> &y) { return x.first < y.first; });
+            if (o.top.size() > 3) o.top.resize(3);
+        };
         float tb = 0.f;
-        if (o.base_ms <= 0.0) { if ((rc = measure(o.best, tb)) != QC_OK) return rc; o.base_ms = tb; }
+        if (o.base_ms <= 0.0) { if ((rc = measure(o.best, tb)) != QC_OK) return rc; o.base_ms = tb; note_top(o.best, tb); }
         for (int k = 0; k < QC_SEARCH_CHUNK && !o.frozen; ++k) {
             if (!propose()) { o.frozen = true; break; }
             const bool seeded = !o.cands.empty();
@@ -1120,11 +1126,16 @@ int qc_launch_fock_classes(qc_system *S, const QcFockArgs &fa, float *class_ms, 
             if (dbg) fprintf(stderr, "[tune] trial %d (build %ld of the handle): %.4f ms against %.4f ms - %s\n", o.trials, (long)o.builds, t, o.base_ms, t < 0.985 * o.base_ms ? "kept" : "dropped");
             if (t < 0.985 * o.base_ms) { o.best = o.trial; o.base_ms = t; o.rejects = 0; }
             else if (!seeded) o.rejects += 1;
+            note_top(o.trial, t);
             if (o.rejects >= QC_SEARCH_REJECTS || o.trials >= QC_SEARCH_TRIALS) o.frozen = true;
         }
         S->unit_stream = o.best;
         S->assign_gen += 1; S->tune_count += 1;             // (this build carries extra builds: not a timing sample)
         if (o.frozen) {
+            // finals inside SCF passes (qc_fock_feedback) - not for multi-rank handles, whose passes report nothing
+            o.fin_sum.assign(o.top.size(), 0.0); o.fin_n.assign(o.top.size(), 0); o.fin_cur = 0;
+            if (S->comm || o.top.size() < 2) o.settled = true;
+            else { S->unit_stream = o.top[0].second; S->cand_skip = true; }
             qc_assign_cache_store(S);
             if (dbg) {
                 fprintf(stderr, "[tune] search ends after %d trials (%ld extra builds): %.4f ms; lanes:", o.trials, (long)o.spent, o.base_ms);
@@ -1153,7 +1164,7 @@ int qc_launch_fock_classes(qc_system *S, const QcFockArgs &fa, float *class_ms, 
 // the shape of the work lists.  The stream assignment does not change results (integer accumulation), only time.
 void qc_online_reset(qc_system *S, bool frozen) {
     S->on = qc_system::QcOnline{};
-    S->on.frozen = frozen;
+    S->on.frozen = frozen; S->on.settled = frozen;
     S->on.best = S->unit_stream;
     S->on.rng = 2463534242u;
 }
@@ -1173,7 +1184,8 @@ void qc_assign_cache_lookup(qc_system *S) {
     std::lock_guard<std::mutex> lk(C.mu);
     for (const auto &kv : C.e)
         if (kv.first == key && kv.second.first.size() == S->unit_stream.size()) {
-            S->unit_stream = kv.second.first; S->on.best = S->unit_stream; S->on.frozen = S->on.frozen || kv.second.second; S->assign_gen += 1;
+            S->unit_stream = kv.second.first; S->on.best = S->unit_stream; S->assign_gen += 1;
+            if (kv.second.second) { S->on.frozen = true; S->on.settled = true; }
             return;
         }
 }
@@ -1182,8 +1194,8 @@ static void qc_assign_cache_store(const qc_system *S) {
     const uint64_t key = qc_assign_key(S);
     QcAssignCache &C = qc_assign_cache();
     std::lock_guard<std::mutex> lk(C.mu);
-    for (auto &kv : C.e) if (kv.first == key) { kv.second = {S->on.best, S->on.frozen}; return; }
-    if (C.e.size() < 64) C.e.push_back({key, {S->on.best, S->on.frozen}});
+    for (auto &kv : C.e) if (kv.first == key) { kv.second = {S->on.best, S->on.settled}; return; }
+    if (C.e.size() < 64) C.e.push_back({key, {S->on.best, S->on.settled}});
 }
 // A build may be issued speculatively (device-side fork, scf_iterate) when nothing of it needs the host: the launches have been timed
 // (that first build waits for its serial passes), the side streams are joined on the device, and the accumulation is the fixed-point one
@@ -1194,8 +1206,24 @@ bool qc_fock_can_speculate(const qc_system *S) {
 }
 // (the SCF passes report their build times: kept as the handle's running mean - the search itself measures its own builds)
 void qc_fock_feedback(qc_system *S, float build_ms, unsigned gen) {
+    qc_system::QcOnline &o = S->on;
     if (gen != S->assign_gen) return;
-    S->on.seen_sum += build_ms; S->on.seen_n += 1;
+    o.seen_sum += build_ms; o.seen_n += 1;
+    if (!o.frozen || o.settled) return;
+    if (o.top.size() < 2 || o.fin_cur >= (int)o.top.size()) { o.settled = true; return; }
+    if (S->cand_skip) { S->cand_skip = false; return; }          // (first build under this finalist)
+    o.fin_sum[o.fin_cur] += build_ms; o.fin_n[o.fin_cur] += 1;
+    if (o.fin_n[o.fin_cur] < 3) return;
+    auto switch_to = [&](const std::vector<int> &a) { if (S->unit_stream != a) { S->unit_stream = a; S->assign_gen += 1; S->cand_skip = true; } };
+    if (o.fin_cur + 1 < (int)o.top.size()) { o.fin_cur += 1; switch_to(o.top[o.fin_cur].second); return; }
+    size_t b = 0;
+    for (size_t i = 1; i < o.top.size(); ++i) if (o.fin_sum[i] / o.fin_n[i] < o.fin_sum[b] / o.fin_n[b]) b = i;
+    static const bool dbg = getenv("QC_TUNE_DEBUG") != nullptr;
+    if (dbg) { fprintf(stderr, "[tune] finals inside SCF passes:"); for (size_t i = 0; i < o.top.size(); ++i) fprintf(stderr, " %.4f (%.4f back to back)", o.fin_sum[i] / o.fin_n[i], o.top[i].first); fprintf(stderr, " -> %zu\n", b); }
+    o.best = o.top[b].second;
+    switch_to(o.best);
+    o.settled = true;
+    qc_assign_cache_store(S);
 }
 
 // temporary device buffer of the two set-up passes below: released on every return path

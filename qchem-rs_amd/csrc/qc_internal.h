@@ -207,6 +207,12 @@ struct qc_system {
         long builds = 0, spent = 0;            // builds asked of this handle / extra builds the search has run
         unsigned rng = 2463534242u;
         double seen_sum = 0.0; long seen_n = 0;   // build times reported by SCF passes under the current assignment
+        // finals (qc_fock_feedback): the three fastest assignments of the search, sampled inside SCF passes - a build that follows a Roothaan
+        // step and a host turn-around is not the back-to-back build the search times, and which of them is fastest THERE differs
+        std::vector<std::pair<float, std::vector<int>>> top;
+        std::vector<double> fin_sum; std::vector<int> fin_n;
+        int fin_cur = 0;
+        bool settled = false;                     // search and finals are over
     } on;
     bool cand_skip = false;                  // the next build is the first under a new assignment: not a sample
     unsigned assign_gen = 0;                 // counts the changes of the stream assignment: a build's time is a sample of the assignment it ran under
