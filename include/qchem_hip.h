@@ -198,6 +198,13 @@ int qc_plan_shard_quartets(qc_system *sys, int rank, int nranks, int32_t *abcd, 
 int qc_debug_ket_entry(int ket, int first_primitive, int length, int packed, int32_t out[3]);
 
 /* ---- measurement hooks */
+/* Dispatch lanes of this handle: the GPU dispatches at most four kernels at a time - hardware queues sit in pairs on four
+ * pipes, and a pipe works on one grid until all its workgroups are launched - so the concurrent launches of a Fock build go to one stream
+ * per pipe.  Which of the handle's streams share a pipe is measured when the handle initialises its device state.  nlanes: streams on
+ * distinct pipes (4 on an MI355X with GPU_MAX_HW_QUEUES=8; 7 = not measured: QC_NO_LANES, or dispatches are serialised by a profiler);
+ * slot_stream[0..6]: side stream behind assignment slot k (the first nlanes are the lanes), slot_stream[7]: 1 if slot 0 shares the pipe of
+ * the handle's own stream (its chain then runs on that stream itself). */
+int qc_dispatch_lanes(qc_system *sys, int32_t *nlanes, int32_t slot_stream[8]);
 int qc_set_stream(qc_system *sys, void *hip_stream);  /* run on the caller's stream (e.g. torch's current stream) */
 int qc_device_ready(void);                             /* QC_OK if a gfx950 device is usable */
 /* Algorithmic work of one Fock build on this handle's shard (SURVEY.md 8d model): */

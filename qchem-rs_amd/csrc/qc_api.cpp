@@ -1170,6 +1170,14 @@ int qc_debug_ket_entry(int ket, int first_primitive, int length, int packed, int
     out[0] = k; out[1] = f; out[2] = l;
     return QC_OK;
 }
+int qc_dispatch_lanes(qc_system *S, int32_t *nlanes, int32_t slot_stream[8]) {
+    if (!S || !nlanes) return QC_ERR_INVALID;
+    int rc = qc_device_init(S);
+    if (rc != QC_OK) return rc;
+    *nlanes = S->nlanes;
+    if (slot_stream) { for (int k = 0; k < QC_NSTREAMS; ++k) slot_stream[k] = S->slot_side[k]; slot_stream[QC_NSTREAMS] = S->lane0_is_main ? 1 : 0; }
+    return QC_OK;
+}
 int qc_scf_set_stop_rule(qc_scf_state *st, double epsilon) {
     if (!st || !(epsilon >= 0.0)) return QC_ERR_INVALID;
     st->eps_hint = epsilon;

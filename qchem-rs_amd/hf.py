@@ -23,9 +23,10 @@ import numpy as np
 
 from .loader import MolecularSystem
 
-# The Fock build launches its class kernels on several HIP streams; ROCm maps streams onto 4 hardware queues by
-# default, 8 lets more of the small classes overlap (measured: -20 % Fock-build time on H2O/cc-pVTZ).  Must be set
-# before the HIP runtime initialises, hence at import time.
+# The Fock build launches its class kernels on several HIP streams.  The chip has four dispatch pipes; with ROCm's default of 4
+# hardware queues, streams that land on one queue serialise completely, with 8 the library can pick one queue per pipe for its
+# concurrent launches and keep the handle's own stream apart (the library measures which streams share a pipe).
+# Must be set before the HIP runtime initialises, hence at import time.
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
@@ -42,7 +43,7 @@ EXPORTS = ["qc_system_create", "qc_system_destroy", "qc_nbasis", "qc_nelectrons"
            "qc_comm_init", "qc_set_shard", "qc_plan_shard", "qc_set_stream", "qc_device_ready", "qc_work_stats_get",
            "qc_fock_profile", "qc_plan_shard_quartets", "qc_scf_begin_rhf", "qc_scf_begin_uhf", "qc_scf_iterate",
            "qc_scf_orbital_energies", "qc_scf_density", "qc_scf_spin_square", "qc_scf_timings", "qc_scf_end", "qc_fock_profile_tiers", "qc_unit_quartets", "qc_sym_eig_warm", "qc_set_fock_mode", "qc_scf_tensor_ms", "qc_set_accumulation", "qc_set_schwarz", "qc_scf_matrix", "qc_rccl_info", "qc_measure_peaks",
-           "qc_scf_set_stop_rule", "qc_scf_counters", "qc_debug_ket_entry"]
+           "qc_scf_set_stop_rule", "qc_scf_counters", "qc_debug_ket_entry", "qc_dispatch_lanes"]
 
 
 class QcError(RuntimeError):
@@ -240,6 +241,12 @@ class System:
 
     def comm_init(self, uid: bytes, rank: int, nranks: int):
         _check(lib().qc_comm_init(self._h, uid, rank, nranks), "qc_comm_init")
+
+    def dispatch_lanes(self):
+        """(number of dispatch lanes, side stream behind every assignment slot, whether slot 0 is the pipe of the handle's own stream)."""
+        n = C.c_int32(); sl = (C.c_int32 * 8)()
+        _check(lib().qc_dispatch_lanes(self._h, C.byref(n), sl), "qc_dispatch_lanes")
+        return n.value, [int(x) for x in sl[:7]], bool(sl[7])
 
     def set_stream(self, stream_ptr: int): _check(lib().qc_set_stream(self._h, C.c_void_p(stream_ptr)), "qc_set_stream")
 

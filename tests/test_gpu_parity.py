@@ -4,6 +4,8 @@ Tolerances: the path computes in f64; BASELINE.json's north_star asks for total 
 path.  Integrals and Fock matrices are compared element-wise at 1e-10 (abs) - two orders tighter than the energy
 target needs - and converged energies at 1e-8 Eh with epsilon = 1e-10 (at looser epsilon the
 reference's *reported* energy is itself 6e-8..2e-6 Eh from self-consistency)."""
+import os
+
 import numpy as np
 import pytest
 
@@ -633,6 +635,17 @@ def test_spin_parallel_roothaan_steps_do_not_change_a_bit(mol, basis, na, nb, mo
     ser, ws = run()
     assert par == ser
     assert np.array_equal(wp[0], ws[0]) and np.array_equal(wp[1], ws[1])
+
+
+def test_dispatch_lanes_are_measured():
+    """qc_lane_probe: the handle's side streams fall into dispatch lanes (streams that share a pipe wait for each other's grids); the
+    assignment slots list every side stream once, the lanes first.  On an MI355X with GPU_MAX_HW_QUEUES=8 (set by hf.py) there are four."""
+    q, s, o = _sys("water", "STO-3G")
+    n, slots, lane0_main = s.dispatch_lanes()
+    assert sorted(slots) == list(range(7))
+    assert 1 <= n <= 7
+    if os.environ.get("GPU_MAX_HW_QUEUES") == "8" and not os.environ.get("QC_NO_LANES"):
+        assert n == 4 and lane0_main, (n, slots, lane0_main)
 
 
 def test_scf_runs_are_bitwise_reproducible():
