@@ -380,6 +380,51 @@ struct QcIssuePool {
 
 static void qc_issue_pool_drop(qc_system *S) { delete S->issue_pool; S->issue_pool = nullptr; }
 
+// ---- One handle at a time may have device-side waits in flight on a device.  A waiting kernel sits at the head of its hardware queue
+// until the kernel that releases it has run; the argument that this cannot deadlock - every wait is issued after everything it depends
+// on, and a hardware queue runs in issue order - holds for ONE issuing sequence.  Two handles issuing from two threads (the header
+// allows that) can park handle A's waiter in front of handle B's marker and B's waiter in front of A's: both then wait out their limit.
+// So the issue of a build - the only place where cross-stream dependencies are created - goes through a per-device gate: the issuing
+// thread holds the gate's mutex while it issues, and if ANOTHER handle still has waits in flight it first waits for that handle's
+// stream (those waits finish without any help from the host: everything they depend on was issued before them).  Uncontended cost: one
+// mutex per build.
+struct QcGate { std::mutex mu; qc_system *owner = nullptr; };
+static QcGate &qc_gate_of(int device) {
+    static QcGate gates[64];
+    return gates[(device >= 0 && device < 64) ? device : 0];
+}
+struct QcGateHold {
+    QcGate &g;
+    qc_system *S;
+    bool waits = false;                       // the issue under this hold put device-side waits in flight
+    explicit QcGateHold(qc_system *S_) : g(qc_gate_of(S_->device)), S(S_) {
+        g.mu.lock();
+        if (g.owner && g.owner != S) {
+            if (g.owner->stream) (void)hipStreamSynchronize(g.owner->stream);      // (the join wait is the last thing of a build on it)
+            g.owner->waits_in_flight = false;
+            g.owner = nullptr;
+        }
+    }
+    ~QcGateHold() {
+        if (waits) { g.owner = S; S->waits_in_flight = true; }
+        g.mu.unlock();
+    }
+};
+// the host has seen the handle's stream drained past its last build: nothing of this handle waits on the device any more
+void qc_gate_quiet(qc_system *S) {
+    if (!S->waits_in_flight) return;
+    QcGate &g = qc_gate_of(S->device);
+    std::lock_guard<std::mutex> lk(g.mu);
+    if (g.owner == S) g.owner = nullptr;
+    S->waits_in_flight = false;
+}
+static void qc_gate_forget(qc_system *S) {          // the handle goes away
+    QcGate &g = qc_gate_of(S->device);
+    std::lock_guard<std::mutex> lk(g.mu);
+    if (g.owner == S) g.owner = nullptr;
+    S->waits_in_flight = false;
+}
+
 // ---- Pool of stream sets (the handle's own stream, the side streams, their events, the dispatch lanes measured on them)
 struct QcStreamSet {
     int device; hipStream_t main, side[QC_NSTREAMS]; hipEvent_t ev_fork, ev_join[QC_NSTREAMS];
@@ -437,6 +482,7 @@ static int qc_lane_probe(qc_system *S) {
     for (int k = 0; k < QC_NSTREAMS; ++k) S->slot_side[k] = k;
     S->nlanes = QC_NSTREAMS; S->lane0_is_main = false;
     if (getenv("QC_NO_LANES")) return QC_OK;
+    QcGateHold gate(S);                  // (one probe at a time per device; another handle's grids in flight can still make two lanes look like one - that costs time, never results)
     using clk = std::chrono::steady_clock;
     auto us = [](clk::time_point a, clk::time_point b) { return std::chrono::duration<double, std::micro>(b - a).count(); };
     const int grid = 8192; const long long ticks = 500;                  // 8192 one-wave workgroups of 5 us, 40 KB of LDS each: four per CU
@@ -576,51 +622,6 @@ static long long qc_wait_limit(const qc_system *S) {
     double serial_ms = 0.0;
     for (float x : S->unit_ms) serial_ms += x;
     return (long long)(std::max(20000.0, 50.0 * serial_ms) * 1e5);
-}
-
-// ---- One handle at a time may have device-side waits in flight on a device.  A waiting kernel sits at the head of its hardware queue
-// until the kernel that releases it has run; the argument that this cannot deadlock - every wait is issued after everything it depends
-// on, and a hardware queue runs in issue order - holds for ONE issuing sequence.  Two handles issuing from two threads (the header
-// allows that) can park handle A's waiter in front of handle B's marker and B's waiter in front of A's: both then wait out their limit.
-// So the issue of a build - the only place where cross-stream dependencies are created - goes through a per-device gate: the issuing
-// thread holds the gate's mutex while it issues, and if ANOTHER handle still has waits in flight it first waits for that handle's
-// stream (those waits finish without any help from the host: everything they depend on was issued before them).  Uncontended cost: one
-// mutex per build.
-struct QcGate { std::mutex mu; qc_system *owner = nullptr; };
-static QcGate &qc_gate_of(int device) {
-    static QcGate gates[64];
-    return gates[(device >= 0 && device < 64) ? device : 0];
-}
-struct QcGateHold {
-    QcGate &g;
-    qc_system *S;
-    bool waits = false;                       // the issue under this hold put device-side waits in flight
-    explicit QcGateHold(qc_system *S_) : g(qc_gate_of(S_->device)), S(S_) {
-        g.mu.lock();
-        if (g.owner && g.owner != S) {
-            if (g.owner->stream) (void)hipStreamSynchronize(g.owner->stream);      // (the join wait is the last thing of a build on it)
-            g.owner->waits_in_flight = false;
-            g.owner = nullptr;
-        }
-    }
-    ~QcGateHold() {
-        if (waits) { g.owner = S; S->waits_in_flight = true; }
-        g.mu.unlock();
-    }
-};
-// the host has seen the handle's stream drained past its last build: nothing of this handle waits on the device any more
-void qc_gate_quiet(qc_system *S) {
-    if (!S->waits_in_flight) return;
-    QcGate &g = qc_gate_of(S->device);
-    std::lock_guard<std::mutex> lk(g.mu);
-    if (g.owner == S) g.owner = nullptr;
-    S->waits_in_flight = false;
-}
-static void qc_gate_forget(qc_system *S) {          // the handle goes away
-    QcGate &g = qc_gate_of(S->device);
-    std::lock_guard<std::mutex> lk(g.mu);
-    if (g.owner == S) g.owner = nullptr;
-    S->waits_in_flight = false;
 }
 
 hipStream_t qc_spin_fork(qc_system *S) {
@@ -955,8 +956,11 @@ int qc_launch_fock_classes(qc_system *S, const QcFockArgs &fa, float *class_ms, 
                     if (ev && per_unit) QC_HIP_CHECK(hipEventRecord(ev[3 + 2 * u], st));
                 }
             if (!event_join) {
+                // (test hook QC_JOIN_FAULT: the first side stream's marker is left out - a join that can never complete, as if a launch on
+                // that stream had died: the waiting kernel runs into its limit and the call that waits for this build must fail)
+                const bool fault = getenv("QC_JOIN_FAULT") != nullptr;
                 for (int i = 0; i < nset; ++i)
-                    if (set[i] != kmain && !q[set[i]].empty()) hipLaunchKernelGGL(qc_join_mark_kernel, dim3(1), dim3(64), 0, S->side[S->slot_side[side_slot(set[i])]], S->d_join);
+                    if (set[i] != kmain && !q[set[i]].empty() && !(fault && i == (set[0] == kmain ? 1 : 0))) hipLaunchKernelGGL(qc_join_mark_kernel, dim3(1), dim3(64), 0, S->side[S->slot_side[side_slot(set[i])]], S->d_join);
                 if (hipGetLastError() != hipSuccess) return QC_ERR_HIP;
             }
             return QC_OK;

@@ -547,25 +547,33 @@ def test_speculative_builds_are_used_cancelled_and_never_show(mol, basis, uhf, n
 
 def test_a_wait_that_gives_up_fails_the_call_that_waited(monkeypatch):
     """A device-side wait (join of the side streams, fork of a speculative build) that runs into its limit has folded an incomplete
-    matrix: the call whose host wait follows it returns QC_ERR_HIP (never a wrong G), and the handle goes on with event joins.  The
-    limit is forced to nothing here (QC_WAIT_LIMIT_MS): every wait that has to wait at all gives up."""
+    matrix: the call whose host wait follows it returns QC_ERR_HIP (never a wrong G), and the handle goes on with event joins.  Forced
+    here: QC_JOIN_FAULT leaves one side stream's marker out (a join that can never complete, as if a launch had died) and the limit is
+    2 ms (QC_WAIT_LIMIT_MS)."""
     import qchem_rs_amd as q
     m = load_system("water", "cc-pVTZ")
     D = _rand_sym(58, 7)
     s = q.System(m)
-    G0 = s.fock_rhf(D)                                            # tuned, device join
-    monkeypatch.setenv("QC_WAIT_LIMIT_MS", "0.00001")
-    s2 = q.System(m)                                              # (the limit is read once per process: a fresh library copy is not needed, a fresh handle is)
-    failed = 0
-    for _ in range(4):
-        try:
-            G = s2.fock_rhf(D)
-            assert np.array_equal(G, G0)                          # a call that succeeds is complete
-        except q.hf.QcError:
-            failed += 1
+    G0 = s.fock_rhf(D)                                            # device join, nothing wrong
+    s2 = q.System(m)
+    G2 = s2.fock_rhf(D)                                           # (its first build: launches timed alone, lanes, proposals)
+    assert np.array_equal(G2, G0)
+    monkeypatch.setenv("QC_WAIT_LIMIT_MS", "2")
+    monkeypatch.setenv("QC_JOIN_FAULT", "1")
+    with pytest.raises(q.hf.QcError):
+        s2.fock_rhf(D)                                            # THIS call fails: its join gave up
+    st = q.ScfStepper(s)                                          # ... and so does the SCF pass whose build's join gives up
+    with pytest.raises(q.hf.QcError):
+        for _ in range(3):
+            st.iterate()
+    st.close()
+    monkeypatch.delenv("QC_JOIN_FAULT")
     monkeypatch.delenv("QC_WAIT_LIMIT_MS")
-    assert failed >= 1                                            # the first concurrent build's join cannot be instant
-    assert np.array_equal(s2.fock_rhf(D), G0)                     # event joins from now on
+    for h in (s, s2):                                             # event joins from now on: complete results again
+        assert np.array_equal(h.fock_rhf(D), G0)
+    out = q.restricted_hartree_fock(s2, q.HartreeFockConfig(100, 1e-10))
+    ref = q.restricted_hartree_fock(q.System(m), q.HartreeFockConfig(100, 1e-10))
+    assert out.iterations == ref.iterations and out.electronic_energy == ref.electronic_energy
     s.close(); s2.close()
 
 
