@@ -33,7 +33,8 @@ struct QcRccl {
     bool ok = false;
 };
 static QcRccl &qc_rccl() {
-    static QcRccl R = [] {
+    // (on the heap and never destroyed: a handle with a communicator may be released after the static destructors have run)
+    static QcRccl &R = *new QcRccl([] {
         QcRccl r;
         const char *env = getenv("QC_RCCL_LIB");
         if (env && *env) { r.handle = dlopen(env, RTLD_NOW | RTLD_GLOBAL); r.path = env; }
@@ -51,7 +52,7 @@ static QcRccl &qc_rccl() {
             if (dladdr(reinterpret_cast<void *>(r.AllReduce), &info) && info.dli_fname) r.path = info.dli_fname;
         }
         return r;
-    }();
+    }());
     return R;
 }
 

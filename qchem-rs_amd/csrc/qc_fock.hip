@@ -390,7 +390,7 @@ static void qc_issue_pool_drop(qc_system *S) { delete S->issue_pool; S->issue_po
 // mutex per build.
 struct QcGate { std::mutex mu; qc_system *owner = nullptr; };
 static QcGate &qc_gate_of(int device) {
-    static QcGate gates[64];
+    static QcGate *gates = new QcGate[64];          // (never destroyed: handles may outlive the static destructors of the process)
     return gates[(device >= 0 && device < 64) ? device : 0];
 }
 struct QcGateHold {
@@ -1180,7 +1180,7 @@ static uint64_t qc_assign_key(const qc_system *S) {
     return h;
 }
 struct QcAssignCache { std::mutex mu; std::vector<std::pair<uint64_t, std::pair<std::vector<int>, bool>>> e; };
-static QcAssignCache &qc_assign_cache() { static QcAssignCache c; return c; }
+static QcAssignCache &qc_assign_cache() { static QcAssignCache *c = new QcAssignCache(); return *c; }     // (never destroyed, as the gates)
 void qc_assign_cache_lookup(qc_system *S) {
     if (getenv("QC_NO_ASSIGN_CACHE")) return;
     const uint64_t key = qc_assign_key(S);
