@@ -124,7 +124,7 @@ static std::vector<unsigned> qc_build_gidx() {
             for (int u = N - t; u >= 0; --u) { ht.push_back(t); hu.push_back(u); hv.push_back(N - t - u); }
     for (size_t h = 0; h < ht.size(); ++h) if (qc_hidx(ht[h], hu[h], hv[h]) != (int)h) abort();
     for (int LAB = 3; LAB <= 6; ++LAB)
-        for (int LCD = 5; LCD <= 6; ++LCD) {
+        for (int LCD = 4; LCD <= 6; ++LCD) {
             if ((int)out.size() != 4 * qc_gidx_off(LAB, LCD)) abort();
             const int HAB = qc_nherm(LAB), HCD = qc_nherm(LCD), MT = (HAB + 15) / 16;
             for (int ks = 0; ks < qc_gidx_ksteps(LCD); ++ks)
@@ -184,7 +184,7 @@ static void qc_issue_pool_drop(qc_system *S);
 void qc_online_reset(qc_system *S, bool frozen);
 void qc_assign_cache_lookup(qc_system *S);
 static void qc_assign_cache_store(const qc_system *S);
-constexpr int QC_SEARCH_FIRST_BUILD = 24, QC_SEARCH_CHUNK = 6, QC_SEARCH_REJECTS = 10, QC_SEARCH_TRIALS = 64;
+constexpr int QC_SEARCH_FIRST_BUILD = 24, QC_SEARCH_CHUNK = 8, QC_SEARCH_TRIALS = 200;
 
 int qc_device_init(qc_system *S) {
     if (S->device_ready) return QC_OK;
@@ -781,7 +781,7 @@ static int launch_segments(qc_system *S, int unit, const std::vector<Seg> &segs,
     if (tier == 1) {
         bool only4 = true;
         for (const Seg &sg : segs) only4 = only4 && sg.c->LCD == 4;
-        if (only4) tier = 2;
+        if (only4 && !S->has_fkets) tier = 2;      // (with f kets around, the d.d / f.p-ket classes may be in their matrix-core form: the f-capable kernel)
     }
     static const bool lds_dbg = getenv("QC_LDS_DEBUG") != nullptr;
     if (lds_dbg) {
@@ -1095,20 +1095,34 @@ int qc_launch_fock_classes(qc_system *S, const QcFockArgs &fa, float *class_ms, 
             }
             return QC_OK;
         };
-        auto propose = [&]() -> bool {
-            if (!o.cands.empty()) { o.trial = o.cands.back(); o.cands.pop_back(); return true; }      // (the proposals of the first build)
+        // The neighbourhood of the current best, in full and in a fixed order: every launch moved to every other lane, every pair of
+        // launches on different lanes swapped - launches of the most loaded lane first (they are the ones whose move can shorten the
+        // build).  The search ends when a whole sweep has found nothing (a local optimum of the FULL neighbourhood: ten random
+        // neighbours in a row, the rule before, left most of it unseen and ended anywhere between 0.172 and 0.192 ms on H2O/cc-pVTZ).
+        auto neighbours = [&]() {
+            o.nb.clear(); o.nb_pos = 0;
             std::vector<int> act;
             for (size_t u = 0; u < units.size(); ++u) if (!units[u].empty()) act.push_back((int)u);
             const int nl = std::min(QC_NSTREAMS, S->nlanes);
-            if (act.size() < 2 || nl < 2) return false;
-            auto next = [&]() { o.rng ^= o.rng << 13; o.rng ^= o.rng >> 17; o.rng ^= o.rng << 5; return o.rng >> 4; };
-            for (int tries = 0; tries < 32; ++tries) {
-                std::vector<int> t = o.best;
-                const int u = act[next() % act.size()];
-                if (next() & 1) { const int k = (int)(next() % nl); if (k == t[u]) continue; t[u] = k; }
-                else { const int v = act[next() % act.size()]; if (t[v] == t[u]) continue; std::swap(t[u], t[v]); }
-                o.trial = t;
-                return true;
+            if (act.size() < 2 || nl < 2) return;
+            float load[QC_NSTREAMS] = {};
+            for (int u : act) load[o.best[u]] += S->unit_ms[u];
+            std::stable_sort(act.begin(), act.end(), [&](int x, int y) { return load[o.best[x]] > load[o.best[y]]; });
+            for (int u : act)
+                for (int k = 0; k < nl; ++k)
+                    if (k != o.best[u]) { std::vector<int> t = o.best; t[u] = k; o.nb.push_back(std::move(t)); }
+            for (size_t i = 0; i < act.size(); ++i)
+                for (size_t j = i + 1; j < act.size(); ++j)
+                    if (o.best[act[i]] != o.best[act[j]]) { std::vector<int> t = o.best; std::swap(t[act[i]], t[act[j]]); o.nb.push_back(std::move(t)); }
+        };
+        auto propose = [&]() -> bool {
+            if (!o.cands.empty()) { o.trial = o.cands.back(); o.cands.pop_back(); return true; }      // (the proposals of the first build)
+            if (o.nb.empty() && o.nb_pos == 0) neighbours();
+            while (o.nb_pos < o.nb.size()) {
+                o.trial = o.nb[o.nb_pos++];
+                bool seen = false;
+                for (const auto &e : o.tried) if (e == o.trial) { seen = true; break; }
+                if (!seen) { o.tried.push_back(o.trial); return true; }
             }
             return false;
         };
@@ -1128,10 +1142,10 @@ int qc_launch_fock_classes(qc_system *S, const QcFockArgs &fa, float *class_ms, 
             if ((rc = measure(o.trial, t)) != QC_OK) return rc;
             o.trials += 1;
             if (dbg) fprintf(stderr, "[tune] trial %d (build %ld of the handle): %.4f ms against %.4f ms - %s\n", o.trials, (long)o.builds, t, o.base_ms, t < 0.985 * o.base_ms ? "kept" : "dropped");
-            if (t < 0.985 * o.base_ms) { o.best = o.trial; o.base_ms = t; o.rejects = 0; }
+            if (t < 0.985 * o.base_ms) { o.best = o.trial; o.base_ms = t; o.rejects = 0; o.nb.clear(); o.nb_pos = 0; }     // (a new neighbourhood)
             else if (!seeded) o.rejects += 1;
             note_top(o.trial, t);
-            if (o.rejects >= QC_SEARCH_REJECTS || o.trials >= QC_SEARCH_TRIALS) o.frozen = true;
+            if (o.trials >= QC_SEARCH_TRIALS) o.frozen = true;
         }
         S->unit_stream = o.best;
         S->assign_gen += 1; S->tune_count += 1;             // (this build carries extra builds: not a timing sample)
@@ -1164,7 +1178,7 @@ int qc_launch_fock_classes(qc_system *S, const QcFockArgs &fa, float *class_ms, 
 // of its builds), but in small instalments once the handle has shown that it lives long: from its 24th build on, a build may spend on
 // trials as many extra builds as the handle has done useful ones so far, minus what was spent already.  A handle that does one SCF pays
 // nothing; one that runs hundreds of builds (geometry loops, benchmarks) converges to the searched assignment at a bounded overhead
-// and then stops (QC_SEARCH_REJECTS rejections in a row, or QC_SEARCH_TRIALS trials); the result goes to a process-wide cache keyed by
+// and then stops (a whole sweep of the neighbourhood without a gain, or QC_SEARCH_TRIALS trials); the result goes to a process-wide cache keyed by
 // the shape of the work lists.  The stream assignment does not change results (integer accumulation), only time.
 void qc_online_reset(qc_system *S, bool frozen) {
     S->on = qc_system::QcOnline{};

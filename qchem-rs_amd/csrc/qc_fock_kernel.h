@@ -319,7 +319,9 @@ __device__ __forceinline__ void qc_build_r(double *__restrict__ Rw, const int2 *
 // LDS row buffer across the batches of one bra and flushes what is non-zero when the bra changes: one global atomic (pair) and one
 // fixed-point conversion per touched element and bra run instead of per slot (the memory-side atomics of these classes were a third
 // of a benzene build's; cf. the bra-major kernels).  run == 0: slots are independent, grid-stride over batches.
-template <int LAB, int LCD, int LGC>
+// (MFMA_OK = false: the instance of a launch that never sees f-ket classes - qc_fock_tier_kernel<LAB, 2> - keeps the VALU form of its d.d / f.p-ket
+// bodies and with it its two waves per SIMD)
+template <int LAB, int LCD, int LGC, bool MFMA_OK = true>
 __device__ __forceinline__ void qc_fock_body(const QcKernelArgs &a, const QcSlot *__restrict__ slots, const int nslots, const int slot_words,
                                              const int blk, const int nblk, const int run = 0, const int rb_rows = 0) {
     constexpr int L = LAB + LCD, HAB = qc_nherm(LAB), HCD = qc_nherm(LCD);
@@ -339,7 +341,7 @@ __device__ __forceinline__ void qc_fock_body(const QcKernelArgs &a, const QcSlot
     double *const Rw = lds + (size_t)g * slot_words;       // this group's private LDS region
     double *const Iblk = Rw + qc_region0(L, LGC);
     const size_t rep = (size_t)(blk % a.nrep) * a.rep_stride;   // accumulation replica of this workgroup
-    constexpr bool MFMA = qc_use_mfma(LAB, LCD) && LGC == 6;   // contractions on the matrix cores (one slot per wave)
+    constexpr bool MFMA = MFMA_OK && qc_use_mfma(LAB, LCD) && LGC == 6;   // contractions on the matrix cores (one slot per wave)
     // recurrence plan of this class's R tables: behind the groups' regions, shared by them (read after the first barrier below)
     int2 *const plan = reinterpret_cast<int2 *>(lds + (size_t)G * slot_words);
     if constexpr (!HOIST) {
@@ -992,7 +994,9 @@ void qc_fock_tier_kernel(const QcTierArgs a) {
     } else if constexpr (TIER == 1) {
         switch (a.seg_code[s]) { QC_CASE(4, 5) QC_CASE(4, 6) QC_CASE(5, 6) QC_CASE(6, 6) default: break; }
     } else {
-        switch (a.seg_code[s]) { QC_CASE(4, 5) QC_CASE(4, 6) default: break; }
+#define QC_CASE_V(LCD, LGC) case ((LCD) << 4 | (LGC)): qc_fock_body<LAB, LCD, LGC, false>(a.base, slots, nslots, words, blk, nblk, a.seg_run[s], a.seg_rbrows[s]); break;
+        switch (a.seg_code[s]) { QC_CASE_V(4, 5) QC_CASE_V(4, 6) default: break; }
+#undef QC_CASE_V
     }
 #undef QC_CASE
 }

@@ -41,14 +41,19 @@ __host__ __device__ constexpr int qc_nherm(int L) { return (L + 1) * (L + 2) * (
 // Classes whose two Hermite contractions run as f64 MFMA tiles (one slot per wave): high-order kets against bras with
 // enough Hermite functions to fill 16-row tiles.  Measured on H2O/cc-pVTZ and benzene/cc-pVDZ: below these bounds the
 // padded tiles and the lost second slot per wave cost more than the LDS reads they save.
-__host__ __device__ constexpr bool qc_use_mfma(int LAB, int LCD) { return LCD >= 5 && LAB >= 3; }
-// Gather records of the matrix-core classes' step 2 (A operand = R values at h1 + h2): per class (LAB 3..6, LCD 5..6) one 16-byte record
+// (round 4: d.d / f.p kets - LCD = 4 - too, in their 64-lane instances: a class whose list cannot fill the chip is a latency chain of single
+// waves, and there the tile form with one wave per 16-column tile is shorter - (dd|dd) of H2O/cc-pVTZ 57 us per workgroup in the VALU
+// form; lists that do fill the chip keep the 32-lane VALU instances with two slots per wave, qc_build_model)
+__host__ __device__ constexpr bool qc_use_mfma(int LAB, int LCD) { return LCD >= 4 && LAB >= 3; }
+// (... the classes that are ALWAYS on the matrix cores)
+__host__ __device__ constexpr bool qc_mfma_always(int LAB, int LCD) { return LCD >= 5 && LAB >= 3; }
+// Gather records of the matrix-core classes' step 2 (A operand = R values at h1 + h2): per class (LAB 3..6, LCD 4..6) one 16-byte record
 // per (k-step, lane); classes concatenated in (LAB, LCD) order, class (LAB, LCD) starts at record qc_gidx_off(LAB, LCD)
 __host__ __device__ constexpr int qc_gidx_ksteps(int LCD) { return ((LCD + 1) * (LCD + 2) * (LCD + 3) / 6 + 3) / 4; }
 __host__ __device__ constexpr int qc_gidx_off(int LAB, int LCD) {
     int o = 0;
     for (int a = 3; a <= 6; ++a)
-        for (int c = 5; c <= 6; ++c) { if (a == LAB && c == LCD) return o; o += 64 * qc_gidx_ksteps(c); }
+        for (int c = 4; c <= 6; ++c) { if (a == LAB && c == LCD) return o; o += 64 * qc_gidx_ksteps(c); }
     return o;
 }
 __host__ __device__ constexpr int qc_ncart(int L) { return (L + 1) * (L + 2) / 2; }
@@ -201,6 +206,8 @@ struct qc_system {
     struct QcOnline {
         bool frozen = false;
         std::vector<int> best, trial;
+        std::vector<std::vector<int>> nb, tried;   // neighbourhood of `best` (swept in order from nb_pos) / every assignment measured so far
+        size_t nb_pos = 0;
         std::vector<std::vector<int>> cands;   // proposals of the first build (longest-first on in-build durations): tried before random neighbours
         double base_ms = 0.0;                  // build time of `best` as the search measured it
         int trials = 0, rejects = 0;
@@ -230,6 +237,7 @@ struct qc_system {
     int accum_fx = 1;                        // 1 (default): fixed-point, order-independent accumulation of G; 0: f64 atomics
     bool merge_bm = false;                    // ... and the ss-ket / high-bra bundles ride in the launch of the ps kets / low bras
     bool merge_t1 = false;                    // the wide-ket launches of the bra classes 0, 1, 2 are one launch (set with the class lists)
+    bool has_fkets = false;                   // some class has an f.d / f.f ket (a basis with f functions): the wide-ket launches are the f-capable kernels
     bool pp_ok = true;                        // every p.p pair's expansion blocks have the packed form the pp-ket bra-major kernel assumes
     std::string last_error;
 };

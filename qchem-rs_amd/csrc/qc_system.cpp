@@ -353,6 +353,19 @@ void qc_build_model(qc_system *S) {
             ppb.clear();
         }
     }
+    {   // d.d / f.p kets against d.p ... f.f bras: a short list (a small molecule) goes to the 64-lane instance of its class, which runs the
+        // contractions as matrix-core tiles with one wave per 16-column tile; a long one keeps the 32-lane VALU form with two slots per wave
+        // (benzene/cc-pVDZ: the tile form cost the full chip 2.6 % in round 2).  QC_MFMA4_MAX: longest list that switches (0: never).
+        const long mx = getenv("QC_MFMA4_MAX") ? atol(getenv("QC_MFMA4_MAX")) : 1024;
+        // (only where the wide-ket launches are the f-capable kernels - a basis with f functions; without them the launch is the variant
+        // that carries the d.d / f.p-ket bodies alone, in their VALU form, at two waves per SIMD: qc_fock_tier_kernel<LAB, 2>)
+        S->has_fkets = false;
+        for (int b = 0; b < NB; ++b) if (!(b & 1) && (b / 14) % (QC_LPAIR + 1) >= 5 && !bucket[b].empty()) S->has_fkets = true;
+        for (int lab = 3; S->has_fkets && lab <= QC_LPAIR; ++lab) {
+            auto &b5 = bucket[(((lab * (QC_LPAIR + 1) + 4) * 7) + 5) * 2], &b6 = bucket[(((lab * (QC_LPAIR + 1) + 4) * 7) + 6) * 2];
+            if (!b5.empty() && (long)b5.size() <= mx) { b6.insert(b6.end(), b5.begin(), b5.end()); b5.clear(); }
+        }
+    }
     S->classes.clear();
     for (int b = 0; b < NB; ++b) {
         auto &v = bucket[b];
@@ -379,7 +392,7 @@ void qc_build_model(qc_system *S) {
 // made of whole 16-lane rows - the Hermite contractions broadcast inside rows (DPP) - so the 5..10 columns of a ds / fs ket
 // leave lanes idle; as 8-lane groups with LDS-fed contractions those classes were 20 % slower.
 int qc_lgc_for(int lab, int lcd, int ncd) {
-    if (qc_use_mfma(lab, lcd)) return 6;            // matrix-core classes: one slot per wave, always the full wave
+    if (qc_mfma_always(lab, lcd)) return 6;         // matrix-core classes: one slot per wave, always the full wave
     static const int allowed[QC_LPAIR + 1][4] = {{4, -1, -1, -1}, {4, -1, -1, -1}, {4, -1, -1, -1}, {4, 5, -1, -1}, {5, 6, -1, -1}, {6, -1, -1, -1}, {6, -1, -1, -1}};
     for (int i = 0; i < 4 && allowed[lcd][i] >= 0; ++i)
         if ((1 << allowed[lcd][i]) >= ncd) return allowed[lcd][i];
@@ -552,7 +565,7 @@ void qc_build_shards(qc_system *S) {
         else {
             qc_make_slots(S, c.shard, itmax, false, c.slots);
             // a matrix-core class (one slot per wave) with fewer slots than the chip has SIMDs: one wave per 16-column tile
-            if (qc_use_mfma(c.LAB, c.LCD) && c.LGC == 6 && c.slots.size() * 4 <= 1024) qc_make_slots(S, c.shard, itmax, true, c.slots);
+            if ((qc_mfma_always(c.LAB, c.LCD) || (S->has_fkets && qc_use_mfma(c.LAB, c.LCD))) && c.LGC == 6 && c.slots.size() * 4 <= 1024) qc_make_slots(S, c.shard, itmax, true, c.slots);
             // Low-L classes (16- / 32-lane groups: several slots per wave): bra-run mode.  Slots are grouped by bra pair - heavy bras
             // first, inside a bra the longest slots first - every batch of G slots gets one bra (null slots pad), and a workgroup takes
             // `run` consecutive batches, so that the targets that belong to the bra stay in its LDS row buffer across them.
