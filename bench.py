@@ -97,6 +97,7 @@ def timed_scf_passes(q, sysh, host, sync, steps, warmup, world_single=True):
         frozen = st.counters()["assign_frozen"] > 0
         st.close()
         warm_runs += 1
+    sysh.freeze_assignment()          # (whatever the search has found by now stays: no instalment of it inside the timed passes)
     per_run = (kconv + 1) if kconv is not None else steps
     # (stop_rule: this loop ends a run once rms < EPS - said to the library, which issues each pass's successor build ahead of time and
     # can then empty the one queued behind a converging pass on the device instead of running it for nothing)
@@ -203,6 +204,7 @@ def accumulation_ab(q, mol, passes=12):
         for _ in range(16):
             warm.iterate()
         warm.close()
+        s.freeze_assignment()
         st = q.ScfStepper(s)
         for _ in range(4):
             st.iterate()

@@ -57,6 +57,7 @@ extern "C" {
     pub fn qc_scf_orbital_energies(st: *mut QcScfState, spin: c_int, out: *mut f64) -> c_int;
     pub fn qc_scf_density(st: *mut QcScfState, spin: c_int, out: *mut f64) -> c_int;
     pub fn qc_scf_spin_square(st: *mut QcScfState, s2: *mut f64) -> c_int;
+    pub fn qc_freeze_assignment(sys: *mut QcSystem) -> c_int;
     pub fn qc_dispatch_lanes(sys: *mut QcSystem, nlanes: *mut i32, slot_stream: *mut i32) -> c_int;
     pub fn qc_scf_set_stop_rule(st: *mut QcScfState, epsilon: f64) -> c_int;
     pub fn qc_scf_counters(st: *mut QcScfState, out: *mut f64, n: c_int) -> c_int;

@@ -205,6 +205,10 @@ int qc_debug_ket_entry(int ket, int first_primitive, int length, int packed, int
  * slot_stream[0..6]: side stream behind assignment slot k (the first nlanes are the lanes), slot_stream[7]: 1 if slot 0 shares the pipe of
  * the handle's own stream (its chain then runs on that stream itself). */
 int qc_dispatch_lanes(qc_system *sys, int32_t *nlanes, int32_t slot_stream[8]);
+/* The assignment of a build's launches to the lanes is refined in instalments of extra builds inside later builds (paid for by use,
+ * DESIGN.md 3.2).  A harness that is about to TIME builds ends that search here and now, with the best assignment found so far, so that
+ * no instalment falls into its timed region.  Results never depend on the assignment. */
+int qc_freeze_assignment(qc_system *sys);
 int qc_set_stream(qc_system *sys, void *hip_stream);  /* run on the caller's stream (e.g. torch's current stream) */
 int qc_device_ready(void);                             /* QC_OK if a gfx950 device is usable */
 /* Algorithmic work of one Fock build on this handle's shard (SURVEY.md 8d model): */

@@ -1171,6 +1171,11 @@ int qc_debug_ket_entry(int ket, int first_primitive, int length, int packed, int
     out[0] = k; out[1] = f; out[2] = l;
     return QC_OK;
 }
+int qc_freeze_assignment(qc_system *S) {
+    if (!S) return QC_ERR_INVALID;
+    qc_assignment_freeze(S);
+    return QC_OK;
+}
 int qc_dispatch_lanes(qc_system *S, int32_t *nlanes, int32_t slot_stream[8]) {
     if (!S || !nlanes) return QC_ERR_INVALID;
     int rc = qc_device_init(S);

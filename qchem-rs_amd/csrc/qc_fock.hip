@@ -184,7 +184,7 @@ static void qc_issue_pool_drop(qc_system *S);
 void qc_online_reset(qc_system *S, bool frozen);
 void qc_assign_cache_lookup(qc_system *S);
 static void qc_assign_cache_store(const qc_system *S);
-constexpr int QC_SEARCH_FIRST_BUILD = 24, QC_SEARCH_CHUNK = 8, QC_SEARCH_TRIALS = 200;
+constexpr int QC_SEARCH_FIRST_BUILD = 24, QC_SEARCH_CHUNK = 8, QC_SEARCH_TRIALS = 120;
 
 int qc_device_init(qc_system *S) {
     if (S->device_ready) return QC_OK;
@@ -908,9 +908,14 @@ int qc_launch_fock_classes(qc_system *S, const QcFockArgs &fa, float *class_ms, 
         {
             std::vector<int> byw;
             for (size_t u = 0; u < units.size(); ++u) if (!units[u].empty()) byw.push_back((int)u);
-            std::stable_sort(byw.begin(), byw.end(), [&](int x, int y) { return S->unit_weight[x] > S->unit_weight[y]; });
+            // (an entry of unit_stream is lane | rank << 3: inside a lane the launches go out by rank, then heaviest first - the rank is how
+            // the assignment search puts a lighter launch in front of a heavier one)
+            std::stable_sort(byw.begin(), byw.end(), [&](int x, int y) {
+                const int rx = S->unit_stream[x] >> 3, ry = S->unit_stream[y] >> 3;
+                return rx != ry ? rx < ry : S->unit_weight[x] > S->unit_weight[y];
+            });
             float load[QC_NSTREAMS] = {};
-            for (int u : byw) { q[S->unit_stream[u]].push_back(u); load[S->unit_stream[u]] += S->unit_weight[u]; }
+            for (int u : byw) { q[S->unit_stream[u] & 7].push_back(u); load[S->unit_stream[u] & 7] += S->unit_weight[u]; }
             for (int k = 0; k < QC_NSTREAMS; ++k) ks[k] = k;
             std::stable_sort(ks, ks + QC_NSTREAMS, [&](int x, int y) { return load[x] > load[y]; });
         }
@@ -1106,14 +1111,26 @@ int qc_launch_fock_classes(qc_system *S, const QcFockArgs &fa, float *class_ms, 
             const int nl = std::min(QC_NSTREAMS, S->nlanes);
             if (act.size() < 2 || nl < 2) return;
             float load[QC_NSTREAMS] = {};
-            for (int u : act) load[o.best[u]] += S->unit_ms[u];
-            std::stable_sort(act.begin(), act.end(), [&](int x, int y) { return load[o.best[x]] > load[o.best[y]]; });
+            int cnt[QC_NSTREAMS] = {}, maxrank[QC_NSTREAMS] = {};
+            for (int u : act) { const int k = o.best[u] & 7; load[k] += S->unit_ms[u]; cnt[k] += 1; maxrank[k] = std::max(maxrank[k], o.best[u] >> 3); }
+            std::stable_sort(act.begin(), act.end(), [&](int x, int y) { return load[o.best[x] & 7] > load[o.best[y] & 7]; });
             for (int u : act)
                 for (int k = 0; k < nl; ++k)
-                    if (k != o.best[u]) { std::vector<int> t = o.best; t[u] = k; o.nb.push_back(std::move(t)); }
+                    if (k != (o.best[u] & 7)) { std::vector<int> t = o.best; t[u] = k; o.nb.push_back(std::move(t)); }
             for (size_t i = 0; i < act.size(); ++i)
                 for (size_t j = i + 1; j < act.size(); ++j)
-                    if (o.best[act[i]] != o.best[act[j]]) { std::vector<int> t = o.best; std::swap(t[act[i]], t[act[j]]); o.nb.push_back(std::move(t)); }
+                    if ((o.best[act[i]] & 7) != (o.best[act[j]] & 7)) {
+                        std::vector<int> t = o.best;
+                        const int ki = t[act[i]] & 7, kj = t[act[j]] & 7;
+                        t[act[i]] = kj; t[act[j]] = ki;
+                        o.nb.push_back(std::move(t));
+                    }
+            // order inside a lane: a launch sent to the back of its lane (the heavier-first rule is not always the better one: which kernel
+            // of a chain meets which kernels of the other chains decides how far they stretch each other)
+            for (int u : act) {
+                const int k = o.best[u] & 7;
+                if (cnt[k] >= 2 && maxrank[k] < 14) { std::vector<int> t = o.best; t[u] = k | ((maxrank[k] + 1) << 3); o.nb.push_back(std::move(t)); }
+            }
         };
         auto propose = [&]() -> bool {
             if (!o.cands.empty()) { o.trial = o.cands.back(); o.cands.pop_back(); return true; }      // (the proposals of the first build)
@@ -1159,7 +1176,8 @@ int qc_launch_fock_classes(qc_system *S, const QcFockArgs &fa, float *class_ms, 
                 fprintf(stderr, "[tune] search ends after %d trials (%ld extra builds): %.4f ms; lanes:", o.trials, (long)o.spent, o.base_ms);
                 for (int k = 0; k < QC_NSTREAMS; ++k) {
                     bool any = false;
-                    for (size_t u = 0; u < units.size(); ++u) if (!units[u].empty() && o.best[u] == k) { fprintf(stderr, "%s u%zu(%.0f)", any ? "" : " [", u, S->unit_ms[u] * 1e3); any = true; }
+                    for (int rk = 0; rk < 16; ++rk)
+                        for (size_t u = 0; u < units.size(); ++u) if (!units[u].empty() && (o.best[u] & 7) == k && (o.best[u] >> 3) == rk) { fprintf(stderr, "%s u%zu(%.0f)%s", any ? "" : " [", u, S->unit_ms[u] * 1e3, rk ? "'" : ""); any = true; }
                     if (any) fprintf(stderr, " ]");
                 }
                 fprintf(stderr, "\n");
@@ -1180,6 +1198,14 @@ int qc_launch_fock_classes(qc_system *S, const QcFockArgs &fa, float *class_ms, 
 // nothing; one that runs hundreds of builds (geometry loops, benchmarks) converges to the searched assignment at a bounded overhead
 // and then stops (a whole sweep of the neighbourhood without a gain, or QC_SEARCH_TRIALS trials); the result goes to a process-wide cache keyed by
 // the shape of the work lists.  The stream assignment does not change results (integer accumulation), only time.
+// (measurement hook: end the search here and now with what it has found - a harness that is about to time builds calls it so that no
+// instalment falls into its timed region)
+void qc_assignment_freeze(qc_system *S) {
+    qc_system::QcOnline &o = S->on;
+    if (o.settled) return;
+    if (!o.best.empty() && S->unit_stream != o.best) { S->unit_stream = o.best; S->assign_gen += 1; }
+    o.frozen = true; o.settled = true;
+}
 void qc_online_reset(qc_system *S, bool frozen) {
     S->on = qc_system::QcOnline{};
     S->on.frozen = frozen; S->on.settled = frozen;

@@ -283,6 +283,7 @@ int qc_one_electron_device(qc_system *S, int which /* 0 S, 1 T, 2 V */, double *
 int qc_launch_fock_classes(qc_system *S, const QcFockArgs &a, float *class_ms /*nullable*/, float *unit_ms = nullptr /*nullable, 14*/, bool nofork = false);
 // hipEvent time of a build inside an SCF pass that ran under stream assignment `gen` (no-op once the choice is made)
 void qc_fock_feedback(qc_system *S, float build_ms, unsigned gen);
+void qc_assignment_freeze(qc_system *S);
 bool qc_fock_can_speculate(const qc_system *S);            // the next build may be issued with a device-side fork (tuned, device join, fixed point)
 void qc_spec_release(hipStream_t st, unsigned *words, unsigned seq, const double *scal, int n, int nspin, double eps, unsigned *h_cancel,
                      unsigned *h_seq, unsigned seqval);

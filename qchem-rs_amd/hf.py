@@ -43,7 +43,7 @@ EXPORTS = ["qc_system_create", "qc_system_destroy", "qc_nbasis", "qc_nelectrons"
            "qc_comm_init", "qc_set_shard", "qc_plan_shard", "qc_set_stream", "qc_device_ready", "qc_work_stats_get",
            "qc_fock_profile", "qc_plan_shard_quartets", "qc_scf_begin_rhf", "qc_scf_begin_uhf", "qc_scf_iterate",
            "qc_scf_orbital_energies", "qc_scf_density", "qc_scf_spin_square", "qc_scf_timings", "qc_scf_end", "qc_fock_profile_tiers", "qc_unit_quartets", "qc_sym_eig_warm", "qc_set_fock_mode", "qc_scf_tensor_ms", "qc_set_accumulation", "qc_set_schwarz", "qc_scf_matrix", "qc_rccl_info", "qc_measure_peaks",
-           "qc_scf_set_stop_rule", "qc_scf_counters", "qc_debug_ket_entry", "qc_dispatch_lanes"]
+           "qc_scf_set_stop_rule", "qc_scf_counters", "qc_debug_ket_entry", "qc_dispatch_lanes", "qc_freeze_assignment"]
 
 
 class QcError(RuntimeError):
@@ -241,6 +241,10 @@ class System:
 
     def comm_init(self, uid: bytes, rank: int, nranks: int):
         _check(lib().qc_comm_init(self._h, uid, rank, nranks), "qc_comm_init")
+
+    def freeze_assignment(self):
+        """End the search for the stream assignment of the build's launches with what it has found (before timing builds)."""
+        _check(lib().qc_freeze_assignment(self._h), "qc_freeze_assignment")
 
     def dispatch_lanes(self):
         """(number of dispatch lanes, side stream behind every assignment slot, whether slot 0 is the pipe of the handle's own stream)."""
