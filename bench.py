@@ -87,10 +87,10 @@ def timed_scf_passes(q, sysh, host, sync, steps, warmup, world_single=True):
     frozen = st.counters()["assign_frozen"] > 0
     st.close()
     # The stream assignment of the build's launches is refined online from the passes' own build times (no tuner run, qc_fock.hip): more
-    # untimed SCF runs until that search has ended (at most 24), so that the timed passes measure the steady state and not the search.
+    # untimed SCF runs until that search has ended (at most 40), so that the timed passes measure the steady state and not the search.
     # (multi-rank: every rank runs its own search on its shard; the decision to go on warming up is taken together - max over the ranks)
     warm_runs = 1
-    while host.max(0.0 if frozen else 1.0) > 0.0 and warm_runs < 24:
+    while host.max(0.0 if frozen else 1.0) > 0.0 and warm_runs < 40:
         st = q.ScfStepper(sysh, stop_rule=EPS)
         for k in range((kconv + 1) if kconv is not None else 30):
             st.iterate()

@@ -285,6 +285,7 @@ int roothaan_small(qc_system *S, ScfWork &W, DeviceDiis &diis, const double *dG,
     a.scal_out = tl.scal_out; a.ctl_all = tl.ctl_all; a.ctl_out = tl.ctl_out; a.fxs_out = tl.fxs_out; a.imax = S->imax;
     a.seq_out = tl.seq_out; a.seq = tl.seq;
     a.fork_words = tl.fork_words; a.fork_seq = tl.fork_seq; a.eps = tl.eps; a.h_cancel = tl.h_cancel;
+    a.tl = S->tl_cur ? S->tl_cur + QC_TL_W * (QC_NUNITS + 2) : nullptr;
     W.cold[spin] = false;
     static const bool force_jacobi = getenv("QC_EIG_JACOBI") != nullptr;
     int rc;
@@ -294,6 +295,7 @@ int roothaan_small(qc_system *S, ScfWork &W, DeviceDiis &diis, const double *dG,
     }
     QcSmallArgs pre = a;
     pre.phases = 1; pre.ctl_all = nullptr; pre.seq_out = nullptr; pre.fork_words = nullptr;
+    if (a.tl) a.tl += QC_TL_W;                              // (the second launch of the pass has its own slot)
     if ((rc = qc_scf_small_launch(st, pre)) != QC_OK) return rc;
     if (qc_tri_ok(n) && !force_jacobi && !W.rotations_only) {
         W.cold[spin] = true;
@@ -490,7 +492,13 @@ int qc_fock_build_device(qc_system *S, const double *dDa, const double *dDb, dou
     // kernel that releases the fork word - qc_fock_prepare_device for exactly these densities - and the planes clean)
     if (fork_seq && !(ready && S->gt_clean)) return QC_ERR_INVALID;
     QcFockArgs a{};
-    a.nrep = QC_NREP; a.rep_stride = nspin * nn; a.fxs = fxs; a.fx_lo = plane; a.fork_seq = fork_seq;
+    // Replicas in use (the planes keep their layout): 8 for n <= 64, all 32 above.  Replicas spread the atomics of hot elements, and the
+    // closing fold reads and zeroes every one of them: at n = 58 that is 1.7 MB with 32 replicas, and the H2O/cc-pVTZ iteration takes 0.308 ms
+    // with 8 against 0.313 with 32 (0.312 with 16, 0.319 with 4, 0.349 with 2; three alternating runs each); benzene/cc-pVDZ (n = 114) shows
+    // no difference between 8, 16 and 32.  QC_NREP_USE: experiment switch.
+    static const int nrep_env = getenv("QC_NREP_USE") ? std::max(1, std::min(QC_NREP, atoi(getenv("QC_NREP_USE")))) : 0;
+    const int nrep_use = nrep_env ? nrep_env : (n <= 64 ? 8 : QC_NREP);
+    a.nrep = nrep_use; a.rep_stride = nspin * nn; a.fxs = fxs; a.fx_lo = plane; a.fork_seq = fork_seq;
     if (!ready) {
         QC_HIP_CHECK(hipMemsetAsync(S->d_Gtmp, 0, (fx ? 2 : 1) * plane * sizeof(double), st));
         if (fx) qc_fx_scale(st, n, dDa, uhf ? dDb : nullptr, S->imax, S->d_fxs);      // this build's fixed-point unit, from its densities
@@ -503,18 +511,27 @@ int qc_fock_build_device(qc_system *S, const double *dDa, const double *dDb, dou
         a.Dj = dDa; a.Dk0 = dDa; a.Dk1 = nullptr; a.cK = 0.5;
     }
     a.G0 = S->d_Gtmp; a.G1 = S->d_Gtmp + nn;
+    // (QC_FOLD_JOIN: the closing fold waits for the side streams' markers itself instead of sitting behind the one-lane waiting kernel - one
+    // dependent launch less, 1 us per H2O/cc-pVTZ pass on the device timeline, nothing measurable per iteration (five alternating runs);
+    // OFF by default: every workgroup of the fold then polls one word, 813 of them at n = 114, and three of nine benzene/cc-pVDZ runs
+    // with that many pollers next to an experimental replica count lost a marker for 20 s - not understood, not reproduced since, not shipped)
+    static const bool fold_join = getenv("QC_FOLD_JOIN") != nullptr;
+    a.fold_joins = fx && !S->comm && S->nranks == 1 && fold_join;
     int rc = qc_launch_fock_classes(S, a, nullptr, nullptr, ready);
     if (rc != QC_OK) return rc;
     if (fx && !S->comm && S->nranks == 1) {
-        // (one launch instead of fold + symmetrise: nothing needs the folded planes)
-        qc_fold_symmetrize(st, n, QC_NREP, nspin * nn, S->d_Gtmp, plane, dGa, dH, dH ? dFa : nullptr, fxs);
-        if (two) qc_fold_symmetrize(st, n, QC_NREP, nspin * nn, S->d_Gtmp + nn, plane, dGb, dH, dH ? dFb : nullptr, fxs);
+        // (one launch instead of fold + symmetrise: nothing needs the folded planes; and the join of the side streams in the same launch)
+        const bool fj = S->fold_join_pending;
+        S->fold_join_pending = false;
+        qc_fold_symmetrize(st, n, nrep_use, nspin * nn, S->d_Gtmp, plane, dGa, dH, dH ? dFa : nullptr, fxs, S->tl_cur ? S->tl_cur + QC_TL_W * (QC_NUNITS + 1) : nullptr,
+                           fj ? S->d_join : nullptr, S->join_target, S->h_join_timeout, S->wait_limit);
+        if (two) qc_fold_symmetrize(st, n, nrep_use, nspin * nn, S->d_Gtmp + nn, plane, dGb, dH, dH ? dFb : nullptr, fxs);
         else if (uhf) QC_HIP_CHECK(hipMemcpyAsync(dGb, dGa, nn * sizeof(double), hipMemcpyDeviceToDevice, st));
         S->gt_clean = true; S->gt_clean_nspin = nspin;      // every replica element of the planes in use was read and zeroed
         if (f_done) *f_done = dH != nullptr && dFa != nullptr && (!uhf || (two && dFb != nullptr));
         return QC_OK;
     }
-    qc_reduce_replicas(st, nspin * nn, QC_NREP, nspin * nn, S->d_Gtmp, S->d_Gred, fx, plane);
+    qc_reduce_replicas(st, nspin * nn, nrep_use, nspin * nn, S->d_Gtmp, S->d_Gred, fx, plane);
     if (S->comm) {
         // partial Fock matrices -> full, one all-reduce per build ([Ga|Gb] concatenated for UHF; hi and lo planes back to
         // back).  Fixed-point partials are summed as integers: the result is bit-identical on every rank, whatever the ring
@@ -640,7 +657,7 @@ struct qc_scf_state {
         if (S && S->prep_owner == this) { S->prepared = false; S->prep_owner = nullptr; }
         delete diis[0]; delete diis[1];
         if (S && S->spec.owner == this) { S->spec.pending = false; S->spec.owner = nullptr; }
-        if (S && S->stream) { (void)hipStreamSynchronize(S->stream); qc_gate_quiet(S); }
+        if (S && S->stream) { (void)hipStreamSynchronize(S->stream); qc_gate_quiet(S); qc_tl_dump(S); }
         for (auto &set : evs) for (hipEvent_t e : set) if (e) (void)hipEventDestroy(e);
         if (h_cancel) (void)hipHostFree(h_cancel);
     }
@@ -797,6 +814,8 @@ static int scf_iterate(qc_scf_state *st, double *energy, double *rms_out, bool m
     const int nspin = st->uhf ? 2 : 1;
     int rc;
     const double th0 = now_ms();
+    qc_stamp("enter pass");
+    if ((rc = qc_tl_begin_pass(S)) != QC_OK) return rc;
     st->ev_cur ^= 1;
     hipEvent_t *const ev = st->evs[st->ev_cur];
     hipEvent_t const ev0 = ev[0], ev1 = ev[1], ev2 = ev[2];
@@ -833,6 +852,7 @@ static int scf_iterate(qc_scf_state *st, double *energy, double *rms_out, bool m
         st->cur_build_tuned = false; st->cur_build_gen = S->assign_gen;
     } else {
         QC_HIP_CHECK(hipEventRecord(ev0, sm));
+        qc_stamp("ev0");
         const int tunes0 = S->tune_count;
         const double tt0 = now_ms();
         if ((rc = qc_fock_build_device(S, st->D[0].p, st->uhf ? st->D[1].p : nullptr, Gcur, st->uhf ? Gcur + nn : nullptr, st->uhf,
@@ -841,8 +861,10 @@ static int scf_iterate(qc_scf_state *st, double *energy, double *rms_out, bool m
         if (st->cur_build_tuned) st->ms_tuner += now_ms() - tt0;
         st->cur_build_gen = S->assign_gen;
     }
+    qc_stamp("build out");
     scf_flush_timing(st);                                                 // (the previous pass's times, now that this pass's build is out)
     if (!spec_hit) QC_HIP_CHECK(hipEventRecord(ev1, sm));
+    qc_stamp("flush timing, ev1");
     // UHF: the two spins' steps are independent (uhf.rs:84-135 runs them one after the other) - the beta step goes to a side stream on
     // another dispatch pipe, behind an event of the build's closing kernel, and meets the handle's stream again before the scalars
     // (device-side join).  Same kernels, same arithmetic, per spin: results are bit for bit those of the serial order (QC_NO_SPIN_PARALLEL).
@@ -927,7 +949,9 @@ static int scf_iterate(qc_scf_state *st, double *energy, double *rms_out, bool m
     if (want_spec && !release_in_kernel)
         qc_spec_release(sm, S->d_join, spec_seq, multi ? reinterpret_cast<const double *>(W.d_sync) : W.h_scal, n, nspin, st->eps_hint, st->h_cancel,
                         seq_wait ? h_seq : nullptr, st->pass_seq + 1);
+    qc_stamp("roothaan out");
     QC_HIP_CHECK(hipEventRecord(ev2, sm));
+    qc_stamp("ev2");
     if (want_spec) {
         // the next pass's build, behind everything above in the handle's stream and behind the fork word on the side streams
         hipEvent_t *const evn = st->evs[st->ev_cur ^ 1];
@@ -969,6 +993,7 @@ static int scf_iterate(qc_scf_state *st, double *energy, double *rms_out, bool m
         if (!st->stored && S->prep_enqueued && !want_spec) QC_HIP_CHECK(wait_event(ev2));
     } else QC_HIP_CHECK(wait_event(ev2));
     const double th2 = now_ms();
+    qc_stamp("pass seen");
     if ((rc = qc_join_check(S)) != QC_OK) return rc;                     // (the join of this pass's build is in front of everything waited for)
     if (!want_spec) qc_gate_quiet(S);                                    // (nothing of this handle waits on the device any more)
     if (!ranks_agree()) { fprintf(stderr, "qchem_hip: rank %d: the ranks' SCF scalars differ - replicated state diverged\n", S->rank); return QC_ERR_RCCL; }
@@ -1043,6 +1068,8 @@ static int scf_iterate(qc_scf_state *st, double *energy, double *rms_out, bool m
     }
     st->g_cur ^= 1;
     st->passes += 1;
+    qc_stamp("pass end");
+    qc_stamp_flush();
     if (energy) *energy = e_sum;
     if (rms_out) *rms_out = st->uhf ? rms_sum / 2.0 : rms_sum;
     return QC_OK;

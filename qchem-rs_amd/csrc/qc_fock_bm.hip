@@ -646,6 +646,7 @@ __device__ __forceinline__ void qc_bm_segment(const QcBmArgs &a, const int s, co
 template <int LCD, int HI>
 __global__ __launch_bounds__(qc_bm_waves(LCD, HI) * 64) void qc_fock_bm_kernel(const QcBmArgs a) {
     if (qc_build_cancelled(a.base)) return;
+    qc_tl_stamp(a.base.tl, 0);
     int s = 0;
     while (s + 1 < a.nseg && (int)blockIdx.x >= a.seg_end[s]) ++s;
     const int b0 = s ? a.seg_end[s - 1] : 0;
@@ -669,6 +670,7 @@ __global__ __launch_bounds__(qc_bm_waves(LCD, HI) * 64) void qc_fock_bm_kernel(c
             default: break;
         }
     }
+    qc_tl_stamp(a.base.tl, 1);
 }
 
 template <int LCD, int HI>

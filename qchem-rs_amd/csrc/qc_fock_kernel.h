@@ -48,7 +48,18 @@ struct QcKernelArgs {
     double *schwarz_out;      // if non-null: no digestion - the slots are (P|P) quartets and sqrt(max |(ab|cd)|) goes to [P]
     const unsigned *cancel;   // non-null: a speculative build (issued before the host knew that the SCF pass in front of it would not be the
     unsigned cancel_seq;      // last one) - its kernels return at once when *cancel == cancel_seq (qc_spec_release_kernel, qc_scf_small.hip)
+    unsigned long long *tl;   // non-null (QC_DEV_TIMELINE): QC_TL_W clock words of this launch - [0] start of workgroup 0, [1 + (workgroup & 31)] ends
 };
+
+// Device-side timeline of an SCF pass (QC_DEV_TIMELINE=1): every kernel of the pass leaves the clock of its first start and its last end -
+// what rocprofv3's kernel trace shows too, but without the profiler's own packets between the dispatches.
+__device__ __forceinline__ void qc_tl_stamp(unsigned long long *tl, int end) {
+    if (tl != nullptr && threadIdx.x == 0 && (end || blockIdx.x == 0)) {
+        const unsigned long long t = wall_clock64();
+        if (end) __hip_atomic_store(tl + 1 + (blockIdx.x & 31), t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        else __hip_atomic_store(tl, t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
 
 // (every class kernel starts with this: one scalar load)
 __device__ __forceinline__ bool qc_build_cancelled(const QcKernelArgs &a) {
@@ -979,6 +990,7 @@ template <int LAB, int TIER>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(((TIER == 0 && LAB <= 2) || TIER == 2) ? 2 : 1)))
 void qc_fock_tier_kernel(const QcTierArgs a) {
     if (qc_build_cancelled(a.base)) return;
+    qc_tl_stamp(a.base.tl, 0);
     // the high-L tiers are few, long, latency-bound waves: let them win issue arbitration against the many short
     // low-L waves they share a SIMD with
     if constexpr (TIER >= 1) __builtin_amdgcn_s_setprio(3);
@@ -999,6 +1011,7 @@ void qc_fock_tier_kernel(const QcTierArgs a) {
 #undef QC_CASE_V
     }
 #undef QC_CASE
+    qc_tl_stamp(a.base.tl, 1);
 }
 
 // (round 3) ONE launch for the wide-ket buckets (LCD >= 4) of the bra classes LAB = 0, 1 and 2 of a basis with f functions: three launches of
@@ -1013,6 +1026,7 @@ template <int V>     // (every instance lives in its own translation unit: gen/q
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(QC_T1LOW_WAVES(V))))
 void qc_fock_tier1_low_kernel(const QcTierArgs a) {
     if (qc_build_cancelled(a.base)) return;
+    qc_tl_stamp(a.base.tl, 0);
     __builtin_amdgcn_s_setprio(3);
     int s = 0;
     while (s + 1 < a.nseg && (int)blockIdx.x >= a.seg_end[s]) ++s;
@@ -1044,6 +1058,7 @@ void qc_fock_tier1_low_kernel(const QcTierArgs a) {
         }
     }
 #undef QC_CASE
+    qc_tl_stamp(a.base.tl, 1);
 }
 template <int V>
 int qc_launch_tier1_low_impl(int grid, size_t lds, hipStream_t st, const QcTierArgs &a) {

@@ -176,11 +176,16 @@ struct qc_system {
     double *d_Dj = nullptr;
     double *d_fxs = nullptr;                 // [2^S, 2^-S]: fixed-point scale of the current build
     int *d_flag = nullptr;
+    // QC_DEV_TIMELINE: ring of QC_TL_PASSES sets of QC_TL_SLOTS kernel slots (QC_TL_W clock words each, qc_tl_stamp), one set per SCF pass; tl_cur = the set
+    // of the pass being enqueued (null: off, or the ring is full); dumped when an SCF state of the handle ends (qc_tl_dump)
+    unsigned long long *d_tl = nullptr, *tl_cur = nullptr;
+    int tl_pass = 0;
     unsigned *d_join = nullptr;              // [0] counter of the device-side join of a build's side streams (qc_join_mark / qc_join_wait);
                                              // [1] fork word: number of the last pass whose densities are final (device-side fork of a speculative build);
                                              // [2] number of the speculative build that was cancelled on the device (its class kernels return at once)
     int *h_join_timeout = nullptr;           // pinned: set by a device-side wait that gave up (the launches it waited for never finished)
     unsigned join_target = 0;
+    bool fold_join_pending = false;          // the last build left its join to the closing fold (QcFockArgs::fold_joins): join_target is what it waits for
     unsigned fork_seq = 0;                   // last value promised to the fork word: the speculative build of pass k + 1 waits for fork_seq = k's number
     long long wait_limit = 0;                // device-side waits give up after this many ticks of the 100 MHz clock (qc_wait_limit)
     std::atomic<bool> waits_in_flight{false}; // device-side waits were issued and the host has not seen the handle's stream drained since (qc_gate)
@@ -210,7 +215,7 @@ struct qc_system {
         size_t nb_pos = 0;
         std::vector<std::vector<int>> cands;   // proposals of the first build (longest-first on in-build durations): tried before random neighbours
         double base_ms = 0.0;                  // build time of `best` as the search measured it
-        int trials = 0, rejects = 0;
+        int trials = 0, rejects = 0, kicks = 0;   // (kicks: restarts of the local search from a perturbed copy of the best assignment known)
         long builds = 0, spent = 0;            // builds asked of this handle / extra builds the search has run
         unsigned rng = 2463534242u;
         double seen_sum = 0.0; long seen_n = 0;   // build times reported by SCF passes under the current assignment
@@ -274,6 +279,9 @@ struct QcFockArgs {
     // device-side fork (speculative build of the next SCF pass): side streams start with a one-lane kernel that waits for the fork word to
     // reach fork_seq; the class kernels return at once when the cancel word equals it
     unsigned fork_seq = 0;   // 0: no device fork
+    // the caller's next kernel on the handle's stream - the closing fold - waits for the join counter itself (qc_system::fold_join_pending
+    // says that it must): no one-lane waiting kernel in front of it, one dependent launch less at the end of the build
+    bool fold_joins = false;
 };
 int qc_launch_eri_full(qc_system *S, double *d_out);
 int qc_schwarz_device(qc_system *S);     // fills pairQ / imax from the (P|P) quartets, then screens the work lists
@@ -292,6 +300,10 @@ void qc_spec_release(hipStream_t st, unsigned *words, unsigned seq, const double
 hipStream_t qc_spin_fork(qc_system *S);
 int qc_spin_join(qc_system *S);
 int qc_join_check(qc_system *S);                           // after a host wait: QC_ERR_HIP if a device-side wait of the handle gave up
+// host-side time stamps of one SCF pass (QC_ISSUE_DEBUG: where the host's time goes between the end of a pass and the launches of the next
+// build; printed as differences at the end of every pass).  No-ops unless the variable is set.
+void qc_stamp(const char *what);
+void qc_stamp_flush();
 void qc_gate_quiet(qc_system *S);                          // the host has seen the handle's stream drained: none of its waits is in flight
 // (scale_done: the fixed-point unit of these densities is already in d_fxs - written by the kernel that produced them)
 int qc_fock_prepare_device(qc_system *S, const double *dDa, const double *dDb, bool uhf, const void *owner, bool scale_done = false);
@@ -338,7 +350,8 @@ void qc_symmetrize_add(hipStream_t st, int n, const double *Gt, size_t lo_off, d
 // fixed-point builds on one rank: replica fold + symmetrisation (+ F = H + G) in one launch
 // (the replicas are zeroed as they are read: the accumulator planes are clean again when it returns)
 void qc_fold_symmetrize(hipStream_t st, int n, int nrep, size_t rep_stride, double *Gt, size_t lo_off, double *G, const double *H, double *F,
-                        const double *fxs);
+                        const double *fxs, unsigned long long *tl = nullptr, const unsigned *join_cnt = nullptr, unsigned join_target = 0,
+                        int *timeout_flag = nullptr, long long limit = 0);
 // out[p * count + x] = sum_r Gt[p * plane_stride + r * stride + x], p < (fx ? 2 : 1)
 void qc_reduce_replicas(hipStream_t st, size_t count, int nrep, size_t stride, const double *Gt, double *out, bool fx, size_t plane_stride);
 void qc_count_diff(hipStream_t st, size_t count, const double *a, const double *b, int *flag);
@@ -411,8 +424,14 @@ struct QcSmallArgs {
     // non-null: a speculative build of the next pass is queued behind this kernel - release the fork word fork_words[1] = fork_seq at the
     // end; before that, if the pass meets the reference's stopping rule at eps (> 0), cancel that build (fork_words[2], *h_cancel)
     unsigned *fork_words; unsigned fork_seq; double eps; unsigned *h_cancel;
+    unsigned long long *tl;        // non-null: [start, end] clock of this launch (QC_DEV_TIMELINE)
 };
 int qc_scf_small_launch(hipStream_t st, const QcSmallArgs &a);
+constexpr int QC_TL_W = 34;   // (words per kernel slot: the launch's end is the maximum over 32 end words - plain stores, no atomics: 8000
+                              // workgroups hammering ONE word with atomic min / max stretched an H2O/cc-pVTZ build from 172 to 231 us)
+constexpr int QC_TL_PASSES = 64, QC_TL_SLOTS = QC_NUNITS + 4;       // launch units | join wait | fold | Roothaan kernel, first / second launch
+int qc_tl_begin_pass(qc_system *S);                                 // (no-op unless QC_DEV_TIMELINE is set)
+void qc_tl_dump(qc_system *S);
 size_t qc_scf_small_lds_bytes(int n);
 
 #define QC_HIP_CHECK(expr)                                                                  \

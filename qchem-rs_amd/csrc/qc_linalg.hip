@@ -1067,7 +1067,25 @@ __global__ void qc_symmetrize_add_kernel(int n, const double *Gt, size_t lo_off,
 // The replicas it has read are zeroed on the way: the next build finds clean accumulator planes without a 1.7 MB memset of its own.
 __global__ __launch_bounds__(64) void qc_fold_symmetrize_kernel(int n, int nrep, size_t rep_stride, long long *__restrict__ Gh, size_t lo_off,
                                                                 double *__restrict__ G, const double *__restrict__ H, double *__restrict__ F,
-                                                                const double *__restrict__ fxs) {
+                                                                const double *__restrict__ fxs, unsigned long long *tl,
+                                                                const unsigned *join_cnt, unsigned join_target, int *timeout_flag, long long limit) {
+    if (tl != nullptr && threadIdx.x == 0 && blockIdx.x == 0) tl[0] = wall_clock64();
+    if (join_cnt != nullptr) {
+        // the device-side join of the build's side streams (qc_join_wait_kernel's loop, qc_fock.hip), by every workgroup of this launch
+        // itself: it sits behind the last class kernel of the handle's own stream and goes on when the other streams' markers are in
+        long long t0 = 0;
+        unsigned it = 0;
+        while ((int)(__hip_atomic_load(join_cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - join_target) < 0) {
+            __builtin_amdgcn_s_sleep(16);
+            if ((++it & 63u) == 0) {
+                const long long t = wall_clock64();
+                if (t0 == 0) t0 = t;
+                else if (t - t0 > limit) { if (threadIdx.x == 0) __hip_atomic_store(timeout_flag, 2, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM); break; }
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    }
+    struct Leave { unsigned long long *tl; __device__ ~Leave() { if (tl != nullptr && threadIdx.x == 0) tl[1 + (blockIdx.x & 31)] = wall_clock64(); } } leave{tl};
     // lane = (element of this workgroup's 16, quarter of the replicas): one batch of loads per lane, the quarters meet by shuffles
     const int e = threadIdx.x >> 2, part = threadIdx.x & 3;
     const int x = blockIdx.x * 16 + e;
@@ -1103,9 +1121,9 @@ __global__ __launch_bounds__(64) void qc_fold_symmetrize_kernel(int n, int nrep,
     if (F) { F[x] = 1.0 * H[x] + 1.0 * g; F[xt] = 1.0 * H[xt] + 1.0 * g; }
 }
 void qc_fold_symmetrize(hipStream_t st, int n, int nrep, size_t rep_stride, double *Gt, size_t lo_off, double *G, const double *H, double *F,
-                        const double *fxs) {
+                        const double *fxs, unsigned long long *tl, const unsigned *join_cnt, unsigned join_target, int *timeout_flag, long long limit) {
     hipLaunchKernelGGL(qc_fold_symmetrize_kernel, dim3((n * n + 15) / 16), dim3(64), 0, st, n, nrep, rep_stride,
-                       reinterpret_cast<long long *>(Gt), lo_off, G, H, F, fxs);
+                       reinterpret_cast<long long *>(Gt), lo_off, G, H, F, fxs, tl, join_cnt, join_target, timeout_flag, limit);
 }
 void qc_symmetrize_add(hipStream_t st, int n, const double *Gt, size_t lo_off, double *G, const double *H, double *F, const double *fxs) {
     if (fxs) hipLaunchKernelGGL(qc_symmetrize_add_kernel<true>, dim3((n * n + 255) / 256), dim3(256), 0, st, n, Gt, lo_off, G, H, F, fxs);

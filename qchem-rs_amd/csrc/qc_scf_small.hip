@@ -176,6 +176,7 @@ __global__ __launch_bounds__(QCS_T) void qc_scf_small_kernel(const QcSmallArgs a
     int *partner = reinterpret_cast<int *>(gsh + 12 * 16), *rank_s = partner + 64, *flg = rank_s + 64;
     const int tid = threadIdx.x, rr = tid >> 6, cc = tid & 63;           // this thread's elements: rows rr + 4 q, column cc
     const bool cok = cc < n;
+    if (a.tl != nullptr && tid == 0) a.tl[0] = wall_clock64();
     bool ok = true;                                                      // (uniform) the eigenvectors for `post` exist
     double *Cpv = B0;                                                    // ... and the block they are in
 #ifdef QC_SMALL_TIMING
@@ -622,6 +623,7 @@ __global__ __launch_bounds__(QCS_T) void qc_scf_small_kernel(const QcSmallArgs a
             __hip_atomic_store(a.fork_words + 1, a.fork_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
         }
     }
+    if (a.tl != nullptr && tid == 0) a.tl[1] = wall_clock64();
     if (a.seq_out) {     // the host polls this word instead of the stream's event (which the packet processor signals some microseconds later)
         __syncthreads();
         if (tid == 0) __hip_atomic_store(a.seq_out, a.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);

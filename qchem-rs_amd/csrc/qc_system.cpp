@@ -383,7 +383,13 @@ void qc_build_model(qc_system *S) {
         S->merge_t1 = fket && std::max(nseg[0], std::max(nseg[1], nseg[2])) <= 12 && getenv("QC_NO_T1_MERGE") == nullptr;
         bool has01 = false, has10 = false;
         for (const auto &c : S->classes) if (c.bm) { has01 = has01 || (c.LCD == 0 && c.LAB >= 3); has10 = has10 || (c.LCD == 1 && c.LAB <= 2); }
-        S->merge_bm = has01 && has10 && getenv("QC_NO_BM_MERGE") == nullptr;
+        // (a matter of launch count, so only for small builds: one launch less is 5 % of an H2O/cc-pVTZ build (32 k quartets, 0.17 ms); in a long
+        // build the merged launch is the longest chain by itself - benzene/cc-pVDZ, 1.1 M quartets: builds 1.379 ms apart against 1.405
+        // merged, three alternating runs each.  QC_BM_MERGE_MAX: the limit in quartets)
+        size_t q_all = 0;
+        for (const auto &c : S->classes) q_all += c.tasks.size();
+        static const long merge_max = getenv("QC_BM_MERGE_MAX") ? atol(getenv("QC_BM_MERGE_MAX")) : 262144;
+        S->merge_bm = has01 && has10 && (long)q_all <= merge_max && getenv("QC_NO_BM_MERGE") == nullptr;
     }
     qc_build_shards(S);
 }
