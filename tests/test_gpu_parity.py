@@ -645,6 +645,77 @@ def test_spin_parallel_roothaan_steps_do_not_change_a_bit(mol, basis, na, nb, mo
     assert np.array_equal(wp[0], ws[0]) and np.array_equal(wp[1], ws[1])
 
 
+def test_assignment_search_and_replica_count_never_show(monkeypatch):
+    """Which launch goes to which dispatch lane is searched while the handle is used (qc_fock.hip: trials of neighbouring assignments,
+    restarts from perturbed copies of the best, finals) and how many accumulator replicas are in use is a tuning matter (8 for n <= 64):
+    neither may change a bit of any build or of any SCF run - and the search ends, by itself or when a harness says so."""
+    import qchem_rs_amd as q
+    m = load_system("water", "cc-pVTZ")
+    D = _rand_sym(58, 47)
+    monkeypatch.setenv("QC_NO_ASSIGN_CACHE", "1")              # (a fresh search, whatever this process has learned before)
+    s = q.System(m)
+    G0 = s.fock_rhf(D)
+    first, trials = None, 0.0
+    for run in range(14):
+        st = q.ScfStepper(s, stop_rule=1e-10)
+        es = []
+        for k in range(40):
+            e, rms = st.iterate()
+            es.append(e)
+            if rms < 1e-10:
+                break
+        c = st.counters()
+        st.close()
+        trials = max(trials, c["assign_trials"])
+        if first is None:
+            first = es
+        assert es == first, run                                  # every pass of every run: the same bits, whatever was being tried
+    assert trials > 0                                            # (the search did run inside these SCF runs)
+    assert np.array_equal(s.fock_rhf(D), G0)
+    s.freeze_assignment()
+    st = q.ScfStepper(s, stop_rule=1e-10)
+    st.iterate()
+    assert st.counters()["assign_frozen"] > 0
+    st.close()
+    s.close()
+    for nrep in ("32", "3"):                                     # integer sums do not depend on how they are split over replicas
+        monkeypatch.setenv("QC_NREP_USE", nrep)
+        s2 = q.System(m)
+        assert np.array_equal(s2.fock_rhf(D), G0), nrep
+        s2.close()
+        monkeypatch.delenv("QC_NREP_USE")
+
+
+def test_device_timeline_and_host_stamps(monkeypatch, capfd):
+    """QC_DEV_TIMELINE / QC_ISSUE_DEBUG (diagnostics): every kernel of an SCF pass leaves its start and end on the device's
+    constant clock, the host its time stamps between the end of a pass and the launches of the next - printed when the SCF state ends /
+    after every pass, and switched on per pass."""
+    q, s, o = _sys("water", "cc-pVDZ")
+    st = q.ScfStepper(s)
+    st.iterate()                                                 # (not traced)
+    monkeypatch.setenv("QC_DEV_TIMELINE", "1")
+    for _ in range(3):
+        st.iterate()
+    monkeypatch.delenv("QC_DEV_TIMELINE")
+    e_traced, _ = st.iterate()
+    st.close()
+    err = capfd.readouterr().err
+    lines = [l for l in err.splitlines() if l.startswith("[timeline] pass")]
+    assert len(lines) == 3, err
+    for l in lines:
+        assert " fold " in l and " small " in l and " unit" in l, l
+        import re
+        spans = re.findall(r"(\w+) (\d+\.\d+)-(\d+\.\d+)", l)
+        assert len(spans) >= 3 and all(float(b) >= float(a) for _, a, b in spans), l
+    # the diagnostics do not touch the arithmetic
+    st2 = q.ScfStepper(s)
+    for _ in range(4):
+        st2.iterate()
+    e_plain, _ = st2.iterate()
+    st2.close()
+    assert e_plain == e_traced
+
+
 def test_dispatch_lanes_are_measured():
     """qc_lane_probe: the handle's side streams fall into dispatch lanes (streams that share a pipe wait for each other's grids); the
     assignment slots list every side stream once, the lanes first.  On an MI355X with GPU_MAX_HW_QUEUES=8 (set by hf.py) there are four."""
