@@ -267,9 +267,9 @@ int roothaan_enqueue(qc_system *S, ScfWork &W, DeviceDiis &diis, const double *d
 struct SmallTail { int nocc; double dfac; double *Dn; const double *Dold; double *scal_out; int *ctl_all, *ctl_out; double *fxs_out; unsigned *seq_out = nullptr; unsigned seq = 0;
                    unsigned *fork_words = nullptr; unsigned fork_seq = 0; double eps = 0.0; unsigned *h_cancel = nullptr; };
 int roothaan_small(qc_system *S, ScfWork &W, DeviceDiis &diis, const double *dG, const double *dD, double *dw_out, double *dC, int spin,
-                   double *dE, double *dF, bool have_F, const SmallTail &tl) {
+                   double *dE, double *dF, bool have_F, const SmallTail &tl, hipStream_t st_in = nullptr, int b = 0) {
     const int n = S->nbasis;
-    hipStream_t st = S->stream;
+    hipStream_t st = st_in ? st_in : S->stream;               // (`st_in`, `b`: the beta step of a spin-parallel pass - side stream, second set of work buffers)
     QcSmallArgs a{};
     a.n = n;
     a.F = have_F ? dF : nullptr; a.F_out = dF;
@@ -299,12 +299,12 @@ int roothaan_small(qc_system *S, ScfWork &W, DeviceDiis &diis, const double *dG,
     if ((rc = qc_scf_small_launch(st, pre)) != QC_OK) return rc;
     if (qc_tri_ok(n) && !force_jacobi && !W.rotations_only) {
         W.cold[spin] = true;
-        if ((rc = qc_eig_tridiag_start(st, n, W.Fps[spin].p, W.X0[0].p, W.tri[0].p)) != QC_OK) return rc;
-        a.phases = 6; a.V0 = W.X0[0].p; a.npass = 3;
+        if ((rc = qc_eig_tridiag_start(st, n, W.Fps[spin].p, W.X0[b].p, W.tri[b].p)) != QC_OK) return rc;
+        a.phases = 6; a.V0 = W.X0[b].p; a.npass = 3;
         return qc_scf_small_launch(st, a);
     }
-    if (W.have_prev[spin]) rc = qc_eig_device_warm(st, n, W.Fps[spin].p, W.CpPrev[spin].p, W.CpNew[spin].p, dw_out, W.ework[0].p, W.t1[0].p, W.t2[0].p, 40, 1e-9, W.ctl + 9);
-    else rc = qc_eig_device(st, n, W.Fps[spin].p, W.CpNew[spin].p, dw_out, W.ework[0].p, 40, 1e-9, W.ctl + 9);
+    if (W.have_prev[spin]) rc = qc_eig_device_warm(st, n, W.Fps[spin].p, W.CpPrev[spin].p, W.CpNew[spin].p, dw_out, W.ework[b].p, W.t1[b].p, W.t2[b].p, 40, 1e-9, W.ctl + 9);
+    else rc = qc_eig_device(st, n, W.Fps[spin].p, W.CpNew[spin].p, dw_out, W.ework[b].p, 40, 1e-9, W.ctl + 9);
     if (rc != QC_OK) return rc;
     a.phases = 4; a.Cp_in = W.CpNew[spin].p;
     return qc_scf_small_launch(st, a);
@@ -692,11 +692,13 @@ static int scf_begin(qc_system *S, bool uhf, int n_alpha, int n_beta, qc_scf_sta
     if (st->nocc[0] < 0 || st->nocc[1] < 0 || st->nocc[0] > n || st->nocc[1] > n) return QC_ERR_INVALID;
     const int nspin = uhf ? 2 : 1;
     st->W.rotations_only = uhf && st->nocc[0] != st->nocc[1];
-    // (not for open-shell runs: their saddle-point trajectories depend on every last bit - DESIGN.md 1 - and keep the arithmetic they were
-    // validated with; QC_NO_SMALL_FUSED: A/B switch, the generic launch sequence)
-    // (round 4: open-shell runs take it too when QC_OPEN_SHELL_FUSED is set - with the DIIS dot products in the generic sequence's summation
-    // order, QcSmallArgs::dots_generic; default decided by the bit-for-bit comparison of the O2-triplet trace)
-    static const bool open_fused = getenv("QC_OPEN_SHELL_FUSED") != nullptr;
+    // (QC_NO_SMALL_FUSED: A/B switch, the generic launch sequence.  Open-shell runs take the one-workgroup kernels too since the two spins'
+    // kernels run side by side - pre | Jacobi kernel | post per spin, O2 triplet/cc-pVDZ 0.130 ms of linear algebra per pass against 0.148
+    // for the generic sequence, 0.198 with the spins one after the other - with the DIIS dot products in the generic sequence's summation
+    // order, QcSmallArgs::dots_generic.  Their saddle-point trajectories depend on every last bit - DESIGN.md 1 - and the two paths differ
+    // in the last bit of the first pass's energy: O2 triplet reaches 1e-10 in 118 passes on this path and in 450 on the generic one, 15
+    // and 15 at the CLI's 1e-6, energies 8e-6 Eh apart there.  QC_NO_OPEN_SHELL_FUSED: A/B switch.)
+    static const bool open_fused = getenv("QC_NO_OPEN_SHELL_FUSED") == nullptr;
     st->W.small_fused = n <= QC_SMALL_MAXN && (!st->W.rotations_only || open_fused) && getenv("QC_NO_SMALL_FUSED") == nullptr;
     if ((rc = st->W.init(n, uhf ? 2 : 1)) != QC_OK) return rc;
     for (int s = 0; s < nspin; ++s) if (st->D[s].alloc(nn) != QC_OK || st->Dn[s].alloc(nn) != QC_OK) return QC_ERR_HIP;
@@ -926,7 +928,20 @@ static int scf_iterate(qc_scf_state *st, double *energy, double *rms_out, bool m
     const bool seq_wait = ((W.small_fused && !multi) || want_spec) && !st->event_wait;
     const unsigned spec_seq = want_spec ? ++S->fork_seq : 0;
     const bool release_in_kernel = want_spec && W.small_fused && !st->uhf && !multi && !st->event_wait;
-    if (W.small_fused) {
+    // UHF on the one-workgroup path: the two spins' kernels side by side as well - beta on a side stream of another dispatch pipe behind an
+    // event of the build's closing kernel, with the second set of work buffers; the kernel that joins the streams on the device also hands
+    // the control words over and stores the sequence word (qc_spin_join_end).  Same kernels per spin: bit for bit the serial order.
+    const bool small_par = W.small_fused && st->uhf && st->spin_parallel && S->nlanes >= 2 && !S->join_by_events && !multi && !want_spec;
+    if (small_par) {
+        hipStream_t side = qc_spin_fork(S);
+        if (!side) return QC_ERR_HIP;
+        for (int s = 0; s < nspin; ++s) {
+            SmallTail tl{st->nocc[s], 1.0, st->Dn[s].p, st->D[s].p, scal_out + 2 * s, nullptr, ctl_out, nullptr};
+            if ((rc = roothaan_small(S, W, *st->diis[s], Gcur + s * nn, st->D[s].p, st->ws.p + s * n, st->Cs.p + s * nn, s, dE[s], dF[s], have_F, tl,
+                                     s == 1 ? side : nullptr, s)) != QC_OK) return rc;
+        }
+        if ((rc = qc_spin_join_end(S, W.ctl, ctl_out, seq_wait ? h_seq : nullptr, st->pass_seq + 1)) != QC_OK) return rc;
+    } else if (W.small_fused) {
         for (int s = 0; s < nspin; ++s) {
             // (RHF, direct fixed-point builds: the kernel that forms the new density also leaves the next build's fixed-point unit)
             const bool scale_here = !st->uhf && !st->stored && S->accum_fx;

@@ -703,6 +703,45 @@ int qc_spin_join(qc_system *S) {
     return hipGetLastError() == hipSuccess ? QC_OK : QC_ERR_HIP;
 }
 
+// The join of the two spins' one-workgroup Roothaan kernels (scf_iterate: alpha on the handle's stream, beta on a side stream) that also
+// ends the pass: once the beta stream's marker is in, the sixteen control words go to the host and are cleared, then the pass's sequence
+// word - what the last spin's kernel does itself when the spins run one after the other (qc_scf_small.hip).
+__global__ void qc_spin_join_end_kernel(unsigned *cnt, unsigned target, int *timeout_flag, long long limit, int *ctl_all, int *ctl_out,
+                                        unsigned *h_seq, unsigned seq) {
+    if (threadIdx.x == 0) {
+        long long t0 = 0;
+        unsigned it = 0;
+        while ((int)(__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - target) < 0) {
+            __builtin_amdgcn_s_sleep(16);
+            if ((++it & 63u) == 0) {
+                const long long t = wall_clock64();
+                if (t0 == 0) t0 = t;
+                else if (t - t0 > limit) { __hip_atomic_store(timeout_flag, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM); break; }
+            }
+        }
+    }
+    __syncthreads();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    if (threadIdx.x < 16) {
+        int *p = ctl_all + threadIdx.x;
+        ctl_out[threadIdx.x] = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(p, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __threadfence_system();
+    __syncthreads();
+    if (threadIdx.x == 0 && h_seq) __hip_atomic_store(h_seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+int qc_spin_join_end(qc_system *S, int *ctl_all, int *ctl_out, unsigned *h_seq, unsigned seq) {
+    QcGateHold gate(S);
+    hipStream_t side = S->side[S->slot_side[S->lane0_is_main ? 1 : 0]];
+    S->spin_target += 1;
+    S->wait_limit = qc_wait_limit(S);
+    hipLaunchKernelGGL(qc_join_mark_kernel, dim3(1), dim3(64), 0, side, S->d_join + 4);
+    hipLaunchKernelGGL(qc_spin_join_end_kernel, dim3(1), dim3(64), 0, S->stream, S->d_join + 4, S->spin_target, S->h_join_timeout, S->wait_limit, ctl_all, ctl_out, h_seq, seq);
+    gate.waits = true;
+    return hipGetLastError() == hipSuccess ? QC_OK : QC_ERR_HIP;
+}
+
 // After a host wait that follows a device-joined build: did one of its waits give up?  Then the matrix it folded was not complete: the
 // call fails (last_error says why), the accumulator planes are no longer known to be clean, the counter and the host's target meet
 // again, and this handle joins through events from now on.

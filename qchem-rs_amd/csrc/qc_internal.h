@@ -299,6 +299,7 @@ void qc_spec_release(hipStream_t st, unsigned *words, unsigned seq, const double
 // handle's stream holds so far; join = the handle's stream waits for it (marker + waiting kernel, under the per-device gate)
 hipStream_t qc_spin_fork(qc_system *S);
 int qc_spin_join(qc_system *S);
+int qc_spin_join_end(qc_system *S, int *ctl_all, int *ctl_out, unsigned *h_seq, unsigned seq);   // (... and ends the pass: control words, sequence word)
 int qc_join_check(qc_system *S);                           // after a host wait: QC_ERR_HIP if a device-side wait of the handle gave up
 // host-side time stamps of one SCF pass (QC_ISSUE_DEBUG: where the host's time goes between the end of a pass and the launches of the next
 // build; printed as differences at the end of every pass).  No-ops unless the variable is set.

@@ -22,6 +22,10 @@ done
 cd $R
 python tools/make_profile_summary.py $TAG $O > $O/summary.txt 2>&1 || { cat $O/summary.txt; exit 1; }
 cat $O/summary.txt
+# the same passes without a profiler in the process: every kernel's own clock (QC_DEV_TIMELINE), and the O2 triplet's linear algebra
+WARM_RUNS=40 python tools/timeline_probe.py 2> $O/device_timeline_raw.txt || exit 1
+{ echo "# tools/timeline_probe.py (QC_DEV_TIMELINE=1): H2O/cc-pVTZ RHF, one SCF run after 40 warm-up runs; microseconds on the device's 100 MHz clock,"; echo "# from the end of the previous pass's last kernel; unitN = launch unit N of the build (qc_unit_of), small2 = second launch of a cold pass"; grep "timeline\]\|events of the same" $O/device_timeline_raw.txt | tail -17; } > profiles/${TAG}_device_timeline.txt
+python tools/open_shell_fused_probe.py > profiles/${TAG}_o2_triplet_linear_algebra.txt 2>&1 || exit 1
 python bench.py > $O/bench_default.json 2> $O/bench_default.err || exit 1
 cp bench_detail.json $O/bench_default_detail.json
 mkdir -p $O/profiles && cp profiles/${TAG}_* $O/profiles/
