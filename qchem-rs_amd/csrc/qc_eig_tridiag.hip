@@ -336,8 +336,10 @@ __device__ __forceinline__ int sturm_count(int n, const double *__restrict__ d, 
         for (int u = 0; u < 8; ++u) { dd[u] = d[i + u]; ee[u] = e2[i + u - 1]; }
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
+            // (a sign change = the sign bits differ: one xor, one shift, one add on the high words - as two compares, a mask xor and a
+            // conditional add the count was half of the loop's 17 instructions per step, and the loop is bound by issue)
             const double pn = fma(dd[u] - x, p, -(ee[u] * q));
-            cnt += ((pn < 0.0) != (p < 0.0)) ? 1 : 0;
+            cnt += (int)((unsigned)(__double2hiint(pn) ^ __double2hiint(p)) >> 31);
             q = p; p = pn;
         }
         const double s = fmax(fabs(p), fabs(q));
@@ -346,7 +348,7 @@ __device__ __forceinline__ int sturm_count(int n, const double *__restrict__ d, 
     }
     for (; i < n; ++i) {
         const double pn = fma(d[i] - x, p, -(e2[i - 1] * q));
-        cnt += ((pn < 0.0) != (p < 0.0)) ? 1 : 0;
+        cnt += (int)((unsigned)(__double2hiint(pn) ^ __double2hiint(p)) >> 31);
         q = p; p = pn;
     }
     return cnt;

@@ -79,24 +79,43 @@ static void qc_bm_device_lists(const qc_system *S, int lcd, const std::vector<Qc
 
 struct QcLaunchPlan;
 static void drop_launch_plan(qc_system *S);
+// (the work lists of all classes live in ONE device buffer, qc_system::d_lists - the classes' pointers point into it: an allocation and a
+// synchronous copy per list, up to three per class, were 2 ms of a cold handle's set-up on H2O/cc-pVTZ)
+static void drop_lists(qc_system *S) {
+    for (auto &c : S->classes) { c.d_slots = nullptr; c.d_bundles = nullptr; c.d_ketlist = nullptr; }
+    if (S->d_lists) { (void)hipFree(S->d_lists); S->d_lists = nullptr; }
+}
 static int upload_slots(qc_system *S) {
     drop_launch_plan(S);
-    for (auto &c : S->classes) {
-        if (c.d_slots) { (void)hipFree(c.d_slots); c.d_slots = nullptr; }
-        if (c.d_bundles) { (void)hipFree(c.d_bundles); c.d_bundles = nullptr; }
-        if (c.d_ketlist) { (void)hipFree(c.d_ketlist); c.d_ketlist = nullptr; }
-        if (!c.slots.empty()) {
-            QC_HIP_CHECK(hipMalloc(&c.d_slots, c.slots.size() * sizeof(QcSlot)));
-            QC_HIP_CHECK(hipMemcpy(c.d_slots, c.slots.data(), c.slots.size() * sizeof(QcSlot), hipMemcpyHostToDevice));
-        }
+    if (S->stream) (void)hipStreamSynchronize(S->stream);         // (nothing in flight reads the old lists)
+    drop_lists(S);
+    std::vector<unsigned char> blob;
+    auto put = [&](const void *src, size_t bytes) -> size_t {
+        const size_t off = (blob.size() + 255) & ~(size_t)255;
+        blob.resize(off + bytes);
+        std::memcpy(blob.data() + off, src, bytes);
+        return off;
+    };
+    struct Where { size_t slots = ~(size_t)0, bundles = ~(size_t)0, kets = ~(size_t)0; };
+    std::vector<Where> where(S->classes.size());
+    for (size_t ci = 0; ci < S->classes.size(); ++ci) {
+        auto &c = S->classes[ci];
+        if (!c.slots.empty()) where[ci].slots = put(c.slots.data(), c.slots.size() * sizeof(QcSlot));
         if (!c.bundles.empty()) {
             std::vector<QcBundleDev> db; std::vector<QcKetUnit> du;
             qc_bm_device_lists(S, c.LCD, c.bundles, c.ketlist, c.ket_packed, db, du);
-            QC_HIP_CHECK(hipMalloc(&c.d_bundles, db.size() * sizeof(QcBundleDev)));
-            QC_HIP_CHECK(hipMemcpy(c.d_bundles, db.data(), db.size() * sizeof(QcBundleDev), hipMemcpyHostToDevice));
-            QC_HIP_CHECK(hipMalloc(&c.d_ketlist, du.size() * sizeof(QcKetUnit)));
-            QC_HIP_CHECK(hipMemcpy(c.d_ketlist, du.data(), du.size() * sizeof(QcKetUnit), hipMemcpyHostToDevice));
+            where[ci].bundles = put(db.data(), db.size() * sizeof(QcBundleDev));
+            where[ci].kets = put(du.data(), du.size() * sizeof(QcKetUnit));
         }
+    }
+    if (blob.empty()) return QC_OK;
+    QC_HIP_CHECK(hipMalloc(&S->d_lists, blob.size()));
+    QC_HIP_CHECK(hipMemcpy(S->d_lists, blob.data(), blob.size(), hipMemcpyHostToDevice));
+    for (size_t ci = 0; ci < S->classes.size(); ++ci) {
+        auto &c = S->classes[ci];
+        if (where[ci].slots != ~(size_t)0) c.d_slots = reinterpret_cast<QcSlot *>(S->d_lists + where[ci].slots);
+        if (where[ci].bundles != ~(size_t)0) c.d_bundles = reinterpret_cast<QcBundleDev *>(S->d_lists + where[ci].bundles);
+        if (where[ci].kets != ~(size_t)0) c.d_ketlist = reinterpret_cast<QcKetUnit *>(S->d_lists + where[ci].kets);
     }
     return QC_OK;
 }
@@ -283,11 +302,7 @@ void qc_device_free(qc_system *S) {
     if (S->stream) (void)hipStreamSynchronize(S->stream);
     qc_gate_forget(S);
     S->spec.pending = false;
-    for (auto &c : S->classes) {
-        if (c.d_slots) { (void)hipFree(c.d_slots); c.d_slots = nullptr; }
-        if (c.d_bundles) { (void)hipFree(c.d_bundles); c.d_bundles = nullptr; }
-        if (c.d_ketlist) { (void)hipFree(c.d_ketlist); c.d_ketlist = nullptr; }
-    }
+    drop_lists(S);
     void *ptrs[] = {S->d_rplan, S->d_gidx, S->d_shells, S->d_pairdata, S->d_pairdataT, S->d_pspack, S->d_pairs, S->d_boys, S->d_D, S->d_G, S->d_Gtmp, S->d_Gred, S->d_Dj, S->d_flag, S->d_fxs};
     S->d_flag = nullptr; S->d_fxs = nullptr;
     qc_issue_pool_drop(S);
@@ -422,9 +437,8 @@ void qc_stamp_flush() {
     fprintf(stderr, "[issue]");
     for (size_t i = 1; i < qc_stamps->size(); ++i) fprintf(stderr, " %s %.1f |", (*qc_stamps)[i].first, (*qc_stamps)[i].second - (*qc_stamps)[i - 1].second);
     fprintf(stderr, " total %.1f us\n", qc_stamps->back().second - qc_stamps->front().second);
-    const auto last = qc_stamps->back();      // (kept: the next pass's first difference is the caller's time between two passes)
-    qc_stamps->clear();
-    qc_stamps->push_back(last);
+    qc_stamps->clear();                         // (a fresh stamp behind the printing: the next pass's first difference is the caller's own time
+    qc_stamp("printed");                        // between two passes)
 }
 // ---- device-side timeline (QC_DEV_TIMELINE): see qc_tl_stamp
 int qc_tl_begin_pass(qc_system *S) {
@@ -1439,10 +1453,9 @@ template <class T> struct QcTmpDev {
 // class kernels in their `schwarz_out` mode - unsplit slots / one-ket bundles, serial launches, once per geometry.
 int qc_schwarz_device(qc_system *S) {
     const size_t np = S->pairs.size();
-    // (the classes' launches are serial on the handle's stream and independent of the host: their temporary lists stay alive in `keep`
-    // and ONE wait ends the pass - a wait per class made it 4 ms for H2O/cc-pVTZ, most of a cold handle's set-up)
-    struct Keep { std::vector<void *> p; ~Keep() { for (void *x : p) if (x) (void)hipFree(x); } } keep;
-    auto keep_alloc = [&](size_t bytes, void **out) -> hipError_t { hipError_t e = hipMalloc(out, bytes); if (e == hipSuccess) keep.p.push_back(*out); return e; };
+    // (the classes' launches are serial on the handle's stream and independent of the host; their temporary lists are packed into ONE
+    // device buffer - one allocation, one copy, one wait for the whole pass: an allocation, two synchronous copies and a wait per class
+    // made it 4 ms for H2O/cc-pVTZ, most of a cold handle's set-up; 3.6 ms still with one wait but 35 allocations and 50 copies)
     QcTmpDev<double> dq;
     QC_HIP_CHECK(dq.alloc(np));
     double *const d_q = dq.p;
@@ -1453,44 +1466,73 @@ int qc_schwarz_device(qc_system *S) {
     std::vector<QcSlot> slots;
     std::vector<QcBundle> bundles; std::vector<int> ketlist;
     std::vector<QcTask> diag;
+    std::vector<unsigned char> blob;                               // every class's lists, 256-byte aligned
+    auto put = [&](const void *src, size_t bytes) -> size_t {
+        const size_t off = (blob.size() + 255) & ~(size_t)255;
+        blob.resize(off + bytes);
+        if (bytes) std::memcpy(blob.data() + off, src, bytes);
+        return off;
+    };
+    struct Job { const QcClass *c; int kind; size_t off_a, off_b; int count, lds; QcClass col; };   // kind 0: slots, 1: bundles, 2: p.p kets through the column kernels
+    std::vector<Job> jobs;
+    jobs.reserve(S->classes.size());
     for (const auto &c : S->classes) {
         diag.clear();
         for (const auto &t : c.tasks) if (t.bra == t.ket) diag.push_back(t);
         if (diag.empty()) continue;
+        Job j{&c, 0, 0, 0, 0, 0, QcClass{}};
         if (c.bm && c.LCD == 2) {   // p.p-ket bra-major class: the column kernels have the Schwarz mode
-            QcClass cc;
-            cc.LAB = c.LAB; cc.LCD = c.LCD; cc.LGC = c.col_lgc; cc.slot_words = c.col_slot_words; cc.lds_bytes = c.col_lds_bytes;
+            j.kind = 2;
+            j.col.LAB = c.LAB; j.col.LCD = c.LCD; j.col.LGC = c.col_lgc; j.col.slot_words = c.col_slot_words; j.col.lds_bytes = c.col_lds_bytes;
             qc_make_slots(S, diag, 0, false, slots);
-            QcSlot *dsl = nullptr;
-            QC_HIP_CHECK(keep_alloc(slots.size() * sizeof(QcSlot), (void **)&dsl));
-            QC_HIP_CHECK(hipMemcpy(dsl, slots.data(), slots.size() * sizeof(QcSlot), hipMemcpyHostToDevice));
-            int rc = launch_segments(S, qc_unit_of(cc.LAB, cc.LCD, false), {Seg{&cc, dsl, (int)slots.size()}}, S->stream, a);
-            if (rc != QC_OK) { (void)hipStreamSynchronize(S->stream); return rc; }
-            continue;
-        }
-        if (c.bm) {
+            j.off_a = put(slots.data(), slots.size() * sizeof(QcSlot)); j.count = (int)slots.size();
+        } else if (c.bm) {
+            j.kind = 1;
             const bool packed = qc_make_bundles(S, diag, 0, bundles, ketlist);
-            QcBundleDev *db = nullptr; QcKetUnit *dk = nullptr;
             std::vector<QcBundleDev> hb; std::vector<QcKetUnit> hu;
             qc_bm_device_lists(S, c.LCD, bundles, ketlist, packed, hb, hu);
-            QC_HIP_CHECK(keep_alloc(hb.size() * sizeof(QcBundleDev), (void **)&db));
-            QC_HIP_CHECK(keep_alloc(hu.size() * sizeof(QcKetUnit), (void **)&dk));
-            QC_HIP_CHECK(hipMemcpy(db, hb.data(), hb.size() * sizeof(QcBundleDev), hipMemcpyHostToDevice));
-            QC_HIP_CHECK(hipMemcpy(dk, hu.data(), hu.size() * sizeof(QcKetUnit), hipMemcpyHostToDevice));
+            j.off_a = put(hb.data(), hb.size() * sizeof(QcBundleDev)); j.off_b = put(hu.data(), hu.size() * sizeof(QcKetUnit));
+            j.count = (int)bundles.size();
             int mx = 0;
             for (const auto &t : diag) mx = std::max(mx, qc_bm_wave_words(c.LAB, S->pairs[t.bra].na * S->pairs[t.bra].nb, S->pairs[t.ket].na * S->pairs[t.ket].nb));
-            int rc = launch_segments(S, qc_unit_of(c.LAB, c.LCD, true), {Seg{&c, nullptr, (int)bundles.size(), db, dk, mx * 8}}, S->stream, a);
-            if (rc != QC_OK) { (void)hipStreamSynchronize(S->stream); return rc; }
-            continue;
+            j.lds = mx * 8;
+        } else {
+            qc_make_slots(S, diag, 0, false, slots);
+            j.off_a = put(slots.data(), slots.size() * sizeof(QcSlot)); j.count = (int)slots.size();
         }
-        qc_make_slots(S, diag, 0, false, slots);
-        QcSlot *dsl = nullptr;
-        QC_HIP_CHECK(keep_alloc(slots.size() * sizeof(QcSlot), (void **)&dsl));
-        QC_HIP_CHECK(hipMemcpy(dsl, slots.data(), slots.size() * sizeof(QcSlot), hipMemcpyHostToDevice));
-        int rc = launch_segments(S, qc_unit_of(c.LAB, c.LCD, false), {Seg{&c, dsl, (int)slots.size()}}, S->stream, a);
-        if (rc != QC_OK) { (void)hipStreamSynchronize(S->stream); return rc; }
+        jobs.push_back(std::move(j));
     }
-    QC_HIP_CHECK(hipStreamSynchronize(S->stream));
+    QcTmpDev<unsigned char> dblob;
+    if (!blob.empty()) {
+        QC_HIP_CHECK(dblob.alloc(blob.size()));
+        QC_HIP_CHECK(hipMemcpyAsync(dblob.p, blob.data(), blob.size(), hipMemcpyHostToDevice, S->stream));
+    }
+    // The launches are independent (each writes its own pairs' entries) and most of them are a few waves working through one long
+    // unsplit slot each (an s.s pair of eight primitives: 4096 primitive quartets in one lane group): their durations add up on one
+    // stream - 3.5 ms for the 35 classes of H2O/cc-pVTZ - so they go round the dispatch lanes, heaviest classes first.
+    const int nl = std::max(1, std::min(S->nlanes, QC_NSTREAMS));
+    if (nl > 1) QC_HIP_CHECK(hipStreamSynchronize(S->stream));    // (the side streams start behind the memset and the copy)
+    std::stable_sort(jobs.begin(), jobs.end(), [](const Job &x, const Job &y) { return x.c->LAB + x.c->LCD > y.c->LAB + y.c->LCD; });
+    int turn = 0;
+    auto sync_all = [&]() -> hipError_t {
+        hipError_t e = hipStreamSynchronize(S->stream);
+        for (int k = 1; k < nl; ++k) { const hipError_t e2 = hipStreamSynchronize(S->side[S->slot_side[k]]); if (e == hipSuccess) e = e2; }
+        return e;
+    };
+    for (const Job &j : jobs) {        // (`jobs` does not move any more: the column-kernel copy of a p.p-ket class is referred to by address)
+        const int lane = turn++ % nl;
+        hipStream_t st = lane == 0 ? S->stream : S->side[S->slot_side[lane]];
+        int rc;
+        if (j.kind == 1)
+            rc = launch_segments(S, qc_unit_of(j.c->LAB, j.c->LCD, true), {Seg{j.c, nullptr, j.count, reinterpret_cast<const QcBundleDev *>(dblob.p + j.off_a),
+                                                                              reinterpret_cast<const QcKetUnit *>(dblob.p + j.off_b), j.lds}}, st, a);
+        else {
+            const QcClass *cls = j.kind == 2 ? &j.col : j.c;
+            rc = launch_segments(S, qc_unit_of(cls->LAB, cls->LCD, false), {Seg{cls, reinterpret_cast<const QcSlot *>(dblob.p + j.off_a), j.count}}, st, a);
+        }
+        if (rc != QC_OK) { (void)sync_all(); return rc; }
+    }
+    QC_HIP_CHECK(sync_all());
     S->pairQ.assign(np, 0.0);
     QC_HIP_CHECK(hipMemcpy(S->pairQ.data(), d_q, np * sizeof(double), hipMemcpyDeviceToHost));
     S->imax = 0.0;

@@ -178,6 +178,7 @@ struct qc_system {
     int *d_flag = nullptr;
     // QC_DEV_TIMELINE: ring of QC_TL_PASSES sets of QC_TL_SLOTS kernel slots (QC_TL_W clock words each, qc_tl_stamp), one set per SCF pass; tl_cur = the set
     // of the pass being enqueued (null: off, or the ring is full); dumped when an SCF state of the handle ends (qc_tl_dump)
+    unsigned char *d_lists = nullptr;        // the work lists of all classes (QcClass::d_slots / d_bundles / d_ketlist point into it)
     unsigned long long *d_tl = nullptr, *tl_cur = nullptr;
     int tl_pass = 0;
     unsigned *d_join = nullptr;              // [0] counter of the device-side join of a build's side streams (qc_join_mark / qc_join_wait);
