@@ -34,7 +34,7 @@ __device__ __forceinline__ void qc_lds_add(double *p, double v) { (void)__builti
 // before any launch.)
 typedef const __attribute__((address_space(4))) double qc_cdouble;
 
-// -DQC_BM_TIMING (tools/build_phase_lib.sh): wave 0 of the first workgroups of a segment prints where its time went (10 ns units)
+// -DQC_BM_TIMING (tools/build_variant_lib.sh): wave 0 of the first workgroups of a segment prints where its time went (10 ns units)
 #ifdef QC_BM_TIMING
 #define QC_BT(i) do { const long long t_ = wall_clock64(); tph[i] += t_ - tlast; tlast = t_; } while (0)
 #define QC_BT_ARGS , long long *tph, long long &tlast
