@@ -1177,6 +1177,32 @@ int qc_launch_fock_classes(qc_system *S, const QcFockArgs &fa, float *class_ms, 
         }
         return QC_OK;
     };
+    // Kernels that overlap stretch each other by class-dependent factors (the bra-major launches 1.8x next to the one-wave-per-SIMD
+    // launches, those hardly at all), which the durations alone do not show: three concurrent builds with events around every launch,
+    // each proposing the longest-first assignment of the durations seen INSIDE it.  These proposals are the first trials of the online
+    // search and are made when it starts (its first instalment): a handle that runs one SCF does not pay for them.
+    auto seed_proposals = [&]() -> int {
+        const size_t gb = ((fa.fxs ? fa.fx_lo : 0) + (size_t)a.nrep * a.rep_stride) * sizeof(double);
+        const std::vector<int> keep = S->unit_stream;
+        EventList evl;
+        if (evl.create(2 + 2 * units.size()) != QC_OK) return QC_ERR_HIP;
+        std::vector<hipEvent_t> &ev = evl.ev;
+        int rc = QC_OK;
+        for (int round = 0; round < 3 && rc == QC_OK; ++round) {
+            if (fa.G0) QC_HIP_CHECK(hipMemsetAsync(fa.G0, 0, gb, S->stream));
+            if ((rc = launch_concurrent(ev.data(), true, 0)) != QC_OK) break;
+            QC_HIP_CHECK(hipEventSynchronize(ev[1]));
+            if ((rc = qc_join_check(S)) != QC_OK) break;
+            std::vector<float> dur(units.size(), 0.f);
+            for (size_t u = 0; u < units.size(); ++u)
+                if (!units[u].empty()) { QC_HIP_CHECK(hipEventSynchronize(ev[3 + 2 * u])); QC_HIP_CHECK(hipEventElapsedTime(&dur[u], ev[2 + 2 * u], ev[3 + 2 * u])); }
+            lpt(dur, QC_NSTREAMS, round == 1 ? 0.015f : 0.f);
+            if (std::find(S->on.cands.begin(), S->on.cands.end(), S->unit_stream) == S->on.cands.end() && S->unit_stream != keep) S->on.cands.push_back(S->unit_stream);
+            S->on.spent += 1;
+        }
+        S->unit_stream = keep; S->unit_weight = S->unit_ms;
+        return rc;
+    };
     if (S->unit_ms.size() != units.size()) {
         // First build of a shard.  No tuner run (round 4): the launches are timed alone once (two serial passes: the first pays the code
         // upload), placed longest-first on the dispatch lanes, and the assignment is refined ONLINE from the build times the SCF passes
@@ -1188,36 +1214,22 @@ int qc_launch_fock_classes(qc_system *S, const QcFockArgs &fa, float *class_ms, 
         // (from the first replica of the hi plane to the last replica in use of the lo plane: the planes keep the layout of QC_NREP replicas
         // whatever the number in use)
         const size_t gbytes = ((fa.fxs ? fa.fx_lo : 0) + (size_t)a.nrep * a.rep_stride) * sizeof(double);
-        int rc = qc_launch_fock_classes(S, fa, nullptr, S->unit_ms.data());     // warm-up: first launches pay code upload
+        // (the warm-up pass only where this process has not launched these units before: their first launches pay the code upload)
+        static std::atomic<unsigned long long> units_warm{0};
+        unsigned long long mine = 0;
+        for (size_t u = 0; u < units.size() && u < 62; ++u) if (!units[u].empty()) mine |= 1ull << u;
+        if (S->merge_bm) mine |= 1ull << 62;                 // (the merged launches are kernels of their own)
+        if (S->merge_t1) mine |= 1ull << 63;
+        int rc = QC_OK;
+        if ((units_warm.load(std::memory_order_acquire) & mine) != mine) rc = qc_launch_fock_classes(S, fa, nullptr, S->unit_ms.data());
         if (rc == QC_OK) rc = qc_launch_fock_classes(S, fa, nullptr, S->unit_ms.data());   // serial, timed
+        if (rc == QC_OK) units_warm.fetch_or(mine, std::memory_order_acq_rel);
         if (rc != QC_OK) return rc;
         static const int fixed_w = getenv("QC_TUNE_FIXED") ? atoi(getenv("QC_TUNE_FIXED")) : 0;      // (experiment switch: lanes used, no online search)
         lpt(S->unit_ms, fixed_w >= 1 && fixed_w <= QC_NSTREAMS ? fixed_w : QC_NSTREAMS, 0.015f);
         S->tune_count += 1; S->assign_gen += 1;
         const bool no_search = fixed_w >= 1 || getenv("QC_TUNE_OFF") != nullptr;
         qc_online_reset(S, no_search);
-        // Kernels that overlap stretch each other by class-dependent factors (the bra-major launches 1.8x next to the one-wave-per-SIMD
-        // launches, those hardly at all), which the durations alone do not show: three concurrent builds with events around every
-        // launch, each proposing the longest-first assignment of the durations seen INSIDE it.  These proposals are the first trials of
-        // the online search; they cost three builds here and nothing later.
-        if (!no_search) {
-            const std::vector<int> first = S->unit_stream;
-            EventList evl;
-            if (evl.create(2 + 2 * units.size()) != QC_OK) return QC_ERR_HIP;
-            std::vector<hipEvent_t> &ev = evl.ev;
-            for (int round = 0; round < 3; ++round) {
-                if (fa.G0) QC_HIP_CHECK(hipMemsetAsync(fa.G0, 0, gbytes, S->stream));
-                if ((rc = launch_concurrent(ev.data(), true, 0)) != QC_OK) return rc;
-                QC_HIP_CHECK(hipEventSynchronize(ev[1]));
-                if ((rc = qc_join_check(S)) != QC_OK) return rc;
-                std::vector<float> dur(units.size(), 0.f);
-                for (size_t u = 0; u < units.size(); ++u)
-                    if (!units[u].empty()) { QC_HIP_CHECK(hipEventSynchronize(ev[3 + 2 * u])); QC_HIP_CHECK(hipEventElapsedTime(&dur[u], ev[2 + 2 * u], ev[3 + 2 * u])); }
-                lpt(dur, QC_NSTREAMS, round == 1 ? 0.015f : 0.f);
-                if (std::find(S->on.cands.begin(), S->on.cands.end(), S->unit_stream) == S->on.cands.end() && S->unit_stream != first) S->on.cands.push_back(S->unit_stream);
-            }
-            S->unit_stream = first; S->unit_weight = S->unit_ms; S->on.best = first;
-        }
         qc_assign_cache_lookup(S);
         if (fa.G0) QC_HIP_CHECK(hipMemsetAsync(fa.G0, 0, gbytes, S->stream));
         nofork = false;                                  // the side streams must see that memset (and the timing passes) finished
@@ -1292,6 +1304,7 @@ int qc_launch_fock_classes(qc_system *S, const QcFockArgs &fa, float *class_ms, 
             return false;
         };
         if (o.best.empty()) o.best = S->unit_stream;
+        if (!o.seeded) { o.seeded = true; if ((rc = seed_proposals()) != QC_OK) return rc; }
         auto note_top = [&](const std::vector<int> &a, float t) {
             for (auto &e : o.top) if (e.second == a) { e.first = std::min(e.first, t); return; }
             o.top.push_back({t, a});

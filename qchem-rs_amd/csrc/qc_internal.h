@@ -216,6 +216,7 @@ struct qc_system {
         size_t nb_pos = 0;
         std::vector<std::vector<int>> cands;   // proposals of the first build (longest-first on in-build durations): tried before random neighbours
         double base_ms = 0.0;                  // build time of `best` as the search measured it
+        bool seeded = false;                   // the proposals of the instrumented builds have been made (first instalment of the search)
         int trials = 0, rejects = 0, kicks = 0;   // (kicks: restarts of the local search from a perturbed copy of the best assignment known)
         long builds = 0, spent = 0;            // builds asked of this handle / extra builds the search has run
         unsigned rng = 2463534242u;

@@ -7,6 +7,7 @@
 // per-rank shards.  Also holds the host implementation of molint::overlap/kinetic/nuclear (rhf.rs:41-43), which
 // SURVEY.md 8f ranks as "next" for the GPU.  Integral formulas: McMurchie-Davidson.
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstring>
 #include <numeric>
@@ -176,6 +177,10 @@ static void pair_hermite_matrix(const QcShell &A, const QcShell &B, int i, int j
 }
 
 void qc_build_model(qc_system *S) {
+    static const bool sdbg = getenv("QC_SETUP_DEBUG") != nullptr;
+    auto tnow = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    double tt = tnow();
+    auto lap = [&](const char *what) { if (sdbg) { const double t = tnow(); fprintf(stderr, "[model] %-28s %.3f ms\n", what, t - tt); tt = t; } };
     int off = 0;
     for (auto &sh : S->shells) {
         for (int k = 0; k < 3; ++k) sh.A[k] = S->xyz[3 * sh.atom + k];
@@ -306,6 +311,7 @@ void qc_build_model(qc_system *S) {
             if (d.K == 0) continue;                       // the whole shell pair is negligible
             S->pairs.push_back(d); S->pairA.push_back(a); S->pairB.push_back(b); S->pairKfull.push_back(A.nprim * B.nprim);
         }
+    lap("shell pairs");
     // unique quartets (pair P >= pair Q), bucketed by launch class.
     //  * bra-major classes (bm): the narrower pair is an ss or ps pair and LAB + LCD <= QC_LREG.  It becomes the ket,
     //    one lane per quartet: the per-primitive-quartet contraction costs ncd * HAB * HCD FMAs, so the pair with the
@@ -316,6 +322,9 @@ void qc_build_model(qc_system *S) {
     S->nquartets = npairs_all * (npairs_all + 1) / 2;      // enumerated (unscreened) count, as the reference would visit
     const int NB = (QC_LPAIR + 1) * (QC_LPAIR + 1) * 7 * 2;
     std::vector<std::vector<QcTask>> bucket(NB);
+    // (the A/B switches of the classification, read once per system - a test switches them - and NOT per quartet: two getenv calls in this
+    // loop were 0.6 us each, a third of the time a handle took to create)
+    const bool no_bm_pp = getenv("QC_NO_BM_PP") != nullptr, no_bm_ps4 = getenv("QC_NO_BM_PS4") != nullptr;
     for (int P = 0; P < np; ++P)
         for (int Q = 0; Q <= P; ++Q) {
             const QcPairDesc &dp = S->pairs[P], &dq = S->pairs[Q];
@@ -326,14 +335,13 @@ void qc_build_model(qc_system *S) {
             // (round 3) p.p kets against p.p / d.s bras, total order 4: bra-major too - lane-per-quartet with the packed p.p records, three
             // bundles per ket group (one per Cartesian axis of the ket's first function, three columns each); the pair that would be the
             // ket of the column kernels (the wide one) stays the ket.  QC_NO_BM_PP: the column kernels keep them (A/B switch).
-            const bool no_bm_pp = getenv("QC_NO_BM_PP") != nullptr;
             const bool w_is_pp = S->shells[S->pairA[wide]].L == 1 && S->shells[S->pairB[wide]].L == 1;
             // (round 3: ps kets against d.d / f.p bras - total order 5: the table of 56 entries next to W[3][35] in a lane, one wave per SIMD
             // like the d.p / f.s bras of that launch - in the bra-major form too.  The column kernels ran (ps|dd) at 1.7 TFLOP/s; measured,
             // alternating runs on one box: H2O/cc-pVTZ iteration 0.3481 against 0.3529 ms (twelve runs each; the LCD = 4 bucket was 944 of the
             // 1444 waves of its tier<1, 1> launch), benzene/cc-pVDZ build 1.398 against 1.390 ms (four each: one launch fewer, no change).
             // QC_NO_BM_PS4 keeps them with the column kernels.)
-            const bool ps4 = getenv("QC_NO_BM_PS4") == nullptr && dn.L == 1 && dw.L == 4;
+            const bool ps4 = !no_bm_ps4 && dn.L == 1 && dw.L == 4;
             if ((dn.L <= 1 && dn.L + dw.L <= QC_LREG) || ps4) {
                 bucket[(((dw.L * (QC_LPAIR + 1) + dn.L) * 7) + 0) * 2 + 1].push_back(QcTask{wide, narrow});
             } else if (!no_bm_pp && S->pp_ok && dn.L == 2 && dw.L == 2 && w_is_pp && dw.K <= 63 && QC_LREG >= 4) {
@@ -366,6 +374,7 @@ void qc_build_model(qc_system *S) {
             if (!b5.empty() && (long)b5.size() <= mx) { b6.insert(b6.end(), b5.begin(), b5.end()); b5.clear(); }
         }
     }
+    lap("quartets into buckets");
     S->classes.clear();
     for (int b = 0; b < NB; ++b) {
         auto &v = bucket[b];
@@ -391,7 +400,9 @@ void qc_build_model(qc_system *S) {
         static const long merge_max = getenv("QC_BM_MERGE_MAX") ? atol(getenv("QC_BM_MERGE_MAX")) : 262144;
         S->merge_bm = has01 && has10 && (long)q_all <= merge_max && getenv("QC_NO_BM_MERGE") == nullptr;
     }
+    lap("classes");
     qc_build_shards(S);
+    lap("work lists");
 }
 
 // Lane-group widths the kernels are instantiated for, per ket Hermite order (the switch in qc_fock_tier_kernel).  A group is
@@ -508,10 +519,24 @@ void qc_build_shards(qc_system *S) {
     std::vector<QcTask> kept;
     for (size_t ci = 0; ci < S->classes.size(); ++ci) {
         auto &c = S->classes[ci];
-        // heaviest first: the primitive-quartet count is the dominant cost inside a class
-        std::stable_sort(c.tasks.begin(), c.tasks.end(), [&](const QcTask &x, const QcTask &y) {
-            return (int64_t)S->pairs[x.bra].K * S->pairs[x.ket].K > (int64_t)S->pairs[y.bra].K * S->pairs[y.ket].K;
-        });
+        // heaviest first: the primitive-quartet count is the dominant cost inside a class.  A stable counting sort on that count (a
+        // product of two primitive-pair counts: a few thousand at most) - the comparator sort with its four indirections per comparison
+        // was most of the 105 ms benzene/cc-pVDZ's lists took on the GPU box's host, twice per cold handle.
+        {
+            int64_t kmax = 0;
+            for (const auto &t : c.tasks) kmax = std::max(kmax, (int64_t)S->pairs[t.bra].K * S->pairs[t.ket].K);
+            if (kmax < (1 << 20)) {
+                std::vector<uint32_t> cnt((size_t)kmax + 2, 0);
+                for (const auto &t : c.tasks) ++cnt[(size_t)(kmax - (int64_t)S->pairs[t.bra].K * S->pairs[t.ket].K) + 1];
+                for (size_t i = 1; i < cnt.size(); ++i) cnt[i] += cnt[i - 1];
+                std::vector<QcTask> sorted(c.tasks.size());
+                for (const auto &t : c.tasks) sorted[cnt[(size_t)(kmax - (int64_t)S->pairs[t.bra].K * S->pairs[t.ket].K)]++] = t;
+                c.tasks.swap(sorted);
+            } else
+                std::stable_sort(c.tasks.begin(), c.tasks.end(), [&](const QcTask &x, const QcTask &y) {
+                    return (int64_t)S->pairs[x.bra].K * S->pairs[x.ket].K > (int64_t)S->pairs[y.bra].K * S->pairs[y.ket].K;
+                });
+        }
         kept.clear();
         for (const auto &t : c.tasks)
             if (!screen || S->pairQ[t.bra] * S->pairQ[t.ket] >= S->schwarz_tau) kept.push_back(t);
