@@ -1347,6 +1347,7 @@ int qc_plan_shard_quartets(qc_system *S, int rank, int nranks, int32_t *abcd /* 
 int qc_work_stats_get(qc_system *S, qc_work_stats *out) {
     if (!S || !out) return QC_ERR_INVALID;
     std::memset(out, 0, sizeof(*out));
+    qc_ensure_lists(S);
     for (const auto &c : S->classes) {
         if (c.shard.empty()) continue;
         out->quartets += (int64_t)c.shard.size(); out->prim_quartets += c.prim_quartets;
@@ -1404,6 +1405,7 @@ int qc_fock_profile(qc_system *S, const double *dD, double *dG, int reps, float 
 int qc_unit_quartets(qc_system *S, int64_t *unit_quartets) {
     if (!S || !unit_quartets) return QC_ERR_INVALID;
     for (int u = 0; u < QC_NUNITS; ++u) unit_quartets[u] = 0;
+    qc_ensure_lists(S);
     for (const auto &c : S->classes) unit_quartets[qc_build_unit_of(S, c.LAB, c.LCD, c.bm)] += (int64_t)c.shard.size();
     return QC_OK;
 }

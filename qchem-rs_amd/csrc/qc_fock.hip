@@ -126,7 +126,7 @@ int qc_device_reshard(qc_system *S) {
     S->cand_skip = false; S->tune_count = 0; S->on = qc_system::QcOnline{};
     S->assign_gen += 1;
     if (S->spec.pending) { if (S->stream) (void)hipStreamSynchronize(S->stream); S->spec.pending = false; }     // (it digests the old lists)
-    qc_build_shards(S);
+    qc_build_shards(S, !S->device_ready);         // (a handle without its device part builds its lists behind the Schwarz pass, or on demand)
     if (!S->device_ready) return QC_OK;
     return upload_slots(S);
 }

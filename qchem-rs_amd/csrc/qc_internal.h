@@ -145,6 +145,7 @@ struct qc_system {
     std::vector<double> pairQ;                  // Schwarz factor sqrt(max_ab (ab|ab)) of each stored pair (empty until the device pass has run)
     double imax = 0.0;                          // max pairQ^2: bound on every |(ij|kl)|
     double schwarz_tau = QC_SCHWARZ_TAU;        // 0: no screening
+    bool lists_stale = false;                   // the work lists have not been built since the classes were (qc_build_shards(S, true))
     int64_t nscreened = 0;                      // quartets (of the whole list, all ranks) dropped by the Schwarz bound
     int64_t nquartets = 0;
     int rank = 0, nranks = 1;
@@ -251,7 +252,10 @@ struct qc_system {
 
 // ---- host model (qc_system.cpp)
 void qc_build_model(qc_system *S);
-void qc_build_shards(qc_system *S);
+// (meta_only: the classes' LDS / slot sizes only, from the whole task lists - what the Schwarz pass of the device set-up needs before the
+// screened lists can exist; the lists are then built once, behind that pass, or on demand: qc_ensure_lists)
+void qc_build_shards(qc_system *S, bool meta_only = false);
+inline void qc_ensure_lists(qc_system *S);
 void qc_host_one_electron(const qc_system *S, int which, double *out);
 void qc_boys_host(int nmax, double x, double *F);
 
@@ -380,6 +384,7 @@ inline void qc_unpack_ket_entry(int entry, bool packed, int *ket, int *kl0, int 
     if (!packed) { *ket = entry; *kl0 = 0; *len = 0; return; }          // (len 0: the whole pair)
     *ket = (int)(e & ((1u << QC_KET_BITS) - 1)); *kl0 = (int)((e >> QC_KET_BITS) & 0x7fu); *len = (int)(e >> (QC_KET_BITS + 7));
 }
+inline void qc_ensure_lists(qc_system *S) { if (S->lists_stale) qc_build_shards(S); }
 inline int qc_unit_of(int LAB, int LCD, bool bm) { return bm ? 2 * (QC_LPAIR + 1) + 2 * LCD + (LAB >= 3 ? 1 : 0) : 2 * LAB + (LCD >= 4 ? 1 : 0); }
 // the launch a class belongs to inside a build: with `merge_t1` (bases with f functions) the wide-ket buckets of the bra classes 0 and 1 ride
 // in the launch of bra class 2, those of class 4 in the launch of class 3, those of class 6 in the launch of class 5 (qc_fock_tier1_low_kernel); the per-class launches of the profiling / set-up passes use qc_unit_of

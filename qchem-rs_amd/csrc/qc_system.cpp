@@ -401,8 +401,10 @@ void qc_build_model(qc_system *S) {
         S->merge_bm = has01 && has10 && (long)q_all <= merge_max && getenv("QC_NO_BM_MERGE") == nullptr;
     }
     lap("classes");
-    qc_build_shards(S);
-    lap("work lists");
+    // (the lists themselves wait for the Schwarz factors of the device set-up - or for whoever asks first, qc_ensure_lists: building them
+    // here as well was 1.6 ms of a 13.7 ms cold SCF of H2O/cc-pVTZ, 60 ms for benzene/cc-pVDZ)
+    qc_build_shards(S, true);
+    lap("class sizes");
 }
 
 // Lane-group widths the kernels are instantiated for, per ket Hermite order (the switch in qc_fock_tier_kernel).  A group is
@@ -510,7 +512,8 @@ bool qc_make_bundles(const qc_system *S, const std::vector<QcTask> &tasks, int i
 // Static shard: inside every launch class the cost-sorted quartet list is dealt to the ranks in boustrophedon order
 // (0..N-1, N-1..0, ...; start rank rotated per class), so each rank holds the same mix of classes and nearly the same
 // modelled cost.  Data-only; no communication.
-void qc_build_shards(qc_system *S) {
+void qc_build_shards(qc_system *S, bool meta_only) {
+    S->lists_stale = meta_only;
     // Schwarz screening (once the factors exist - they come from a device pass): |(ab|cd)| <= Q_ab Q_cd, quartets below
     // schwarz_tau are not evaluated.  Density-independent, so the work lists stay static; the reference visits every quartet
     // (its own TODO, uhf.rs:49-50), throughput figures keep counting the enumerated ones.
@@ -519,6 +522,27 @@ void qc_build_shards(qc_system *S) {
     std::vector<QcTask> kept;
     for (size_t ci = 0; ci < S->classes.size(); ++ci) {
         auto &c = S->classes[ci];
+        if (meta_only) {
+            // sizes over the WHOLE task list (an upper bound of any shard's): slot words / LDS bytes of the class, of its column-kernel form
+            // (p.p-ket bra-major classes), rows of the bra-major exchange buffer
+            c.shard.clear(); c.slots.clear(); c.bundles.clear(); c.ketlist.clear();
+            c.prim_quartets = 0; c.bytes_alg = 0; c.flops_alg = 0; c.run = 0; c.rb_rows = 0;
+            int words = 0, cw = 0, mx = 0;
+            c.bm_rows = 0;
+            if (c.bm && c.LCD == 2) c.col_lgc = qc_lgc_for(c.LAB, c.LCD, 9);
+            for (const auto &t : c.tasks) {
+                const QcPairDesc &b = S->pairs[t.bra], &k = S->pairs[t.ket];
+                const int ncd = k.na * k.nb, nab = b.na * b.nb, kt = b.na * k.na + b.na * k.nb + b.nb * k.na + b.nb * k.nb;
+                words = std::max(words, qc_region0(b.L + k.L, c.LGC) + nab * ncd + nab + ncd + 2 * kt + (c.LGC == 6 ? ncd + 2 * kt : 0));
+                if (c.bm && c.LCD == 2) cw = std::max(cw, qc_region0(b.L + k.L, c.col_lgc) + nab * ncd + nab + ncd + 2 * kt);
+                if (c.bm) { mx = std::max(mx, qc_bm_wave_words(c.LAB, nab, c.LCD == 2 ? 3 : ncd)); c.bm_rows = std::max(c.bm_rows, b.na + b.nb); }
+            }
+            c.slot_words = words;
+            c.lds_bytes = words * 8 * (64 >> c.LGC) + (qc_hoisted(c.LAB + c.LCD) ? 0 : qc_nplan(c.LAB + c.LCD) * 8);
+            if (c.bm && c.LCD == 2) { c.col_slot_words = cw; c.col_lds_bytes = cw * 8 * (64 >> c.col_lgc) + (qc_hoisted(c.LAB + c.LCD) ? 0 : qc_nplan(c.LAB + c.LCD) * 8); }
+            if (c.bm) { c.slot_words = mx; c.lds_bytes = mx * 8; }
+            continue;
+        }
         // heaviest first: the primitive-quartet count is the dominant cost inside a class.  A stable counting sort on that count (a
         // product of two primitive-pair counts: a few thousand at most) - the comparator sort with its four indirections per comparison
         // was most of the 105 ms benzene/cc-pVDZ's lists took on the GPU box's host, twice per cold handle.
