@@ -28,5 +28,6 @@ WARM_RUNS=40 python tools/timeline_probe.py 2> $O/device_timeline_raw.txt || exi
 python tools/open_shell_fused_probe.py > profiles/${TAG}_o2_triplet_linear_algebra.txt 2>&1 || exit 1
 python bench.py > $O/bench_default.json 2> $O/bench_default.err || exit 1
 cp bench_detail.json $O/bench_default_detail.json
+cp $O/bench_default.json profiles/${TAG}_bench_default.json; cp $O/bench_default_detail.json profiles/${TAG}_bench_default_detail.json
 mkdir -p $O/profiles && cp profiles/${TAG}_* $O/profiles/
 wc -c $O/bench_default.json
