@@ -446,11 +446,25 @@ void qc_make_slots(const qc_system *S, const std::vector<QcTask> &tasks, int itm
 // With whole pairs a wave runs as long as its most contracted ket (64 primitive pairs for a pair of contracted s shells) while the
 // lanes of single-primitive kets idle, and a molecule with few shell pairs cannot fill 64 lanes per bra at all (H2O/cc-pVTZ: 55 ss
 // pairs); chunks of equal length fill the lanes and bound the trip count.
+// stable counting sort, ascending key in [0, nkeys): the list orders below have small integer keys, and a comparator merge sort over the
+// two to four million entries of a large system's bra-major classes was 200 of the 250 ms its work lists took (this container's host)
+template <class T, class KeyFn>
+static void qc_counting_sort(std::vector<T> &v, size_t nkeys, KeyFn key) {
+    if (v.size() < 2) return;
+    std::vector<uint32_t> cnt(nkeys + 1, 0);
+    for (const auto &x : v) ++cnt[(size_t)key(x) + 1];
+    for (size_t i = 1; i < cnt.size(); ++i) cnt[i] += cnt[i - 1];
+    std::vector<T> out(v.size());
+    for (const auto &x : v) out[cnt[(size_t)key(x)]++] = x;
+    v.swap(out);
+}
+
 bool qc_make_bundles(const qc_system *S, const std::vector<QcTask> &tasks, int itmax, std::vector<QcBundle> &bundles, std::vector<int> &ketlist, int unit) {
     bundles.clear(); ketlist.clear();
     if (unit > 0 && S->pairs.size() < (1u << QC_KET_BITS)) {
         struct U { int bra, ket, kl0, len; };
         std::vector<U> us;
+        us.reserve(tasks.size() * 2);
         for (const auto &t : tasks) {
             const int K = S->pairs[t.ket].K;
             if (K > 127) { us.clear(); break; }                  // (does not fit the packed entry: whole pairs below)
@@ -461,7 +475,10 @@ bool qc_make_bundles(const qc_system *S, const std::vector<QcTask> &tasks, int i
             }
         }
         if (!us.empty()) {
-            std::stable_sort(us.begin(), us.end(), [](const U &x, const U &y) { return x.bra != y.bra ? x.bra < y.bra : x.len > y.len; });
+            // by bra, inside a bra the longest chunks first, stable: the minor key first, then the major one (len <= 127)
+            qc_counting_sort(us, 128, [](const U &x) { return 127 - x.len; });
+            qc_counting_sort(us, S->pairs.size(), [](const U &x) { return x.bra; });
+            ketlist.reserve(us.size());
             for (size_t i = 0; i < us.size();) {
                 size_t j = i;
                 while (j < us.size() && us[j].bra == us[i].bra && j - i < 64) ++j;
@@ -479,17 +496,30 @@ bool qc_make_bundles(const qc_system *S, const std::vector<QcTask> &tasks, int i
                     bundles.push_back(QcBundle{us[i].bra, (int)((int64_t)Kab * sp / nparts), (int)((int64_t)Kab * (sp + 1) / nparts), first, (int)(j - i), maxK, 0, 0});
                 i = j;
             }
-            std::stable_sort(bundles.begin(), bundles.end(), [](const QcBundle &x, const QcBundle &y) {
-                return (int64_t)(x.ij_hi - x.ij_lo) * x.maxK > (int64_t)(y.ij_hi - y.ij_lo) * y.maxK;
-            });
+            {   // long bundles first (stable)
+                int64_t cmax = 0;
+                for (const auto &x : bundles) cmax = std::max(cmax, (int64_t)(x.ij_hi - x.ij_lo) * x.maxK);
+                if (cmax < (1 << 22)) qc_counting_sort(bundles, (size_t)cmax + 1, [cmax](const QcBundle &x) { return cmax - (int64_t)(x.ij_hi - x.ij_lo) * x.maxK; });
+                else std::stable_sort(bundles.begin(), bundles.end(), [](const QcBundle &x, const QcBundle &y) {
+                    return (int64_t)(x.ij_hi - x.ij_lo) * x.maxK > (int64_t)(y.ij_hi - y.ij_lo) * y.maxK;
+                });
+            }
             return true;
         }
     }
     std::vector<QcTask> t(tasks);
-    std::stable_sort(t.begin(), t.end(), [&](const QcTask &x, const QcTask &y) {
-        if (x.bra != y.bra) return x.bra < y.bra;
-        return S->pairs[x.ket].K > S->pairs[y.ket].K;
-    });
+    {   // by bra, inside a bra the kets with the most primitive pairs first, stable
+        int kmax = 0;
+        for (const auto &x : t) kmax = std::max(kmax, S->pairs[x.ket].K);
+        if (kmax < (1 << 20)) {
+            qc_counting_sort(t, (size_t)kmax + 1, [&](const QcTask &x) { return kmax - S->pairs[x.ket].K; });
+            qc_counting_sort(t, S->pairs.size(), [](const QcTask &x) { return x.bra; });
+        } else
+            std::stable_sort(t.begin(), t.end(), [&](const QcTask &x, const QcTask &y) {
+                if (x.bra != y.bra) return x.bra < y.bra;
+                return S->pairs[x.ket].K > S->pairs[y.ket].K;
+            });
+    }
     for (size_t i = 0; i < t.size();) {
         size_t j = i;
         while (j < t.size() && t[j].bra == t[i].bra && j - i < 64) ++j;
@@ -503,9 +533,14 @@ bool qc_make_bundles(const qc_system *S, const std::vector<QcTask> &tasks, int i
         i = j;
     }
     // long bundles first: the tail of the launch is made of short ones
-    std::stable_sort(bundles.begin(), bundles.end(), [](const QcBundle &x, const QcBundle &y) {
-        return (int64_t)(x.ij_hi - x.ij_lo) * x.maxK > (int64_t)(y.ij_hi - y.ij_lo) * y.maxK;
-    });
+    {   // long bundles first (stable): cost = bra primitive pairs x longest ket
+        int64_t cmax = 0;
+        for (const auto &x : bundles) cmax = std::max(cmax, (int64_t)(x.ij_hi - x.ij_lo) * x.maxK);
+        if (cmax < (1 << 22)) qc_counting_sort(bundles, (size_t)cmax + 1, [cmax](const QcBundle &x) { return cmax - (int64_t)(x.ij_hi - x.ij_lo) * x.maxK; });
+        else std::stable_sort(bundles.begin(), bundles.end(), [](const QcBundle &x, const QcBundle &y) {
+            return (int64_t)(x.ij_hi - x.ij_lo) * x.maxK > (int64_t)(y.ij_hi - y.ij_lo) * y.maxK;
+        });
+    }
     return false;          // entries are plain pair indices
 }
 
@@ -514,6 +549,11 @@ bool qc_make_bundles(const qc_system *S, const std::vector<QcTask> &tasks, int i
 // modelled cost.  Data-only; no communication.
 void qc_build_shards(qc_system *S, bool meta_only) {
     S->lists_stale = meta_only;
+    static const bool sdbg = getenv("QC_SETUP_DEBUG") != nullptr;
+    double tacc[6] = {0, 0, 0, 0, 0, 0};
+    auto tnow = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    double tlast = tnow();
+    auto acc = [&](int k) { if (sdbg) { const double t = tnow(); tacc[k] += t - tlast; tlast = t; } };
     // Schwarz screening (once the factors exist - they come from a device pass): |(ab|cd)| <= Q_ab Q_cd, quartets below
     // schwarz_tau are not evaluated.  Density-independent, so the work lists stay static; the reference visits every quartet
     // (its own TODO, uhf.rs:49-50), throughput figures keep counting the enumerated ones.
@@ -561,6 +601,7 @@ void qc_build_shards(qc_system *S, bool meta_only) {
                     return (int64_t)S->pairs[x.bra].K * S->pairs[x.ket].K > (int64_t)S->pairs[y.bra].K * S->pairs[y.ket].K;
                 });
         }
+        acc(0);
         kept.clear();
         for (const auto &t : c.tasks)
             if (!screen || S->pairQ[t.bra] * S->pairQ[t.ket] >= S->schwarz_tau) kept.push_back(t);
@@ -577,6 +618,7 @@ void qc_build_shards(qc_system *S, bool meta_only) {
             for (size_t i = 0; i < kept.size(); ++i)
                 if (qc_shard_owner(i, S->nranks, ci) == S->rank) c.shard.push_back(kept[i]);
         }
+        acc(1);
         // slot length: long enough to amortise the per-slot digestion, short enough that the class still fills the chip
         int64_t tot_pq = 0;
         for (const auto &t : c.shard) tot_pq += (int64_t)S->pairs[t.bra].K * S->pairs[t.ket].K;
@@ -654,6 +696,7 @@ void qc_build_shards(qc_system *S, bool meta_only) {
                 c.run = run_env;
             }
         }
+        acc(c.bm ? 2 : 3);
         c.prim_quartets = 0; c.bytes_alg = 0; c.flops_alg = 0;
         int words = 0;
         for (const auto &t : c.shard) {
@@ -704,7 +747,9 @@ void qc_build_shards(qc_system *S, bool meta_only) {
             c.slot_words = mx;
             c.lds_bytes = mx * 8;
         }
+        acc(4);
     }
+    if (sdbg && !meta_only) fprintf(stderr, "[lists] order %.2f  screen + deal %.2f  bundles %.2f  slots %.2f  work model + sizes %.2f ms\n", tacc[0], tacc[1], tacc[2], tacc[3], tacc[4]);
 }
 
 // ---- one-electron matrices on the host (molint::overlap / kinetic / nuclear, rhf.rs:41-43); which: 0 S, 1 T, 2 V
