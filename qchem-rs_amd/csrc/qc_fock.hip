@@ -98,6 +98,11 @@ static int upload_slots(qc_system *S) {
     };
     struct Where { size_t slots = ~(size_t)0, bundles = ~(size_t)0, kets = ~(size_t)0; };
     std::vector<Where> where(S->classes.size());
+    {   // (one allocation for the host copy too: growing it list by list copied benzene's 40 MB several times over)
+        size_t est = 0;
+        for (const auto &c : S->classes) est += c.slots.size() * sizeof(QcSlot) + c.bundles.size() * sizeof(QcBundleDev) + c.ketlist.size() * sizeof(QcKetUnit) + 3 * 256;
+        blob.reserve(est);
+    }
     for (size_t ci = 0; ci < S->classes.size(); ++ci) {
         auto &c = S->classes[ci];
         if (!c.slots.empty()) where[ci].slots = put(c.slots.data(), c.slots.size() * sizeof(QcSlot));

@@ -52,6 +52,25 @@ def test_host_model_matches_oracle_without_a_gpu():
     assert ws.quartets == 32131 and ws.prim_quartets > ws.quartets and ws.bytes_alg > 0 and ws.flops_alg > 0
 
 
+def test_work_lists_are_built_on_demand_and_in_a_fixed_order():
+    """Creating a handle sizes its launch classes only; the work lists are built when somebody asks (or behind the Schwarz pass of the device
+    set-up).  Whoever asks first gets the same lists: work statistics straight after creation equal those after a shard round trip, and the
+    quartet list of a shard - classes in order, inside a class by descending primitive-quartet count, stable - does not depend on how often
+    it is asked for (the orders are stable counting sorts: a repeat is identical element for element)."""
+    import qchem_rs_amd as q
+    m = load_system("water", "cc-pVTZ")
+    s1, s2 = q.System(m), q.System(m)
+    ws1 = s1.work_stats()                                   # on demand
+    s2.set_shard(1, 3); s2.set_shard(0, 1)                  # through a re-shard
+    ws2 = s2.work_stats()
+    for f in ("quartets", "prim_quartets", "nclasses", "bytes_alg", "flops_alg"):
+        assert getattr(ws1, f) == getattr(ws2, f), f
+    a, b = s1.plan_shard_quartets(1, 4), s2.plan_shard_quartets(1, 4)
+    assert np.array_equal(a, b) and np.array_equal(a, s1.plan_shard_quartets(1, 4))
+    assert s1.work_stats().quartets == ws1.quartets         # the plan calls leave the handle's own lists as they were
+    s1.close(); s2.close()
+
+
 @pytest.mark.parametrize("nranks", [2, 3, 8])
 def test_shard_plan_is_a_partition(nranks):
     import qchem_rs_amd as q
