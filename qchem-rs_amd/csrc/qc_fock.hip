@@ -289,6 +289,26 @@ int qc_device_init(qc_system *S) {
         if (!concurrent && getenv("QC_SCF_DEBUG")) fprintf(stderr, "qchem_hip: kernels of different streams do not run concurrently here (profiler counters?): event join\n");
         if (concurrent && !lanes_known) { prc = qc_lane_probe(S); if (prc != QC_OK) return prc; S->lanes_probed = getenv("QC_NO_LANES") == nullptr; }
     }
+    {   // the DS unit's lane order (qc_fock_bm.hip): asked once per device and process
+        static std::mutex mu;
+        static int known[64];                          // 0 unknown, 1 fixed order, 2 not
+        int dev = S->device >= 0 && S->device < 64 ? S->device : 0;
+        std::lock_guard<std::mutex> lk(mu);
+        if (known[dev] == 0) {
+            double *d = nullptr, h[64];
+            QC_HIP_CHECK(hipMalloc(&d, 64 * sizeof(double)));
+            int prc = qc_ds_order_probe(S->stream, d);
+            hipError_t e = hipMemcpyAsync(h, d, sizeof(h), hipMemcpyDeviceToHost, S->stream);
+            if (e == hipSuccess) e = hipStreamSynchronize(S->stream);
+            (void)hipFree(d);
+            if (prc != QC_OK || e != hipSuccess) return QC_ERR_HIP;
+            bool same = true;
+            for (int i = 1; i < 64; ++i) same = same && std::memcmp(&h[i], &h[0], sizeof(double)) == 0;
+            known[dev] = same ? 1 : 2;
+            if (!same) fprintf(stderr, "qchem_hip: this device's DS unit does not add the lanes of one instruction in a fixed order: exchange rows go to global memory directly\n");
+        }
+        S->ds_order_ok = known[dev] == 1 && getenv("QC_DS_ORDER_FAIL") == nullptr;        // (QC_DS_ORDER_FAIL: test hook - as if the probe had failed)
+    }
     lap("join + lane probes");
     QC_HIP_CHECK(hipMalloc(&S->d_fxs, 2 * sizeof(double)));
     // Schwarz factors of the pairs (once per geometry), then the screened work lists
@@ -853,7 +873,7 @@ static int launch_segments(qc_system *S, int unit, const std::vector<Seg> &segs,
         // exchange rows of a wave's current bra in LDS: (na + nb) rows x n columns per spin
         const int rowbytes = (base.Dk1 ? 2 : 1) * rows * S->nbasis * 8;
         // (QC_BM_NO_ROWBUF forces the large-n fallback - direct global atomics per bundle - so that tests can reach it)
-        t.use_rowbuf = (base.eri_out == nullptr && base.schwarz_out == nullptr && QC_BM_LDS_TABLE + 2 * (iblock + rowbytes) <= lds_max && !getenv("QC_BM_NO_ROWBUF")) ? 1 : 0;
+        t.use_rowbuf = (base.eri_out == nullptr && base.schwarz_out == nullptr && QC_BM_LDS_TABLE + 2 * (iblock + rowbytes) <= lds_max && S->ds_order_ok && !getenv("QC_BM_NO_ROWBUF")) ? 1 : 0;
         const int wbytes = iblock + (t.use_rowbuf ? rowbytes : 0);
         while (nw > 1 && QC_BM_LDS_TABLE + nw * wbytes > lds_max) nw /= 2;          // Cartesian d / f bras: 36+ rows of I per wave
         int grid = 0, k = 0;

@@ -24,4 +24,5 @@ struct QcBmArgs {
     const QcKetUnit *seg_ketlist[QC_MAXSEG];
 };
 
+int qc_ds_order_probe(hipStream_t st, double *d_out64);      // 64 sums of the same 64-lane DS add: equal bits = the order is fixed
 int qc_launch_bm(int lcd, int hi, int grid, int nwaves /* <= qc_bm_waves(lcd, hi) */, size_t lds, hipStream_t st, const QcBmArgs &a);

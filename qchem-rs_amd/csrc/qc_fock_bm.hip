@@ -686,6 +686,36 @@ static int launch_bm(int grid, int nwaves, size_t lds, hipStream_t st, const QcB
     return hipGetLastError() == hipSuccess ? QC_OK : QC_ERR_HIP;
 }
 
+// The exchange rows of a bundle are summed in LDS with f64 DS atomics, several lanes of ONE instruction adding to one address (qc_lds_add):
+// bitwise reproducible builds need the DS unit to serve such lanes in an order that does not depend on timing.  No manual says so; every
+// device seen does it.  This probe asks the device at hand: 64 lanes add values of very different magnitudes (the sum depends on the
+// order) to one word, 64 times over, with another wave of the workgroup hammering the same LDS bank meanwhile; all 64 sums must be the same
+// bits.  A device that fails is served without the row buffer (direct fixed-point global atomics: order-independent by construction).
+__global__ __launch_bounds__(128) void qc_ds_order_probe_kernel(double *out) {
+    __shared__ double acc[64 + 64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (wave == 1) {                                   // traffic on the same banks, other addresses
+        for (int rep = 0; rep < 4096; ++rep) qc_lds_add(&acc[64 + ((lane * 7 + rep) & 63)], 1.0);
+        return;
+    }
+    const double v = ldexp(1.0 + 0.001 * lane, (lane * 37) % 53 - 20) * ((lane & 1) ? -1.0 : 1.0);
+    for (int rep = 0; rep < 64; ++rep) {
+        double *word = &acc[rep & 1];
+        if (lane == 0) *word = 0.0;
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        if ((lane + rep) & 3) qc_lds_add(&acc[2 + (lane & 31)], 1.0);      // (an unrelated add with a partial mask in front)
+        qc_lds_add(word, v);                           // the probed instruction: 64 lanes, one address
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        if (lane == 0) out[rep] = *word;
+    }
+}
+int qc_ds_order_probe(hipStream_t st, double *d_out64) {
+    hipLaunchKernelGGL(qc_ds_order_probe_kernel, dim3(1), dim3(128), 0, st, d_out64);
+    return hipGetLastError() == hipSuccess ? QC_OK : QC_ERR_HIP;
+}
+
 int qc_launch_bm(int lcd, int hi, int grid, int nwaves, size_t lds, hipStream_t st, const QcBmArgs &a) {
     if (lcd == 3) return hi ? QC_ERR_UNSUPPORTED : launch_bm<3, 0>(grid, nwaves, lds, st, a);
     if (lcd == 2) return hi ? QC_ERR_UNSUPPORTED : launch_bm<2, 0>(grid, nwaves, lds, st, a);

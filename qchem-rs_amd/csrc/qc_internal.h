@@ -145,6 +145,7 @@ struct qc_system {
     std::vector<double> pairQ;                  // Schwarz factor sqrt(max_ab (ab|ab)) of each stored pair (empty until the device pass has run)
     double imax = 0.0;                          // max pairQ^2: bound on every |(ij|kl)|
     double schwarz_tau = QC_SCHWARZ_TAU;        // 0: no screening
+    bool ds_order_ok = true;                    // the DS unit served the lanes of one f64 add in a reproducible order (qc_ds_order_probe, per device)
     bool lists_stale = false;                   // the work lists have not been built since the classes were (qc_build_shards(S, true))
     int64_t nscreened = 0;                      // quartets (of the whole list, all ranks) dropped by the Schwarz bound
     int64_t nquartets = 0;

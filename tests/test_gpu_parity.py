@@ -716,6 +716,25 @@ def test_device_timeline_and_host_stamps(monkeypatch, capfd):
     assert e_plain == e_traced
 
 
+def test_ds_lane_order_is_probed_and_a_device_that_fails_loses_nothing_but_time(monkeypatch):
+    """The exchange rows of a bra-major bundle are pre-summed with f64 DS atomics, several lanes of one instruction adding to one word: bitwise
+    reproducibility needs the DS unit to serve them in a fixed order.  qc_ds_order_probe asks the device at set-up (64 x the same 64-lane add
+    with values of very different magnitudes: all sums the same bits); a device that failed would get the direct fixed-point global atomics -
+    here forced (QC_DS_ORDER_FAIL): same matrix to rounding, still reproducible bit for bit, still symmetric."""
+    import qchem_rs_amd as q
+    m = load_system("benzene", "6-31G_st_st")
+    s = q.System(m)
+    D = _rand_sym(s.n, 53)
+    G = s.fock_rhf(D)
+    s.close()
+    monkeypatch.setenv("QC_DS_ORDER_FAIL", "1")
+    s2 = q.System(m)
+    G2 = s2.fock_rhf(D)
+    assert np.array_equal(G2, s2.fock_rhf(D)) and np.array_equal(G2, G2.T)
+    assert np.abs(G2 - G).max() < 1e-12 * max(1.0, np.abs(G).max())
+    s2.close()
+
+
 def test_dispatch_lanes_are_measured():
     """qc_lane_probe: the handle's side streams fall into dispatch lanes (streams that share a pipe wait for each other's grids); the
     assignment slots list every side stream once, the lanes first.  On an MI355X with GPU_MAX_HW_QUEUES=8 (set by hf.py) there are four."""
