@@ -883,11 +883,12 @@ def test_startup_stages_match_oracle(mol, basis):
     assert abs(np.sum(D0 * S_ref) - 2 * (s.n_electrons() // 2)) < 1e-9          # tr(D S) = N
 
 
-@pytest.mark.parametrize("mol,basis", [("water", "cc-pVDZ"), ("ethylene", "STO-3G")])
+@pytest.mark.parametrize("mol,basis", [("water", "cc-pVDZ"), ("ethylene", "STO-3G"), ("water", "cc-pVTZ"), ("ethylene", "6-31G_st_st")])
 def test_rhf_passes_match_oracle_one_by_one(mol, basis):
     """Every pass of the loop body (rhf.rs:67-88) against the oracle's trace: energy and density rms of pass k agree, so guess,
     DIIS window growth (passthrough below 4 samples, extrapolation from the 4th on, diis.rs:28-59), eigensolve and density
-    update are each pinned - not only the converged end point."""
+    update are each pinned - not only the converged end point.  (water / cc-pVTZ is BASELINE's headline configuration: f shells, the
+    one-workgroup Roothaan kernel with its tridiagonal and refinement eigensolves, 8 launches on the dispatch lanes.)"""
     q, s, o = _sys(mol, basis)
     ref = o.rhf(100, 1e-10, trace=True)
     st = q.ScfStepper(s)
