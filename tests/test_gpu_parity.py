@@ -771,7 +771,7 @@ def test_schwarz_factors_and_screening():
     assert np.abs(G_all - G).max() < TOL_INT * max(1.0, np.abs(G_ref).max())
 
 
-@pytest.mark.parametrize("mol,basis,na,nb", [("water", "cc-pVDZ", 0, 0), ("oxygen", "cc-pVDZ", 9, 7)])
+@pytest.mark.parametrize("mol,basis,na,nb", [("water", "cc-pVDZ", 0, 0), ("oxygen", "cc-pVDZ", 9, 7), ("water", "cc-pVTZ", 0, 0), ("ethylene", "6-31G_st_st", 0, 0)])
 def test_uhf_passes_match_oracle_one_by_one(mol, basis, na, nb):
     """The UHF loop body (uhf.rs:80-163) pass by pass: both Fock matrices from the OLD densities, per-spin DIIS(2,8), the averaged
     rms of uhf.rs:137 and the energy expression of uhf.rs:145-153 - closed shell under the reference's N/2 rule, and the open-shell
