@@ -36,9 +36,10 @@ def test_library_is_native_and_device_ready():
 
 
 @pytest.mark.parametrize("mol,basis", [("hydrogen", "STO-3G"), ("water", "STO-3G"), ("water", "6-31G_st_st"),
-                                       ("water", "cc-pVDZ"), ("ethylene", "STO-3G"), ("ethylene", "cc-pVDZ")])
+                                       ("water", "cc-pVDZ"), ("ethylene", "STO-3G"), ("ethylene", "cc-pVDZ"), ("water", "cc-pVTZ")])
 def test_eri_tensor_matches_oracle(mol, basis):
-    # (ethylene/cc-pVDZ: C spherical d against H p - the shell classes of benzene/cc-pVDZ, BASELINE config 5)
+    # (ethylene/cc-pVDZ: C spherical d against H p - the shell classes of benzene/cc-pVDZ, BASELINE config 5;
+    #  water/cc-pVTZ: the headline configuration - all 11.3 M elements, f shells included)
     q, s, o = _sys(mol, basis)
     I_gpu, I_cpu = s.eri(), o.eri()
     assert np.abs(I_gpu - I_cpu).max() < TOL_INT
