@@ -496,7 +496,8 @@ int qc_fock_build_device(qc_system *S, const double *dDa, const double *dDb, dou
     // closing fold reads and zeroes every one of them: at n = 58 that is 1.7 MB with 32 replicas, and the H2O/cc-pVTZ iteration takes 0.308 ms
     // with 8 against 0.313 with 32 (0.312 with 16, 0.319 with 4, 0.349 with 2; three alternating runs each); benzene/cc-pVDZ (n = 114) shows
     // no difference between 8, 16 and 32.  QC_NREP_USE: experiment switch.
-    static const int nrep_env = getenv("QC_NREP_USE") ? std::max(1, std::min(QC_NREP, atoi(getenv("QC_NREP_USE")))) : 0;
+    const char *nrep_s = getenv("QC_NREP_USE");                 // (read per build: a test switches it inside one process)
+    const int nrep_env = nrep_s ? std::max(1, std::min(QC_NREP, atoi(nrep_s))) : 0;
     const int nrep_use = nrep_env ? nrep_env : (n <= 64 ? 8 : QC_NREP);
     a.nrep = nrep_use; a.rep_stride = nspin * nn; a.fxs = fxs; a.fx_lo = plane; a.fork_seq = fork_seq;
     if (!ready) {

@@ -484,8 +484,11 @@ def test_launch_structure_switches_do_not_change_a_bit(monkeypatch):
     e0 = q.restricted_hartree_fock(s0, q.HartreeFockConfig(100, 1e-10))
     # (round 4: QC_SPEC - speculative build of the next pass behind the Roothaan step, device-side fork; QC_NO_LANES - launch units drawn
     # among all seven side streams instead of the four dispatch lanes)
+    # (QC_NO_BM_MERGE / QC_NO_T1_MERGE: the merged launches of the small builds apart again - 9 and 11 launches instead of 8; QC_NREP_USE: all
+    # 32 accumulator replicas instead of 8)
     for env in ({"QC_EVENT_JOIN": "1"}, {"QC_ISSUE_THREADS": "3"}, {"QC_ISSUE_THREADS": "2", "QC_EVENT_WAIT": "1"}, {"QC_SPEC": "1"},
-                {"QC_SPEC": "1", "QC_EVENT_WAIT": "1"}, {"QC_NO_LANES": "1"}):
+                {"QC_SPEC": "1", "QC_EVENT_WAIT": "1"}, {"QC_NO_LANES": "1"}, {"QC_NO_BM_MERGE": "1"}, {"QC_NO_T1_MERGE": "1"},
+                {"QC_NO_BM_MERGE": "1", "QC_NO_T1_MERGE": "1", "QC_NREP_USE": "32"}):
         for k, v in env.items():
             monkeypatch.setenv(k, v)
         s = q.System(m)
