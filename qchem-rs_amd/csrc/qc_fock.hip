@@ -875,7 +875,11 @@ static int launch_segments(qc_system *S, int unit, const std::vector<Seg> &segs,
         // (QC_BM_NO_ROWBUF forces the large-n fallback - direct global atomics per bundle - so that tests can reach it)
         t.use_rowbuf = (base.eri_out == nullptr && base.schwarz_out == nullptr && QC_BM_LDS_TABLE + 2 * (iblock + rowbytes) <= lds_max && S->ds_order_ok && !getenv("QC_BM_NO_ROWBUF")) ? 1 : 0;
         const int wbytes = iblock + (t.use_rowbuf ? rowbytes : 0);
-        while (nw > 1 && QC_BM_LDS_TABLE + nw * wbytes > lds_max) nw /= 2;          // Cartesian d / f bras: 36+ rows of I per wave
+        while (nw > 1 && QC_BM_LDS_TABLE + nw * wbytes > lds_max) nw = nw > 4 ? nw - 1 : nw / 2;   // Cartesian d / f bras: 36+ rows of I per wave
+        {   // (QC_BM_NW: experiment switch - at most that many waves per workgroup, so that two workgroups of different launches fit a CU's LDS)
+            static const int nw_env = getenv("QC_BM_NW") ? atoi(getenv("QC_BM_NW")) : 0;
+            if (nw_env > 0) nw = std::min(nw, nw_env);
+        }
         int grid = 0, k = 0;
         for (const Seg &sg : segs) {
             // persistent workgroups of `nw` waves: at most ~12 waves per CU, each wave strides through the bundle list

@@ -6,7 +6,10 @@
 // 1: LAB >= 3); the grid is the concatenation of the classes' bundle lists ("segments"), one wave per bundle.
 // waves per workgroup (they share the LDS Boys table, nothing else); the launcher uses fewer when the I blocks are large
 // (Cartesian d bras).  8 waves for the launches with 13-14 KB I blocks was measured: no gain, the ss-ket ones lose.
-constexpr int qc_bm_waves(int lcd, int hi) { return 4; }
+#ifndef QC_BM_WAVES
+#define QC_BM_WAVES 4
+#endif
+constexpr int qc_bm_waves(int lcd, int hi) { return QC_BM_WAVES; }
 constexpr int QC_BM_LDS_TABLE = ((QC_BOYS_NGRID * 9 + 1) & ~1) * 8;   // bytes of the table at the head of the workgroup's LDS
 struct QcBmArgs {
     QcKernelArgs base;
